@@ -1,0 +1,46 @@
+"""Build ``csrc/libegonet_hip.so`` in-tree with hipcc for gfx950.
+
+    python -m egonet_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The shared object is git-ignored but
+travels with the repo snapshot to the GPU box.
+"""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(CSRC, 'libegonet_hip.so')
+ARCH = 'gfx950'
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+
+
+def needs_build():
+    if not os.path.isfile(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + \
+        [os.path.join(os.path.dirname(HERE), 'include', 'egonet_hip.h')]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-shared', '-fPIC',
+           '-Wno-unused-result', '-o', OUT] + sources()
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(OUT)

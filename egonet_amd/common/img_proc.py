@@ -1,0 +1,88 @@
+"""Key-point decode and crop geometry -- the hot-path subset of the reference's
+``libs/common/img_proc.py`` with the same function names and return values.
+
+Decode runs on the GPU (``csrc/decode.hip``, one wavefront per heat-map):
+  ``soft_arg_max(t)``     reference img_proc.py:678-707 (CUDA tensor in/out)
+  ``get_max_preds(a)``    reference img_proc.py:608-637 (numpy in/out like the
+                          reference; CUDA tensors are accepted and stay on device)
+  ``hard_arg_max(t)``     get_max_preds + the integer arg-max index
+Host helpers (pure Python, per bounding box): ``modify_bbox`` & co.
+(img_proc.py:411-459).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+SIZE = 200.0
+
+
+def _decode(t, mode, want_idx=True):
+    if not (torch.is_tensor(t) and t.is_cuda):
+        raise TypeError('decode kernels need a CUDA tensor; there is no CPU fallback')
+    assert t.dim() == 4, 'batch_images should be 4-ndim'
+    t = t.contiguous().float()
+    n, k, h, w = t.shape
+    xy = torch.empty(n, k, 2, dtype=torch.float32, device=t.device)
+    mx = torch.empty(n, k, 1, dtype=torch.float32, device=t.device)
+    idx = torch.empty(n, k, dtype=torch.int32, device=t.device) if want_idx else None
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.lib().egn_decode_heatmaps_f32(
+            _lib.ptr(t), n, k, h, w, mode, _lib.ptr(xy), _lib.ptr(mx), _lib.ptr(idx),
+            _lib.current_stream(t.device)), 'decode')
+    return xy, mx, idx
+
+
+def soft_arg_max(batch_heatmaps):
+    """Soft-arg-max over each [H,W] map: returns (preds [N,K,2] (x,y) in map
+    pixels, maxvals [N,K,1] = raw maximum)."""
+    xy, mx, _ = _decode(batch_heatmaps, 1, want_idx=False)
+    return xy, mx
+
+
+def hard_arg_max(batch_heatmaps):
+    """(preds, maxvals, flat arg-max index [N,K] int32) on the device."""
+    return _decode(batch_heatmaps, 0, want_idx=True)
+
+
+def get_max_preds(batch_heatmaps):
+    """Hard arg-max.  numpy in -> numpy out (the reference's contract); a CUDA
+    tensor in -> CUDA tensors out."""
+    if isinstance(batch_heatmaps, np.ndarray):
+        assert batch_heatmaps.ndim == 4, 'batch_images should be 4-ndim'
+        t = torch.from_numpy(np.ascontiguousarray(batch_heatmaps, dtype=np.float32)).cuda()
+        xy, mx, _ = _decode(t, 0, want_idx=False)
+        return xy.cpu().numpy(), mx.cpu().numpy()
+    xy, mx, _ = _decode(batch_heatmaps, 0, want_idx=False)
+    return xy, mx
+
+
+# -- bounding-box helpers (host, per box) -----------------------------------
+def enlarge_bbox(left, top, right, bottom, enlarge):
+    cx, cy = (left + right) / 2, (top + bottom) / 2
+    hw, hh = 0.5 * (right - left) * enlarge[0], 0.5 * (bottom - top) * enlarge[1]
+    return [cx - hw, cy - hh, cx + hw, cy + hh]
+
+
+def resize_bbox(left, top, right, bottom, target_ar=1.):
+    width, height = right - left, bottom - top
+    cx, cy = (left + right) / 2, (top + bottom) / 2
+    if height / width > target_ar:
+        half = 0.5 * height * (1 / target_ar)
+        left, right = cx - half, cx + half
+    else:
+        half = 0.5 * width * target_ar
+        top, bottom = cy - half, cy + half
+    return {'bbox': [left, top, right, bottom], 'c': np.array([cx, cy]),
+            's': np.array([(right - left) / SIZE, (bottom - top) / SIZE])}
+
+
+def modify_bbox(bbox, target_ar, enlarge=1.1):
+    box = enlarge_bbox(bbox[0], bbox[1], bbox[2], bbox[3], [enlarge, enlarge])
+    return resize_bbox(box[0], box[1], box[2], box[3], target_ar=target_ar)
+
+
+def to_npy(tensor):
+    return tensor if isinstance(tensor, np.ndarray) else tensor.data.cpu().numpy()

@@ -1,0 +1,85 @@
+// decode.hip -- key-point decode from NCHW heat-maps, one 64-lane wavefront per
+// (n,k) map.  HBM-bound: every map element is read once (hard arg-max) or once
+// from HBM + once from L2/L1 (soft-arg-max second pass over a 16 KB map).
+//
+// hard (img_proc.py:608-637): flat arg-max, first index on ties,
+//   (idx % W, floor(idx / W)), zeroed where max <= 0.
+// soft (img_proc.py:678-707): softmax over the flattened map, then
+//   x = sum_w w * sum_h p, y = sum_h h * sum_w p  ==  sum_i p_i * (x_i, y_i);
+//   maxvals = raw maximum.
+#include "egn_internal.h"
+
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(v, off);
+    const int oi = __shfl_xor(i, off);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ hm, int nmaps, int H, int W,
+                                                     int mode, float* __restrict__ out_xy,
+                                                     float* __restrict__ out_max, int32_t* __restrict__ out_idx) {
+  const int lane = threadIdx.x & 63;
+  const int map = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (map >= nmaps) return;
+  const int hw = H * W;
+  const float* __restrict__ p = hm + (size_t)map * hw;
+
+  // pass 1: maximum and its first index
+  float best = -INFINITY;
+  int bidx = 0x7fffffff;
+  for (int i = lane; i < hw; i += 64) {
+    const float v = p[i];
+    if (v > best) { best = v; bidx = i; }
+  }
+  wave_argmax(best, bidx);
+  if (bidx == 0x7fffffff) bidx = 0;  // all -inf / NaN map: numpy returns index 0
+
+  float ox, oy;
+  if (mode == 0) {
+    ox = (float)(bidx % W);
+    oy = floorf((float)bidx / (float)W);
+    if (!(best > 0.0f)) { ox = 0.f; oy = 0.f; }
+  } else {
+    float s = 0.f, sx = 0.f, sy = 0.f;
+    for (int i = lane; i < hw; i += 64) {
+      const float e = __expf(p[i] - best);
+      const int y = i / W;
+      const int x = i - y * W;
+      s += e;
+      sx += e * (float)x;
+      sy += e * (float)y;
+    }
+    s = wave_sum(s);
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    ox = sx / s;
+    oy = sy / s;
+  }
+  if (lane == 0) {
+    out_xy[2 * (size_t)map] = ox;
+    out_xy[2 * (size_t)map + 1] = oy;
+    out_max[map] = best;
+    if (out_idx) out_idx[map] = bidx;
+  }
+}
+
+extern "C" int egn_decode_heatmaps_f32(const float* hm, int N, int K, int H, int W, int mode,
+                                       float* out_xy, float* out_max, int32_t* out_idx, void* stream) {
+  if (N < 0 || K <= 0 || H <= 0 || W <= 0 || (mode != 0 && mode != 1)) return EGN_E_BADARG;
+  const int nmaps = N * K;
+  if (nmaps == 0) return 0;
+  const int waves_per_block = 4;
+  const int grid = (nmaps + waves_per_block - 1) / waves_per_block;
+  hipLaunchKernelGGL(decode_kernel, dim3(grid), dim3(64 * waves_per_block), 0, (hipStream_t)stream,
+                     hm, nmaps, H, W, mode, out_xy, out_max, out_idx);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,44 @@
+// Internal declarations shared by the HIP translation units of libegonet_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/egonet_hip.h"
+
+#define EGN_CHECK_HIP(expr)                      \
+  do {                                           \
+    hipError_t _e = (expr);                      \
+    if (_e != hipSuccess) return (int)_e;        \
+  } while (0)
+
+// conv chunking constants (the packed-weight format depends on them)
+constexpr int EGN_CK = 16;          // input channels per K chunk
+constexpr int EGN_CKQ = EGN_CK / 4; // float4 planes per chunk
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  float* y;
+  int N, H, W, Cin, cs_in;
+  int Ho, Wo, Cout, cs_out, CoutP;
+  int KH, KW, stride, pad;
+  int TH, TW, TNB;   // output tile: TNB images x TH rows x TW cols
+  int HH, HW;        // input (halo) tile dims per image
+  int npix, npixp;   // halo pixels per tile, rounded up to 16
+  int tiles_x, tiles_y;
+  int nchunk, taps, tps;  // K chunks, taps = KH*KW, taps per LDS stage
+  int act, out_nchw;
+};
+
+struct ConvConfig {
+  int id;
+  int wm, wn, mt, nt;  // waves in M/N, 16x16 sub-tiles per wave in M/N
+  int tile_m() const { return wm * mt * 16; }
+  int tile_n() const { return wn * nt * 16; }
+  int threads() const { return 64 * wm * wn; }
+};
+
+int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream);
+int egn_conv_plan(ConvArgs& a, int& cfg_id, size_t& lds_bytes);

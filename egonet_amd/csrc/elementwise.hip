@@ -1,0 +1,151 @@
+// elementwise.hip -- HBM-bound helpers: multi-resolution fuse, layout changes,
+// coordinate ramps.  All float4-vectorised over the NHWC channel axis
+// (channel stride cs is a multiple of 4), grid-stride loops capped at
+// 256 CUs x 8 blocks.
+#include "egn_internal.h"
+
+struct FuseArgs {
+  float* y;
+  const float* t[4];
+  int shift[4];
+  int nterms;
+  int N, H, W, cs4;  // cs4 = cs / 4
+  int relu;
+};
+
+__global__ __launch_bounds__(256) void fuse_sum_relu_kernel(FuseArgs a) {
+  const size_t total = (size_t)a.N * a.H * a.W * a.cs4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % a.cs4);
+    size_t p = e / a.cs4;
+    const int x = (int)(p % a.W);
+    p /= a.W;
+    const int y = (int)(p % a.H);
+    const int n = (int)(p / a.H);
+    float4 acc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k >= a.nterms) break;
+      const int s = a.shift[k];
+      const int hs = a.H >> s, ws = a.W >> s;
+      const size_t idx = (((size_t)n * hs + (y >> s)) * ws + (x >> s)) * a.cs4 + c4;
+      const float4 v = reinterpret_cast<const float4*>(a.t[k])[idx];
+      if (k == 0) {
+        acc = v;
+      } else {
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+    }
+    if (a.relu) {
+      acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f);
+      acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+    }
+    reinterpret_cast<float4*>(a.y)[e] = acc;
+  }
+}
+
+static inline int grid_for(size_t work_items, int block) {
+  size_t g = (work_items + block - 1) / block;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int egn_fuse_sum_relu_f32(float* y, int N, int H, int W, int C, int cs,
+                                     int nterms, const float* const* terms,
+                                     const int* shifts, int relu, void* stream) {
+  if (nterms < 1 || nterms > 4 || cs % 4 || C > cs) return EGN_E_BADARG;
+  FuseArgs a;
+  a.y = y;
+  for (int k = 0; k < 4; ++k) { a.t[k] = nullptr; a.shift[k] = 0; }
+  for (int k = 0; k < nterms; ++k) {
+    a.t[k] = terms[k];
+    a.shift[k] = shifts[k];
+    if (shifts[k] < 0 || (H >> shifts[k]) << shifts[k] != H || (W >> shifts[k]) << shifts[k] != W)
+      return EGN_E_BADARG;
+  }
+  a.nterms = nterms; a.N = N; a.H = H; a.W = W; a.cs4 = cs / 4; a.relu = relu;
+  const size_t total = (size_t)N * H * W * a.cs4;
+  hipLaunchKernelGGL(fuse_sum_relu_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+// NCHW -> NHWC (channel stride cs, pad channels zeroed).  One thread per
+// (n, y, x, c4): reads 4 planes (coalesced along x across lanes), writes one
+// float4.  Lanes are ordered x-fastest so the plane reads coalesce; the
+// float4 stores of a wave cover 64 consecutive pixels.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int N, int C, int H, int W, int cs4) {
+  const size_t hw = (size_t)H * W;
+  const size_t total = (size_t)N * cs4 * hw;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = e % hw;
+    const size_t r = e / hw;
+    const int c4 = (int)(r % cs4);
+    const int n = (int)(r / cs4);
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c4 * 4 + k;
+      v[k] = c < C ? x[((size_t)n * C + c) * hw + p] : 0.f;
+    }
+    reinterpret_cast<float4*>(y)[((size_t)n * hw + p) * cs4 + c4] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           int N, int C, int H, int W, int cs) {
+  const size_t hw = (size_t)H * W;
+  const size_t total = (size_t)N * C * hw;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const size_t p = e % hw;
+    const size_t r = e / hw;
+    const int c = (int)(r % C);
+    const int n = (int)(r / C);
+    y[e] = x[((size_t)n * hw + p) * cs + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void coord_ramps_kernel(float* __restrict__ y, int N, int H, int W, int cs, int c0) {
+  const size_t total = (size_t)N * H * W;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(e % W);
+    const int yy = (int)((e / W) % H);
+    // np.linspace(0, 1, n)[i] = i * (1/(n-1)) computed in float64, cast to fp32
+    const double fx = W > 1 ? (double)x * (1.0 / (double)(W - 1)) : 0.0;
+    const double fy = H > 1 ? (double)yy * (1.0 / (double)(H - 1)) : 0.0;
+    y[e * cs + c0] = (float)fx;
+    y[e * cs + c0 + 1] = (float)fy;
+  }
+}
+
+extern "C" int egn_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int H, int W, int cs,
+                                    void* stream) {
+  if (cs % 4 || cs < C) return EGN_E_BADARG;
+  const size_t total = (size_t)N * (cs / 4) * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, N, C, H, W, cs / 4);
+  return (int)hipGetLastError();
+}
+
+extern "C" int egn_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int H, int W, int cs,
+                                    void* stream) {
+  if (cs < C) return EGN_E_BADARG;
+  const size_t total = (size_t)N * C * H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, N, C, H, W, cs);
+  return (int)hipGetLastError();
+}
+
+extern "C" int egn_fill_coord_ramps_f32(float* y, int N, int H, int W, int cs, int c0, void* stream) {
+  if (c0 < 0 || c0 + 2 > cs) return EGN_E_BADARG;
+  const size_t total = (size_t)N * H * W;
+  hipLaunchKernelGGL(coord_ramps_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, y, N, H, W, cs, c0);
+  return (int)hipGetLastError();
+}

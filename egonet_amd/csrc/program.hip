@@ -1,0 +1,301 @@
+// program.hip -- C ABI front-end: direct conv entry point and the "program"
+// recorder/executor (a native launch list with slot-relative pointers, hipEvent
+// per-op timing and hipGraph capture/replay).
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "egn_internal.h"
+
+extern "C" int egn_version(void) { return (1 << 16) | 0; }
+
+extern "C" const char* egn_strerror(int code) {
+  if (code == 0) return "ok";
+  if (code == EGN_E_BADARG) return "egonet_hip: bad argument / unsupported shape";
+  if (code == EGN_E_LDS) return "egonet_hip: tile does not fit in LDS";
+  if (code == EGN_E_STATE) return "egonet_hip: program in wrong state";
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "egonet_hip: unknown error";
+}
+
+static int fill_conv_args(ConvArgs& a, const float* x, const float* wpack, const float* scale,
+                          const float* shift, const float* res, float* y, int N, int H, int W, int Cin,
+                          int cs_in, int Cout, int cs_out, int KH, int KW, int stride, int pad, int act,
+                          int out_nchw) {
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.w = wpack; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.cs_in = cs_in;
+  a.Cout = Cout; a.cs_out = cs_out;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+  a.act = act; a.out_nchw = out_nchw;
+  if (out_nchw && res) return EGN_E_BADARG;
+  return 0;
+}
+
+extern "C" int egn_conv2d_f32(const float* x, const float* wpack, const float* scale, const float* shift,
+                              const float* res, float* y, int N, int H, int W, int Cin, int cs_in, int Cout,
+                              int cs_out, int KH, int KW, int stride, int pad, int act, int out_nchw,
+                              int cfg, void* stream) {
+  ConvArgs a;
+  int rc = fill_conv_args(a, x, wpack, scale, shift, res, y, N, H, W, Cin, cs_in, Cout, cs_out, KH, KW,
+                          stride, pad, act, out_nchw);
+  if (rc) return rc;
+  size_t lds;
+  rc = egn_conv_plan(a, cfg, lds);
+  if (rc) return rc;
+  return egn_conv_launch(a, cfg, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------
+// programs
+// ---------------------------------------------------------------------------
+enum OpKind { OP_CONV = 1, OP_FUSE = 2, OP_NCHW2NHWC = 3, OP_NHWC2NCHW = 4, OP_RAMPS = 5, OP_DECODE = 6 };
+
+struct Op {
+  int kind;
+  // conv
+  ConvArgs conv;
+  int cfg;
+  egn_ref r[8];  // pointer refs, meaning depends on kind
+  // generic ints
+  int i[12];
+  std::string tag;
+  double flops, bytes;
+};
+
+struct egn_program {
+  std::vector<void*> slots;
+  std::vector<Op> ops;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+static inline void* resolve(const egn_program* p, const egn_ref& r) {
+  if (r.slot < 0) return nullptr;
+  return (char*)p->slots[r.slot] + r.off;
+}
+static inline bool ref_ok(const egn_program* p, const egn_ref& r) {
+  return r.slot < (int)p->slots.size();
+}
+
+extern "C" egn_program* egn_program_create(int nslots) {
+  if (nslots < 1 || nslots > 64) return nullptr;
+  egn_program* p = new egn_program();
+  p->slots.assign(nslots, nullptr);
+  return p;
+}
+
+extern "C" void egn_program_destroy(egn_program* p) {
+  if (!p) return;
+  if (p->exec) hipGraphExecDestroy(p->exec);
+  if (p->graph) hipGraphDestroy(p->graph);
+  delete p;
+}
+
+extern "C" int egn_program_bind(egn_program* p, int slot, void* base) {
+  if (!p || slot < 0 || slot >= (int)p->slots.size()) return EGN_E_BADARG;
+  if (p->slots[slot] != base && p->exec) {  // a captured graph holds the old addresses
+    hipGraphExecDestroy(p->exec); p->exec = nullptr;
+    hipGraphDestroy(p->graph); p->graph = nullptr;
+  }
+  p->slots[slot] = base;
+  return 0;
+}
+
+extern "C" int egn_program_num_ops(const egn_program* p) { return p ? (int)p->ops.size() : 0; }
+
+extern "C" int egn_program_add_conv2d(egn_program* p, egn_ref x, egn_ref wpack, egn_ref scale, egn_ref shift,
+                                      egn_ref res, egn_ref y, int N, int H, int W, int Cin, int cs_in,
+                                      int Cout, int cs_out, int KH, int KW, int stride, int pad, int act,
+                                      int out_nchw, int cfg) {
+  if (!p) return EGN_E_BADARG;
+  Op op;
+  op.kind = OP_CONV;
+  op.flops = op.bytes = 0;
+  int rc = fill_conv_args(op.conv, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, cs_in,
+                          Cout, cs_out, KH, KW, stride, pad, act, out_nchw);
+  if (rc) return rc;
+  if (out_nchw && res.slot >= 0) return EGN_E_BADARG;
+  size_t lds;
+  rc = egn_conv_plan(op.conv, cfg, lds);
+  if (rc) return rc;
+  op.cfg = cfg;
+  op.r[0] = x; op.r[1] = wpack; op.r[2] = scale; op.r[3] = shift; op.r[4] = res; op.r[5] = y;
+  for (int k = 0; k < 6; ++k)
+    if (!ref_ok(p, op.r[k])) return EGN_E_BADARG;
+  op.flops = 2.0 * N * op.conv.Ho * op.conv.Wo * (double)Cout * Cin * KH * KW;
+  p->ops.push_back(op);
+  return 0;
+}
+
+extern "C" int egn_program_add_fuse(egn_program* p, egn_ref y, int N, int H, int W, int C, int cs, int nterms,
+                                    const egn_ref* terms, const int* shifts, int relu) {
+  if (!p || nterms < 1 || nterms > 4 || cs % 4 || C > cs) return EGN_E_BADARG;
+  Op op;
+  op.kind = OP_FUSE;
+  op.flops = op.bytes = 0;
+  op.r[0] = y;
+  for (int k = 0; k < nterms; ++k) {
+    op.r[1 + k] = terms[k];
+    op.i[6 + k] = shifts[k];
+    if (!ref_ok(p, terms[k])) return EGN_E_BADARG;
+  }
+  op.i[0] = N; op.i[1] = H; op.i[2] = W; op.i[3] = C; op.i[4] = cs; op.i[5] = nterms; op.i[10] = relu;
+  p->ops.push_back(op);
+  return 0;
+}
+
+static int add_simple(egn_program* p, int kind, egn_ref a, egn_ref b, int i0, int i1, int i2, int i3, int i4,
+                      int i5) {
+  if (!p || !ref_ok(p, a) || !ref_ok(p, b)) return EGN_E_BADARG;
+  Op op;
+  op.kind = kind;
+  op.flops = op.bytes = 0;
+  op.r[0] = a; op.r[1] = b;
+  op.i[0] = i0; op.i[1] = i1; op.i[2] = i2; op.i[3] = i3; op.i[4] = i4; op.i[5] = i5;
+  p->ops.push_back(op);
+  return 0;
+}
+
+extern "C" int egn_program_add_nchw_to_nhwc(egn_program* p, egn_ref x, egn_ref y, int N, int C, int H, int W,
+                                            int cs) {
+  if (cs % 4 || cs < C) return EGN_E_BADARG;
+  return add_simple(p, OP_NCHW2NHWC, x, y, N, C, H, W, cs, 0);
+}
+extern "C" int egn_program_add_nhwc_to_nchw(egn_program* p, egn_ref x, egn_ref y, int N, int C, int H, int W,
+                                            int cs) {
+  if (cs < C) return EGN_E_BADARG;
+  return add_simple(p, OP_NHWC2NCHW, x, y, N, C, H, W, cs, 0);
+}
+extern "C" int egn_program_add_ramps(egn_program* p, egn_ref y, int N, int H, int W, int cs, int c0) {
+  egn_ref none = {-1, 0};
+  return add_simple(p, OP_RAMPS, y, none, N, H, W, cs, c0, 0);
+}
+extern "C" int egn_program_add_decode(egn_program* p, egn_ref hm, int N, int K, int H, int W, int mode,
+                                      egn_ref out_xy, egn_ref out_max, egn_ref out_idx) {
+  if (!p || !ref_ok(p, hm) || !ref_ok(p, out_xy) || !ref_ok(p, out_max) || !ref_ok(p, out_idx))
+    return EGN_E_BADARG;
+  Op op;
+  op.kind = OP_DECODE;
+  op.flops = op.bytes = 0;
+  op.r[0] = hm; op.r[1] = out_xy; op.r[2] = out_max; op.r[3] = out_idx;
+  op.i[0] = N; op.i[1] = K; op.i[2] = H; op.i[3] = W; op.i[4] = mode;
+  p->ops.push_back(op);
+  return 0;
+}
+
+extern "C" int egn_program_tag(egn_program* p, const char* tag, double flops, double bytes) {
+  if (!p || p->ops.empty()) return EGN_E_STATE;
+  Op& op = p->ops.back();
+  op.tag = tag ? tag : "";
+  if (flops > 0) op.flops = flops;
+  op.bytes = bytes;
+  return 0;
+}
+
+extern "C" int egn_program_op_info(const egn_program* p, int i, int* kind, double* flops, double* bytes,
+                                   char* tag, int tag_len) {
+  if (!p || i < 0 || i >= (int)p->ops.size()) return EGN_E_BADARG;
+  const Op& op = p->ops[i];
+  if (kind) *kind = op.kind;
+  if (flops) *flops = op.flops;
+  if (bytes) *bytes = op.bytes;
+  if (tag && tag_len > 0) {
+    strncpy(tag, op.tag.c_str(), tag_len - 1);
+    tag[tag_len - 1] = 0;
+  }
+  return 0;
+}
+
+static int launch_op(egn_program* p, Op& op, hipStream_t s) {
+  switch (op.kind) {
+    case OP_CONV: {
+      ConvArgs a = op.conv;
+      a.x = (const float*)resolve(p, op.r[0]);
+      a.w = (const float*)resolve(p, op.r[1]);
+      a.scale = (const float*)resolve(p, op.r[2]);
+      a.shift = (const float*)resolve(p, op.r[3]);
+      a.res = (const float*)resolve(p, op.r[4]);
+      a.y = (float*)resolve(p, op.r[5]);
+      return egn_conv_launch(a, op.cfg, s);
+    }
+    case OP_FUSE: {
+      const float* terms[4];
+      int shifts[4];
+      for (int k = 0; k < op.i[5]; ++k) {
+        terms[k] = (const float*)resolve(p, op.r[1 + k]);
+        shifts[k] = op.i[6 + k];
+      }
+      return egn_fuse_sum_relu_f32((float*)resolve(p, op.r[0]), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4],
+                                   op.i[5], terms, shifts, op.i[10], s);
+    }
+    case OP_NCHW2NHWC:
+      return egn_nchw_to_nhwc_f32((const float*)resolve(p, op.r[0]), (float*)resolve(p, op.r[1]), op.i[0],
+                                  op.i[1], op.i[2], op.i[3], op.i[4], s);
+    case OP_NHWC2NCHW:
+      return egn_nhwc_to_nchw_f32((const float*)resolve(p, op.r[0]), (float*)resolve(p, op.r[1]), op.i[0],
+                                  op.i[1], op.i[2], op.i[3], op.i[4], s);
+    case OP_RAMPS:
+      return egn_fill_coord_ramps_f32((float*)resolve(p, op.r[0]), op.i[0], op.i[1], op.i[2], op.i[3],
+                                      op.i[4], s);
+    case OP_DECODE:
+      return egn_decode_heatmaps_f32((const float*)resolve(p, op.r[0]), op.i[0], op.i[1], op.i[2], op.i[3],
+                                     op.i[4], (float*)resolve(p, op.r[1]), (float*)resolve(p, op.r[2]),
+                                     (int32_t*)resolve(p, op.r[3]), s);
+  }
+  return EGN_E_BADARG;
+}
+
+extern "C" int egn_program_run(egn_program* p, void* stream) {
+  if (!p) return EGN_E_BADARG;
+  for (Op& op : p->ops) {
+    int rc = launch_op(p, op, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int egn_program_run_timed(egn_program* p, void* stream, float* ms, int n_ms) {
+  if (!p || !ms || n_ms < (int)p->ops.size()) return EGN_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = p->ops.size();
+  std::vector<hipEvent_t> ev(n + 1);
+  for (auto& e : ev) EGN_CHECK_HIP(hipEventCreate(&e));
+  int rc = 0;
+  EGN_CHECK_HIP(hipEventRecord(ev[0], s));
+  for (size_t i = 0; i < n && !rc; ++i) {
+    rc = launch_op(p, p->ops[i], s);
+    if (!rc) rc = (int)hipEventRecord(ev[i + 1], s);
+  }
+  if (!rc) rc = (int)hipStreamSynchronize(s);
+  if (!rc)
+    for (size_t i = 0; i < n; ++i) {
+      float t = 0.f;
+      hipEventElapsedTime(&t, ev[i], ev[i + 1]);
+      ms[i] = t;
+    }
+  for (auto& e : ev) hipEventDestroy(e);
+  return rc;
+}
+
+extern "C" int egn_program_capture(egn_program* p, void* stream) {
+  if (!p) return EGN_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (p->exec) { hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+  if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
+  EGN_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  int rc = egn_program_run(p, stream);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(s, &g);
+  if (rc) { if (g) hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) return (int)e;
+  p->graph = g;
+  EGN_CHECK_HIP(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
+  return 0;
+}
+
+extern "C" int egn_program_replay(egn_program* p, void* stream) {
+  if (!p || !p->exec) return EGN_E_STATE;
+  return (int)hipGraphLaunch(p->exec, (hipStream_t)stream);
+}

@@ -1,0 +1,577 @@
+"""Execution engines: turn a parameter-owning ``nn.Module`` into a native launch
+program of gfx950 HIP kernels (C ABI: include/egonet_hip.h).
+
+``HRNetEngine``   backbone + heads        (reference hrnet.py:563-614)
+``LifterEngine``  2D->3D residual MLP      (reference FCmodel.py:92-105)
+
+A program is recorded once per (device, batch shape):
+  * ``_Recorder`` walks the module tree and records symbolic ops on symbolic
+    NHWC buffers (channel stride rounded up to 4);
+  * buffer lifetimes are derived from the op list and packed into ONE activation
+    arena by a best-fit free-list allocator (an HRNet-W48 forward at B=64 needs
+    a few hundred MB instead of ~18 GB of distinct outputs, so the working set
+    of neighbouring layers stays inside the 256 MB Infinity Cache);
+  * weights are folded (BatchNorm -> per-channel scale/shift) and prepacked into
+    ONE device blob in the layout the conv kernel stages through LDS;
+  * the ops are emitted into a native ``egn_program`` whose pointers are
+    (slot, offset) pairs: slot 0 arena, 1 weights, 2.. user tensors.
+A forward is then a single C call that issues ~320 kernel launches.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import Ref, NULL_REF, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY
+
+CK = 16                 # input channels per K chunk (EGN_CK in csrc/egn_internal.h)
+ACT_RES_AFTER = 0x10
+BN_EPS_DEFAULT = 1e-5
+SLOT_ARENA, SLOT_WEIGHTS, SLOT_USER0 = 0, 1, 2
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+# ---------------------------------------------------------------------------
+# weight packing
+# ---------------------------------------------------------------------------
+def pack_conv_weight(w):
+    """[Cout,Cin,KH,KW] -> flat fp32 [nchunk][KH*KW][CK/4][CoutP][4]
+    (ci = chunk*16 + quad*4 + r; zero padded)."""
+    w = w.detach().to(torch.float32).cpu()
+    cout, cin, kh, kw = w.shape
+    coutp = _round_up(cout, 16)
+    nchunk = (cin + CK - 1) // CK
+    wp = torch.zeros(coutp, nchunk * CK, kh * kw, dtype=torch.float32)
+    wp[:cout, :cin] = w.reshape(cout, cin, kh * kw)
+    wp = wp.view(coutp, nchunk, CK // 4, 4, kh * kw).permute(1, 4, 2, 0, 3).contiguous()
+    return wp.reshape(-1)
+
+
+def fold_scale_shift(cout, bias=None, bn=None):
+    """Per-channel (scale, shift) so that  bn(conv(x) + bias) == conv(x)*scale + shift,
+    eval-mode BatchNorm (running stats).  Computed in float64, stored fp32,
+    zero padded to CoutP."""
+    coutp = _round_up(cout, 16)
+    scale = torch.ones(cout, dtype=torch.float64)
+    shift = torch.zeros(cout, dtype=torch.float64)
+    if bias is not None:
+        shift = bias.detach().double().cpu().clone()
+    if bn is not None:
+        g = bn.weight.detach().double().cpu() if bn.weight is not None else torch.ones(cout, dtype=torch.float64)
+        b = bn.bias.detach().double().cpu() if bn.bias is not None else torch.zeros(cout, dtype=torch.float64)
+        inv = 1.0 / torch.sqrt(bn.running_var.detach().double().cpu() + bn.eps)
+        s = g * inv
+        shift = b + (shift - bn.running_mean.detach().double().cpu()) * s
+        scale = s
+    out_s = torch.zeros(coutp, dtype=torch.float32)
+    out_b = torch.zeros(coutp, dtype=torch.float32)
+    out_s[:cout] = scale.float()
+    out_b[:cout] = shift.float()
+    return out_s, out_b
+
+
+# ---------------------------------------------------------------------------
+# symbolic recording
+# ---------------------------------------------------------------------------
+class Buf(object):
+    """Symbolic fp32 tensor.  NHWC [n,h,w,cs] (cs = channel stride) in the arena,
+    or an external user tensor bound to ``slot``."""
+    __slots__ = ('n', 'h', 'w', 'c', 'cs', 'slot', 'off', 'nbytes', 'first', 'last', 'name')
+
+    def __init__(self, n, h, w, c, cs=None, slot=SLOT_ARENA, nbytes=None, name=''):
+        self.n, self.h, self.w, self.c = n, h, w, c
+        self.cs = _round_up(c, 4) if cs is None else cs
+        self.slot = slot
+        self.off = 0
+        self.nbytes = nbytes if nbytes is not None else n * h * w * self.cs * 4
+        self.first = self.last = -1
+        self.name = name
+
+    def ref(self):
+        return Ref(self.slot, self.off)
+
+
+class _Recorder(object):
+    def __init__(self):
+        self.ops = []          # (kind, dict)
+        self.blobs = []        # list of 1-D fp32 tensors -> weights blob
+        self.blob_off = 0
+        self.bufs = []
+
+    # -- storage --
+    def new(self, n, h, w, c, name=''):
+        b = Buf(n, h, w, c, name=name)
+        self.bufs.append(b)
+        return b
+
+    def weight(self, t):
+        off = self.blob_off
+        self.blobs.append(t)
+        self.blob_off += _round_up(t.numel() * 4, 256)
+        return Ref(SLOT_WEIGHTS, off)
+
+    def _touch(self, *bufs):
+        i = len(self.ops)
+        for b in bufs:
+            if b is None:
+                continue
+            if b.first < 0:
+                b.first = i
+            b.last = i
+
+    # -- ops --
+    def conv(self, x, weight, bias=None, bn=None, act=ACT_NONE, res=None, stride=1, pad=0,
+             dst=None, out_nchw=False, cout_cs=None, tag=''):
+        cout, cin, kh, kw = weight.shape
+        assert cin == x.c, (cin, x.c, tag)
+        ho = (x.h + 2 * pad - kh) // stride + 1
+        wo = (x.w + 2 * pad - kw) // stride + 1
+        if dst is None:
+            dst = self.new(x.n, ho, wo, cout, name=tag)
+            if cout_cs is not None:
+                dst.cs = cout_cs
+                dst.nbytes = x.n * ho * wo * cout_cs * 4
+        scale, shift = fold_scale_shift(cout, bias, bn)
+        op = dict(x=x, w=self.weight(pack_conv_weight(weight)), scale=self.weight(scale),
+                  shift=self.weight(shift), res=res, y=dst, cin=cin, cout=cout, kh=kh, kw=kw,
+                  stride=stride, pad=pad, act=act, out_nchw=int(out_nchw), ho=ho, wo=wo, tag=tag)
+        self._touch(x, res, dst)
+        self.ops.append(('conv', op))
+        return dst
+
+    def fuse(self, terms, relu, tag=''):
+        """terms: list of (Buf, shift); output resolution = that of a shift-0 term."""
+        base = [t for t, s in terms if s == 0][0]
+        y = self.new(base.n, base.h, base.w, base.c, name=tag)
+        self._touch(y, *[t for t, _ in terms])
+        self.ops.append(('fuse', dict(y=y, terms=terms, relu=int(relu), tag=tag)))
+        return y
+
+    def nchw_to_nhwc(self, x_ext, n, c, h, w, tag=''):
+        y = self.new(n, h, w, c, name=tag)
+        self._touch(y)
+        self.ops.append(('to_nhwc', dict(x=x_ext, y=y, tag=tag)))
+        return y
+
+    def nhwc_to_nchw(self, x, c, dst_ext, tag=''):
+        self._touch(x)
+        self.ops.append(('to_nchw', dict(x=x, y=dst_ext, c=c, tag=tag)))
+
+    def ramps(self, y, c0, tag=''):
+        self._touch(y)
+        self.ops.append(('ramps', dict(y=y, c0=c0, tag=tag)))
+
+    def decode(self, hm_ext, n, k, h, w, mode, xy, mx, idx, tag=''):
+        self.ops.append(('decode', dict(hm=hm_ext, n=n, k=k, h=h, w=w, mode=mode, xy=xy, mx=mx,
+                                        idx=idx, tag=tag)))
+
+    # -- finalisation --
+    def plan_arena(self):
+        """Greedy best-fit packing of arena buffers by lifetime; returns bytes."""
+        live = [b for b in self.bufs if b.slot == SLOT_ARENA and b.first >= 0]
+        events = sorted(live, key=lambda b: b.first)
+        free = []              # (off, size)
+        active = []            # (last, buf)
+        top = 0
+        for b in events:
+            # release buffers whose last use is before this definition
+            still = []
+            for last, ab in active:
+                if last < b.first:
+                    free.append((ab.off, _round_up(ab.nbytes, 256)))
+                else:
+                    still.append((last, ab))
+            active = still
+            # coalesce
+            free.sort()
+            merged = []
+            for off, sz in free:
+                if merged and merged[-1][0] + merged[-1][1] == off:
+                    merged[-1] = (merged[-1][0], merged[-1][1] + sz)
+                else:
+                    merged.append((off, sz))
+            free = merged
+            need = _round_up(b.nbytes, 256)
+            best = None
+            for i, (off, sz) in enumerate(free):
+                if sz >= need and (best is None or sz < free[best][1]):
+                    best = i
+            if best is None:
+                # grow: extend a free block that ends at the top if there is one
+                if free and free[-1][0] + free[-1][1] == top:
+                    off, sz = free.pop()
+                    b.off = off
+                    top = off + need
+                else:
+                    b.off = top
+                    top += need
+            else:
+                off, sz = free.pop(best)
+                b.off = off
+                if sz > need:
+                    free.append((off + need, sz - need))
+            active.append((b.last, b))
+        return top
+
+    def weights_blob(self, device):
+        blob = torch.zeros(max(self.blob_off, 256) // 4, dtype=torch.float32)
+        off = 0
+        for t in self.blobs:
+            blob[off // 4: off // 4 + t.numel()] = t
+            off += _round_up(t.numel() * 4, 256)
+        return blob.to(device)
+
+
+class Program(object):
+    """Owns a native egn_program plus the torch storage its slots point to."""
+
+    def __init__(self, rec, device, n_user_slots):
+        L = _lib.lib()
+        self.lib = L
+        self.device = device
+        arena_bytes = rec.plan_arena()
+        self.arena = torch.zeros(max(arena_bytes, 256) // 4, dtype=torch.float32, device=device)
+        self.weights = rec.weights_blob(device)
+        self.handle = C.c_void_p(L.egn_program_create(SLOT_USER0 + n_user_slots))
+        if not self.handle:
+            raise _lib.EgonetHipError('egn_program_create failed')
+        self.arena_bytes = arena_bytes
+        self.weight_bytes = rec.blob_off
+        self.tags = []
+        self.meta = []
+        _lib.check(L.egn_program_bind(self.handle, SLOT_ARENA, _lib.ptr(self.arena)))
+        _lib.check(L.egn_program_bind(self.handle, SLOT_WEIGHTS, _lib.ptr(self.weights)))
+        for kind, op in rec.ops:
+            self._emit(kind, op)
+
+    def _emit(self, kind, op):
+        L, h = self.lib, self.handle
+        flops, nbytes = 0.0, 0.0
+        if kind == 'conv':
+            x, y = op['x'], op['y']
+            res = op['res'].ref() if op['res'] is not None else NULL_REF
+            cs_out = y.cs if not op['out_nchw'] else op['cout']
+            _lib.check(L.egn_program_add_conv2d(
+                h, x.ref(), op['w'], op['scale'], op['shift'], res, y.ref(),
+                x.n, x.h, x.w, op['cin'], x.cs, op['cout'], cs_out, op['kh'], op['kw'],
+                op['stride'], op['pad'], op['act'], op['out_nchw'], op.get('cfg', 0)), op['tag'])
+            m = x.n * op['ho'] * op['wo']
+            flops = 2.0 * m * op['cout'] * op['cin'] * op['kh'] * op['kw']
+            nbytes = 4.0 * (x.n * x.h * x.w * op['cin'] + m * op['cout'] * (2 if op['res'] is not None else 1)
+                            + op['cout'] * op['cin'] * op['kh'] * op['kw'])
+            klass = 'conv%dx%ds%d %d->%d@%dx%d' % (op['kh'], op['kw'], op['stride'], op['cin'],
+                                                    op['cout'], op['ho'], op['wo'])
+        elif kind == 'fuse':
+            y = op['y']
+            terms = op['terms']
+            refs = (Ref * len(terms))(*[t.ref() for t, _ in terms])
+            shifts = (C.c_int * len(terms))(*[s for _, s in terms])
+            _lib.check(L.egn_program_add_fuse(h, y.ref(), y.n, y.h, y.w, y.c, y.cs, len(terms), refs,
+                                              shifts, op['relu']), op['tag'])
+            nbytes = 4.0 * y.n * y.c * (y.h * y.w + sum((y.h >> s) * (y.w >> s) for _, s in terms))
+            klass = 'fuse%d %d@%dx%d' % (len(terms), y.c, y.h, y.w)
+        elif kind == 'to_nhwc':
+            y = op['y']
+            _lib.check(L.egn_program_add_nchw_to_nhwc(h, op['x'], y.ref(), y.n, y.c, y.h, y.w, y.cs))
+            nbytes = 4.0 * y.n * y.h * y.w * (y.c + y.cs)
+            klass = 'nchw2nhwc %d@%dx%d' % (y.c, y.h, y.w)
+        elif kind == 'to_nchw':
+            x = op['x']
+            _lib.check(L.egn_program_add_nhwc_to_nchw(h, x.ref(), op['y'], x.n, op['c'], x.h, x.w, x.cs))
+            nbytes = 8.0 * x.n * x.h * x.w * op['c']
+            klass = 'nhwc2nchw %d@%dx%d' % (op['c'], x.h, x.w)
+        elif kind == 'ramps':
+            y = op['y']
+            _lib.check(L.egn_program_add_ramps(h, y.ref(), y.n, y.h, y.w, y.cs, op['c0']))
+            nbytes = 8.0 * y.n * y.h * y.w
+            klass = 'ramps'
+        elif kind == 'decode':
+            _lib.check(L.egn_program_add_decode(h, op['hm'], op['n'], op['k'], op['h'], op['w'],
+                                                op['mode'], op['xy'], op['mx'], op['idx']))
+            nbytes = 4.0 * op['n'] * op['k'] * op['h'] * op['w']
+            klass = 'decode%d %dx%d' % (op['mode'], op['h'], op['w'])
+        else:
+            raise ValueError(kind)
+        L.egn_program_tag(h, (op.get('tag') or klass).encode(), flops, nbytes)
+        self.meta.append(dict(kind=kind, klass=klass, tag=op.get('tag', ''), flops=flops, bytes=nbytes))
+
+    def bind(self, slot, tensor):
+        _lib.check(self.lib.egn_program_bind(self.handle, slot, _lib.ptr(tensor)))
+
+    def run(self):
+        _lib.check(self.lib.egn_program_run(self.handle, _lib.current_stream(self.device)), 'program_run')
+
+    def run_timed(self):
+        n = self.lib.egn_program_num_ops(self.handle)
+        ms = (C.c_float * n)()
+        _lib.check(self.lib.egn_program_run_timed(self.handle, _lib.current_stream(self.device), ms, n))
+        return np.array(ms[:], dtype=np.float64)
+
+    def capture(self):
+        _lib.check(self.lib.egn_program_capture(self.handle, _lib.current_stream(self.device)))
+
+    def replay(self):
+        _lib.check(self.lib.egn_program_replay(self.handle, _lib.current_stream(self.device)))
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.egn_program_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------
+# HRNet
+# ---------------------------------------------------------------------------
+def _act_of(seq):
+    return ACT_RELU if any(isinstance(m, nn.ReLU) for m in seq) else ACT_NONE
+
+
+class HRNetEngine(object):
+    """Runs ``PoseHighResolutionNet`` (eval mode) on one GPU as HIP kernels."""
+
+    def __init__(self, model):
+        self.model = model
+        self.programs = {}        # (device, N, H, W, decode) -> Program
+        self._stamp = None
+
+    # -- recording ---------------------------------------------------------
+    def _block(self, r, x, blk, tag):
+        y = x
+        for i in range(1, blk.depth + 1):
+            conv = getattr(blk, 'conv%d' % i)
+            bn = getattr(blk, 'bn%d' % i)
+            k = conv.kernel_size[0]
+            if i < blk.depth:
+                y = r.conv(y, conv.weight, None, bn, ACT_RELU, None, conv.stride[0], conv.padding[0],
+                           tag='%s.conv%d' % (tag, i))
+            else:
+                if blk.downsample is None:
+                    res = x
+                else:
+                    pc, pb = blk.downsample[0], blk.downsample[1]
+                    res = r.conv(x, pc.weight, None, pb, ACT_NONE, None, pc.stride[0], 0,
+                                 tag=tag + '.downsample')
+                y = r.conv(y, conv.weight, None, bn, ACT_RELU, res, conv.stride[0], conv.padding[0],
+                           tag='%s.conv%d' % (tag, i))
+        return y
+
+    def _unit_chain(self, r, x, seq_of_units, tag):
+        """Sequential of Sequential(conv, bn[, relu]) (transition / fuse down paths)."""
+        t = x
+        for s, unit in enumerate(seq_of_units):
+            conv, bn = unit[0], unit[1]
+            t = r.conv(t, conv.weight, None, bn, _act_of(unit), None, conv.stride[0], conv.padding[0],
+                       tag='%s.%d' % (tag, s))
+        return t
+
+    def _module(self, r, xs, mod, tag):
+        xs = list(xs)
+        for b, branch in enumerate(mod.branches):
+            for k, blk in enumerate(branch):
+                xs[b] = self._block(r, xs[b], blk, '%s.branches.%d.%d' % (tag, b, k))
+        if mod.fuse_layers is None:
+            return xs
+        outs = []
+        for i, row in enumerate(mod.fuse_layers):
+            terms = []
+            for j in range(mod.num_branches):
+                q = '%s.fuse_layers.%d.%d' % (tag, i, j)
+                if row[j] is None:
+                    terms.append((xs[j], 0))
+                elif j > i:
+                    conv, bn = row[j][0], row[j][1]
+                    t = r.conv(xs[j], conv.weight, None, bn, ACT_NONE, None, 1, 0, tag=q)
+                    terms.append((t, j - i))
+                else:
+                    terms.append((self._unit_chain(r, xs[j], row[j], q), 0))
+            outs.append(r.fuse(terms, True, tag='%s.fuse%d' % (tag, i)))
+        return outs
+
+    def _record(self, n, cin, h, w, decode_mode):
+        m = self.model
+        r = _Recorder()
+        x = r.nchw_to_nhwc(Ref(SLOT_USER0, 0), n, cin, h, w, tag='input')
+        t = r.conv(x, m.conv1.weight, None, m.bn1, ACT_RELU, None, 2, 1, tag='conv1')
+        t = r.conv(t, m.conv2.weight, None, m.bn2, ACT_RELU, None, 2, 1, tag='conv2')
+        for k, blk in enumerate(m.layer1):
+            t = self._block(r, t, blk, 'layer1.%d' % k)
+        ys = [t]
+        for idx in (1, 2, 3):
+            trans = getattr(m, 'transition%d' % idx)
+            xs = []
+            for i, tr in enumerate(trans):
+                if tr is None:
+                    xs.append(ys[i])
+                elif isinstance(tr[0], nn.Conv2d):      # conv, bn, relu
+                    xs.append(r.conv(ys[-1], tr[0].weight, None, tr[1], ACT_RELU, None, 1, 1,
+                                     tag='transition%d.%d' % (idx, i)))
+                else:
+                    xs.append(self._unit_chain(r, ys[-1], tr, 'transition%d.%d' % (idx, i)))
+            for k, mod in enumerate(getattr(m, 'stage%d' % (idx + 1))):
+                xs = self._module(r, xs, mod, 'stage%d.%d' % (idx + 1, k))
+            ys = xs
+        trunk = ys[0]
+        J = m.num_joints
+        mh, mw = trunk.h, trunk.w
+        maps_ext = Ref(SLOT_USER0 + 1, 0)
+        out_shapes = {'maps': (n, J, mh, mw)}
+        if m.head_type == 'heatmap':
+            fl = m.final_layer
+            buf = Buf(n, mh, mw, J, cs=J, slot=SLOT_USER0 + 1, name='maps')
+            r.conv(trunk, fl.weight, fl.bias, None, ACT_NONE, None, 1, fl.padding[0], dst=buf,
+                   out_nchw=True, tag='final_layer')
+            nslots = 2
+        else:
+            h1 = m.head1[0]
+            aug = r.conv(trunk, h1.weight, h1.bias, None, ACT_NONE, None, 1, 0,
+                         cout_cs=_round_up(J + 2, 4), tag='head1')
+            r.ramps(aug, J, tag='coor_maps')
+            r.nhwc_to_nchw(aug, J, maps_ext, tag='maps_nchw')
+            aug.c = J + 2
+            t = aug
+            for k in range(4):
+                t = self._block(r, t, m.head2[k], 'head2.%d' % k)
+            fc = m.head2[4]
+            if t.h != fc.kernel_size[0] or t.w != fc.kernel_size[1]:
+                raise ValueError('coordinate head expects a %s map, got %dx%d'
+                                 % (fc.kernel_size, t.h, t.w))
+            cbuf = Buf(n, 1, 1, 2 * J, cs=2 * J, slot=SLOT_USER0 + 2, name='coords')
+            r.conv(t, fc.weight, fc.bias, None, ACT_SIGMOID, None, 1, 0, dst=cbuf, out_nchw=True,
+                   tag='head2.4')
+            out_shapes['coords'] = (n, J, 2)
+            nslots = 3
+        if decode_mode is not None:
+            r.decode(maps_ext, n, J, mh, mw, decode_mode, Ref(SLOT_USER0 + nslots, 0),
+                     Ref(SLOT_USER0 + nslots + 1, 0), Ref(SLOT_USER0 + nslots + 2, 0), tag='decode')
+            out_shapes['decode_slot'] = SLOT_USER0 + nslots
+            nslots += 3
+        return r, nslots, out_shapes
+
+    def _stamp_now(self):
+        p = next(self.model.parameters())
+        return (p.data_ptr(), p._version, p.device)
+
+    def program(self, x, decode_mode=None):
+        stamp = self._stamp_now()
+        if stamp != self._stamp:
+            self.programs.clear()
+            self._stamp = stamp
+        n, c, h, w = x.shape
+        key = (x.device, n, c, h, w, decode_mode)
+        prog = self.programs.get(key)
+        if prog is None:
+            if h % 32 or w % 32:
+                raise ValueError('HRNet input height/width must be multiples of 32, got %dx%d' % (h, w))
+            rec, nslots, shapes = self._record(n, c, h, w, decode_mode)
+            prog = Program(rec, x.device, nslots)
+            prog.out_shapes = shapes
+            self.programs[key] = prog
+        return prog
+
+    # -- execution ---------------------------------------------------------
+    def forward(self, x, decode_mode=None, timed=False):
+        """x [N,C,H,W] fp32 CUDA.  Returns what the module's forward returns;
+        with decode_mode 0/1 additionally (xy[N,K,2], maxvals[N,K,1], idx[N,K])."""
+        if x.dtype != torch.float32:
+            raise TypeError('egonet_amd HRNet engine computes in fp32, got %s' % x.dtype)
+        x = x.contiguous()
+        with torch.cuda.device(x.device):
+            prog = self.program(x, decode_mode)
+            shp = prog.out_shapes
+            maps = torch.empty(shp['maps'], dtype=torch.float32, device=x.device)
+            prog.bind(SLOT_USER0, x)
+            prog.bind(SLOT_USER0 + 1, maps)
+            outs = maps
+            if 'coords' in shp:
+                coords = torch.empty(shp['coords'], dtype=torch.float32, device=x.device)
+                prog.bind(SLOT_USER0 + 2, coords)
+                outs = (maps, coords)
+            dec = None
+            if decode_mode is not None:
+                n, k = shp['maps'][:2]
+                xy = torch.empty(n, k, 2, dtype=torch.float32, device=x.device)
+                mx = torch.empty(n, k, 1, dtype=torch.float32, device=x.device)
+                idx = torch.empty(n, k, dtype=torch.int32, device=x.device)
+                s = shp['decode_slot']
+                prog.bind(s, xy)
+                prog.bind(s + 1, mx)
+                prog.bind(s + 2, idx)
+                dec = (xy, mx, idx)
+            if timed:
+                self.last_ms = prog.run_timed()
+            else:
+                prog.run()
+        return outs if dec is None else (outs, dec)
+
+
+# ---------------------------------------------------------------------------
+# lifter
+# ---------------------------------------------------------------------------
+class LifterEngine(object):
+    """Runs ``FCModel`` (eval mode) as six fused GEMM launches (Linear + folded
+    BatchNorm1d + ReLU (+ residual)); a Linear is a 1x1 convolution on
+    [N,1,1,C]."""
+
+    def __init__(self, model):
+        self.model = model
+        self.programs = {}
+        self._stamp = None
+
+    def _record(self, n, ld_in=None):
+        m = self.model
+        act = ACT_LEAKY if m.leaky else ACT_RELU
+        r = _Recorder()
+        cin = m.w1.in_features
+        if ld_in is None:
+            x = r.nchw_to_nhwc(Ref(SLOT_USER0, 0), n, cin, 1, 1, tag='input')
+        else:                      # caller provides [n, ld_in] rows already padded
+            x = Buf(n, 1, 1, cin, cs=ld_in, slot=SLOT_USER0, name='input')
+
+        def lin(t, fc, bn, a, res, tag, dst=None, nchw=False):
+            return r.conv(t, fc.weight.view(fc.out_features, fc.in_features, 1, 1), fc.bias, bn, a,
+                          res, 1, 0, dst=dst, out_nchw=nchw, tag=tag)
+
+        y = lin(x, m.w1, m.batch_norm1, act, None, 'w1')
+        for b, blk in enumerate(m.res_blocks):
+            z = lin(y, blk.w1, blk.batch_norm1, act, None, 'res%d.w1' % b)
+            y = lin(z, blk.w2, blk.batch_norm2, act | ACT_RES_AFTER, y, 'res%d.w2' % b)
+        out = Buf(n, 1, 1, m.w2.out_features, cs=m.w2.out_features, slot=SLOT_USER0 + 1, name='out')
+        lin(y, m.w2, None, ACT_NONE, None, 'w2', dst=out, nchw=True)
+        return r
+
+    def program(self, device, n, ld_in=None):
+        p = next(self.model.parameters())
+        stamp = (p.data_ptr(), p._version, p.device)
+        if stamp != self._stamp:
+            self.programs.clear()
+            self._stamp = stamp
+        key = (device, n, ld_in)
+        prog = self.programs.get(key)
+        if prog is None:
+            prog = Program(self._record(n, ld_in), device, 2)
+            self.programs[key] = prog
+        return prog
+
+    def forward(self, x, ld_in=None):
+        """x [N,in] fp32 CUDA (or [N,ld_in] zero-padded rows) -> [N,out]."""
+        if x.dtype != torch.float32:
+            raise TypeError('egonet_amd lifter engine computes in fp32, got %s' % x.dtype)
+        x = x.contiguous()
+        n = x.shape[0]
+        out = torch.empty(n, self.model.w2.out_features, dtype=torch.float32, device=x.device)
+        if n == 0:
+            return out
+        with torch.cuda.device(x.device):
+            prog = self.program(x.device, n, ld_in)
+            prog.bind(SLOT_USER0, x)
+            prog.bind(SLOT_USER0 + 1, out)
+            prog.run()
+        return out

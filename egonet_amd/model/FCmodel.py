@@ -1,0 +1,102 @@
+"""Fully-connected 2D->3D lifter -- MI355X build.
+
+Drop-in for the reference's ``libs/model/FCmodel.py``: ``get_fc_model(stage_id,
+cfgs, input_size, output_size)`` (FCmodel.py:107-121) returns a module with the
+reference's ``forward`` / ``get_representation`` contract and ``state_dict``
+layout (37 entries: ``w1, batch_norm1, res_blocks.{i}.{w1,batch_norm1,w2,
+batch_norm2}, w2``), so ``L.pth`` loads unchanged.
+
+Eval-mode CUDA forwards run as six fused fp32-MFMA GEMM launches
+(``egonet_amd.engine.LifterEngine``); CPU tensors and training-mode forwards
+use ``torch.nn.functional`` on the tensor's own device.
+"""
+import torch
+import torch.nn as nn
+
+
+def _activation(leaky):
+    return nn.LeakyReLU(inplace=True) if leaky else nn.ReLU(inplace=True)
+
+
+class ResidualBlock(nn.Module):
+    """x + drop(act(bn2(w2(drop(act(bn1(w1 x)))))))   (FCmodel.py:9-43)."""
+
+    def __init__(self, num_neurons, p_dropout=0.5, kaiming=False, leaky=False):
+        super().__init__()
+        self.num_neurons, self.p_dropout, self.leaky = num_neurons, p_dropout, leaky
+        self.relu = _activation(leaky)
+        self.dropout = nn.Dropout(p_dropout)
+        for i in (1, 2):
+            fc = nn.Linear(num_neurons, num_neurons)
+            if kaiming:
+                nn.init.kaiming_normal_(fc.weight.data)
+            setattr(self, 'w%d' % i, fc)
+            setattr(self, 'batch_norm%d' % i, nn.BatchNorm1d(num_neurons))
+
+    def forward(self, x):
+        y = x
+        for i in (1, 2):
+            y = getattr(self, 'batch_norm%d' % i)(getattr(self, 'w%d' % i)(y))
+            y = self.dropout(self.relu(y))
+        return x + y
+
+
+class FCModel(nn.Module):
+    """FCmodel.py:45-105."""
+
+    def __init__(self, stage_id=1, num_neurons=1024, num_blocks=2, p_dropout=0.5, norm_twoD=False,
+                 kaiming=False, refine_3d=False, leaky=False, dm=False, input_size=32, output_size=64):
+        super().__init__()
+        self.stage_id, self.num_neurons, self.num_blocks = stage_id, num_neurons, num_blocks
+        self.p_dropout, self.refine_3d, self.leaky, self.dm = p_dropout, refine_3d, leaky, dm
+        self.input_size, self.output_size = input_size, output_size
+        self.w1 = nn.Linear(input_size, num_neurons)
+        self.batch_norm1 = nn.BatchNorm1d(num_neurons)
+        self.res_blocks = nn.ModuleList(
+            [ResidualBlock(num_neurons, p_dropout, leaky=leaky) for _ in range(num_blocks)])
+        self.w2 = nn.Linear(num_neurons, output_size)
+        self.relu = _activation(leaky)
+        self.dropout = nn.Dropout(p_dropout)
+        if kaiming:
+            nn.init.kaiming_normal_(self.w1.weight.data)
+            nn.init.kaiming_normal_(self.w2.weight.data)
+        self._engine = None
+
+    def _hip_ok(self, x):
+        return x.is_cuda and not self.training and not torch.is_grad_enabled()
+
+    def _hip_engine(self):
+        from egonet_amd import engine
+        if self._engine is None:
+            self._engine = engine.LifterEngine(self)
+        return self._engine
+
+    def forward(self, x):
+        if self._hip_ok(x):
+            return self._hip_engine().forward(x)
+        return self.w2(self.get_representation(x))
+
+    def get_representation(self, x):
+        y = self.dropout(self.relu(self.batch_norm1(self.w1(x))))
+        for blk in self.res_blocks:
+            y = blk(y)
+        return y
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._engine = None
+        return super().load_state_dict(*a, **k)
+
+
+def get_fc_model(stage_id, cfgs, input_size, output_size, architecture_type='FCModel'):
+    c = cfgs[architecture_type]
+    return FCModel(stage_id=stage_id, refine_3d=c['refine_3d'], norm_twoD=c['norm_twoD'],
+                   num_blocks=c['num_blocks'], input_size=input_size, output_size=output_size,
+                   num_neurons=c['num_neurons'], p_dropout=c['dropout'], leaky=c['leaky'])
+
+
+def get_cascade():
+    return nn.ModuleList([])

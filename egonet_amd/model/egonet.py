@@ -1,0 +1,292 @@
+"""Ego-Net inference orchestrator -- MI355X build.
+
+Mirrors the reference's ``libs/model/egonet.py`` public surface for the hot
+path (``EgoNet(cfgs, pre_trained)``, attributes ``HC, L, LS, resolution,
+xy_dict, pth_trans``; methods ``get_keypoints``, ``lift_2d_to_3d``,
+``get_6d_rep``, ``get_observation_angle_proj/_trans``, ``forward``,
+``post_process``) and adds ``infer_crops``: the whole chain
+
+    crops -> HC -> decode -> x resolution -> inverse crop affine -> normalise
+          -> L -> un-normalise -> cuboid template + Kabsch + euler -> alpha
+
+for a whole batch in one stream of HIP launches with no host round trip, where
+the reference loops over instances in Python (egonet.py:443-453, 469-486,
+279-295).  ``get_keypoints`` / ``lift_2d_to_3d`` are thin record-keeping
+wrappers over that batched path and return the reference's dictionaries.
+
+Crop extraction (``crop_instances``, cv2.warpAffine) and plotting are outside
+the hot path: ``forward(annot_dict)`` needs ``cv2`` and
+imports it lazily.
+"""
+import ctypes as C
+import math
+from os.path import join as pjoin
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from . import FCmodel
+from . import heatmapModel  # noqa: F401  (plugin namespace)
+from ..common.img_proc import modify_bbox, to_npy
+import egonet_amd.model as models  # noqa: F401  (eval() lookup below, like the reference)
+
+
+def _dev_f64(a, device):
+    return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(device)
+
+
+class EgoNet(nn.Module):
+    def __init__(self, cfgs, pre_trained=False):
+        super().__init__()
+        hm = cfgs['heatmapModel']
+        # plugin lookup by name, as in the reference (egonet.py:43-44)
+        self.HC = eval('models.heatmapModel.' + hm['name'] + '.get_pose_net')(cfgs, is_train=False)
+        self.resolution = hm['input_size']
+        self.xy_dict = {'flag': hm['add_xy']} if 'add_xy' in hm else None
+        fc = cfgs['FCModel']
+        self.L = FCmodel.get_fc_model(stage_id=1, cfgs=cfgs, input_size=fc['input_size'],
+                                      output_size=fc['output_size'])
+        self.LS = None
+        self.pth_trans = None
+        if pre_trained:
+            ckpt = cfgs['dirs']['ckpt']
+            self.HC.load_state_dict(torch.load(pjoin(ckpt, 'HC.pth')))
+            self.LS = np.load(pjoin(ckpt, 'LS.npy'), allow_pickle=True).item()
+            self.L.load_state_dict(torch.load(pjoin(ckpt, 'L.pth')))
+
+    # ------------------------------------------------------------------
+    # batched device pipeline
+    # ------------------------------------------------------------------
+    @torch.no_grad()
+    def infer_crops(self, instances, centers, scales, K=None, kpts_x_for_alpha=None,
+                    alpha_mode='proj', decode='auto', to_host=True):
+        """instances [n,C,H,W] fp32 CUDA crops; centers/scales [n,2] float64
+        (``modify_bbox`` outputs).  Returns a dict with
+          kpts_2d [n,2J] f64 (screen), kpts_3d [n,J-1,3] f64, euler [n,3],
+          translation [n,3], alpha [n] (if K is given), local [n,J,2] fp32
+        as numpy arrays (``to_host``) or device tensors.
+        decode: 'coords' (coordinate head, the shipped configs), 'soft' /
+        'hard' (heat-map arg-max), 'auto' = by ``HC.head_type``.
+        """
+        if not instances.is_cuda:
+            raise ValueError('infer_crops is the GPU pipeline; pass CUDA crops')
+        if self.LS is None:
+            raise ValueError('lifter statistics LS are not loaded')
+        dev = instances.device
+        n = instances.shape[0]
+        L = _lib.lib()
+        HC = self.HC
+        J = HC.num_joints
+        width, height = self.resolution
+        if decode == 'auto':
+            decode = 'coords' if HC.head_type == 'coordinates' else 'soft'
+        with torch.cuda.device(dev):
+            stream = _lib.current_stream(dev)
+            if decode == 'coords':
+                _, local = HC._hip_engine().forward(instances.float())
+                mul = (float(width), float(height))
+            else:
+                mode = 1 if decode == 'soft' else 0
+                out, (local, _, _) = HC._hip_engine().forward(instances.float(), decode_mode=mode)
+                maps = out[0] if isinstance(out, tuple) else out
+                mul = (float(width) / maps.shape[3], float(height) / maps.shape[2])
+            key = ('ls', dev)
+            if getattr(self, '_ls_dev_key', None) != key:
+                self._ls_dev = {k: _dev_f64(v, dev).reshape(-1) for k, v in self.LS.items()}
+                self._ls_dev_key = key
+            ls = self._ls_dev
+            ld_in = (2 * J + 3) // 4 * 4
+            c_d = _dev_f64(centers, dev)
+            s_d = _dev_f64(scales, dev)
+            screen = torch.empty(n, 2 * J, dtype=torch.float64, device=dev)
+            lin = torch.zeros(n, ld_in, dtype=torch.float32, device=dev)
+            _lib.check(L.egn_keypoints_to_screen_f64(
+                _lib.ptr(local), n, J, mul[0], mul[1], _lib.ptr(c_d), _lib.ptr(s_d), int(width),
+                int(height), _lib.ptr(screen), _lib.ptr(ls['mean_in']), _lib.ptr(ls['std_in']),
+                _lib.ptr(lin), ld_in, stream), 'keypoints_to_screen')
+            y = self.L._hip_engine().forward(lin, ld_in=ld_in)
+            D = y.shape[1]
+            pred3d = torch.empty(n, D, dtype=torch.float64, device=dev)
+            _lib.check(L.egn_unnormalize_f64(_lib.ptr(y), n, D, D, _lib.ptr(ls['mean_out']),
+                                             _lib.ptr(ls['std_out']), _lib.ptr(pred3d), stream))
+            res = {'local': local, 'kpts_2d': screen, 'kpts_3d': pred3d.view(n, -1, 3)}
+            if D == 96:
+                euler = torch.empty(n, 3, dtype=torch.float64, device=dev)
+                alpha = torch.empty(n, dtype=torch.float64, device=dev)
+                amode = 0 if (alpha_mode == 'proj' and K is not None) else 1
+                kx = screen[:, 0].contiguous() if kpts_x_for_alpha is None else _dev_f64(kpts_x_for_alpha, dev)
+                fx, cx = (float(K[0, 0]), float(K[0, 2])) if K is not None else (1.0, 0.0)
+                _lib.check(L.egn_pose_solve_f64(_lib.ptr(pred3d), n, _lib.ptr(kx), fx, cx, amode,
+                                                _lib.ptr(euler), _lib.ptr(alpha), stream), 'pose_solve')
+                res.update(euler=euler, alpha=alpha, translation=pred3d.view(n, -1, 3)[:, 0, :])
+        if to_host:
+            res = {k: v.cpu().numpy() for k, v in res.items()}
+        return res
+
+    # ------------------------------------------------------------------
+    # reference-shaped API
+    # ------------------------------------------------------------------
+    def new_img_dict(self):
+        return {k: [] for k in ('center', 'scale', 'rotation', 'bbox_resize', 'kpts_2d_pred',
+                                'label', 'score')}
+
+    def get_keypoints(self, instances, records, is_cuda=True):
+        """Reference egonet.py:424-467 (coordinates head): fills
+        ``records[i]['kpts']`` and returns the per-image dictionary."""
+        if is_cuda:
+            instances = instances.cuda()
+        if any(float(r.get('rotation', 0.)) != 0. for r in records):
+            raise NotImplementedError('rotated crops are not produced by the inference path')
+        if instances.is_cuda:
+            width, height = self.resolution
+            out = self.HC(instances)
+            local = out[1].contiguous()
+            n, J = local.shape[:2]
+            dev = local.device
+            screen = torch.empty(n, 2 * J, dtype=torch.float64, device=dev)
+            c_d = _dev_f64(np.stack([np.asarray(r['center'], dtype=np.float64) for r in records]), dev)
+            s_d = _dev_f64(np.stack([np.asarray(r['scale'], dtype=np.float64) for r in records]), dev)
+            with torch.cuda.device(dev):
+                _lib.check(_lib.lib().egn_keypoints_to_screen_f64(
+                    _lib.ptr(local), n, J, float(width), float(height), _lib.ptr(c_d), _lib.ptr(s_d),
+                    int(width), int(height), _lib.ptr(screen), None, None, None, 0,
+                    _lib.current_stream(dev)), 'keypoints_to_screen')
+            screen = screen.cpu().numpy().reshape(n, J, 2)
+        else:
+            raise ValueError('get_keypoints needs a GPU (the reference rejects CPU inference too, '
+                             'tools/inference.py:230-231)')
+        ret = {}
+        for i, record in enumerate(records):
+            record['kpts'] = screen[i]
+            d = ret.setdefault(record['path'], self.new_img_dict())
+            d['kpts_2d_pred'].append(record['kpts'].reshape(1, -1))
+            for k in ('center', 'scale', 'bbox_resize', 'label', 'score', 'rotation'):
+                d[k].append(record[k])
+        return ret
+
+    def lift_2d_to_3d(self, records, cuda=True):
+        """Reference egonet.py:469-486, but ONE lifter launch for all images."""
+        paths = list(records.keys())
+        if not paths:
+            return records
+        data = np.concatenate([np.concatenate(records[p]['kpts_2d_pred'], axis=0) for p in paths])
+        counts = [len(records[p]['kpts_2d_pred']) for p in paths]
+        x = ((data - self.LS['mean_in']) / self.LS['std_in']).astype(np.float32)
+        x = torch.from_numpy(x)
+        if cuda:
+            x = x.cuda()
+        with torch.no_grad():
+            pred = self.L(x).data.cpu().numpy()
+        pred = pred * self.LS['std_out'] + self.LS['mean_out']
+        o = 0
+        for p, c in zip(paths, counts):
+            records[p]['kpts_3d_pred'] = pred[o:o + c].reshape(c, -1, 3)
+            o += c
+        return records
+
+    def get_6d_rep(self, predictions, ax=None, color='black'):
+        """Reference egonet.py:279-295, batched on the GPU."""
+        predictions = np.asarray(predictions, dtype=np.float64).reshape(len(predictions), -1, 3)
+        euler, _ = self._pose(predictions, None, None, 1)
+        return euler, predictions[:, 0, :]
+
+    def _pose(self, pred3d, kpt_x, K, amode):
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda':
+            raise ValueError('pose solve runs on the GPU; move the model with .cuda()')
+        n = len(pred3d)
+        p = _dev_f64(pred3d.reshape(n, -1), dev)
+        euler = torch.empty(n, 3, dtype=torch.float64, device=dev)
+        alpha = torch.empty(n, dtype=torch.float64, device=dev)
+        kx = _dev_f64(kpt_x, dev) if kpt_x is not None else None
+        fx, cx = (float(K[0, 0]), float(K[0, 2])) if K is not None else (1.0, 0.0)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().egn_pose_solve_f64(_lib.ptr(p), n, _lib.ptr(kx), fx, cx, amode,
+                                                     _lib.ptr(euler), _lib.ptr(alpha),
+                                                     _lib.current_stream(dev)), 'pose_solve')
+        return euler.cpu().numpy(), alpha.cpu().numpy()
+
+    @staticmethod
+    def _wrap(alpha):
+        while alpha > math.pi:
+            alpha -= math.pi * 2
+        while alpha < -math.pi:
+            alpha += math.pi * 2
+        return alpha
+
+    def get_observation_angle_trans(self, euler_angles, translations):
+        """egonet.py:203-217 (host, trivial)."""
+        return np.array([self._wrap(e[1] - math.atan2(-t[2], t[0]) - 0.5 * math.pi)
+                         for e, t in zip(euler_angles, translations)])
+
+    def get_observation_angle_proj(self, euler_angles, kpts, K):
+        """egonet.py:219-236 (host, trivial)."""
+        f, cx = K[0, 0], K[0, 2]
+        return np.array([self._wrap(e[1] - math.atan2(-f, k[0, 0] - cx) - 0.5 * math.pi)
+                         for e, k in zip(euler_angles, kpts)])
+
+    def gather_lifting_results(self, record, alpha_mode='trans'):
+        """egonet.py:297-339 without plotting / string formatting."""
+        record['euler_angles'], record['translation'] = self.get_6d_rep(record['kpts_3d_pred'])
+        if alpha_mode == 'trans':
+            record['alphas'] = self.get_observation_angle_trans(record['euler_angles'],
+                                                                record['translation'])
+        elif alpha_mode == 'proj':
+            record['alphas'] = self.get_observation_angle_proj(record['euler_angles'],
+                                                               record['kpts_2d_pred'], record['K'])
+        else:
+            raise NotImplementedError
+        return record
+
+    def post_process(self, records, visualize=False, color_dict=None, save_dict=None,
+                     alpha_mode='trans'):
+        """egonet.py:385-408: pose angles per image.  Plotting and KITTI text
+        output are outside the hot path."""
+        if visualize or (save_dict and save_dict.get('flag')):
+            raise NotImplementedError('visualisation / result files are outside the hot path')
+        for path in records:
+            records[path] = self.gather_lifting_results(records[path], alpha_mode=alpha_mode)
+        return records
+
+    # ------------------------------------------------------------------
+    # crop extraction (adjacent to the hot path; needs cv2 like the reference)
+    # ------------------------------------------------------------------
+    def make_records(self, annot_dict):
+        """Per-instance records from an annotation dict (egonet.py:105-155
+        minus the image work)."""
+        width, height = self.resolution
+        target_ar = height / width
+        records = []
+        for i, path in enumerate(annot_dict['path']):
+            boxes = annot_dict['boxes'][i]
+            labels = annot_dict['labels'][i] if 'labels' in annot_dict else -np.ones(len(boxes), dtype=np.int64)
+            scores = annot_dict['scores'][i] if 'scores' in annot_dict else -np.ones(len(boxes))
+            for j, bbox in enumerate(boxes):
+                bbox = to_npy(bbox)
+                ret = modify_bbox(bbox, target_ar)
+                records.append({'path': path, 'center': ret['c'], 'scale': ret['s'], 'bbox': bbox,
+                                'bbox_resize': ret['bbox'], 'rotation': 0., 'label': labels[j],
+                                'score': scores[j]})
+        return records
+
+    def forward(self, annot_dict):
+        try:
+            import cv2  # noqa: F401
+        except ImportError as e:
+            raise ImportError('EgoNet.forward crops instances with cv2 like the reference '
+                              '(egonet.py:68-155); use infer_crops() with pre-cropped patches') from e
+        from ..common import crop_cv2
+        instances, records = crop_cv2.crop_instances(self, annot_dict)
+        recs = self.get_keypoints(instances, records)
+        recs = self.lift_2d_to_3d(recs)
+        for idx, path in enumerate(annot_dict['path']):
+            for k_src, k_dst in (('boxes', 'boxes'), ('kpts', 'kpts_2d_gt'), ('kpts_3d_gt', 'kpts_3d_gt'),
+                                 ('pose_vecs_gt', 'pose_vecs_gt'), ('kpts_3d_before', 'kpts_3d_before')):
+                if k_src in annot_dict and path in recs:
+                    recs[path][k_dst] = to_npy(annot_dict[k_src][idx])
+            for k in ('raw_txt_format', 'K'):
+                if k in annot_dict and path in recs:
+                    recs[path][k] = annot_dict[k][idx]
+        return recs

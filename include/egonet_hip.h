@@ -1,0 +1,189 @@
+/*
+ * egonet_hip.h -- C ABI of the MI355X (gfx950) hot-path library of egonet_amd.
+ *
+ * The reference (Nicholasli1995/EgoNet) is pure Python on torch.nn: it has no
+ * FFI of its own.  Each entry point below replaces the ATen op sequence issued
+ * by the cited reference lines; the Python host layer (egonet_amd/model/...)
+ * mirrors the reference's operator API (get_pose_net / get_fc_model / EgoNet)
+ * and reaches these functions through ctypes.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, >0 = hipError_t, <0 = EGN_E_* below;
+ *     no exception crosses this boundary.
+ *   - all pointers are DEVICE pointers owned by the caller (torch tensors);
+ *     the library never allocates user-visible memory.
+ *   - `stream` is a hipStream_t passed as void*; nothing synchronises.
+ *   - activations are fp32 NHWC with a channel stride `cs` (multiple of 4,
+ *     pad channels hold zeros) unless a parameter says NCHW.
+ */
+#ifndef EGONET_HIP_H
+#define EGONET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGN_E_BADARG   (-1)   /* inconsistent shapes / unsupported parameter  */
+#define EGN_E_LDS      (-2)   /* tile does not fit in the 160 KiB LDS          */
+#define EGN_E_STATE    (-3)   /* program used in the wrong state               */
+
+#define EGN_ACT_NONE    0
+#define EGN_ACT_RELU    1
+#define EGN_ACT_SIGMOID 2
+#define EGN_ACT_LEAKY   3     /* slope 0.01 (torch LeakyReLU default)          */
+#define EGN_ACT_MASK    0x0f
+#define EGN_ACT_RES_AFTER 0x10 /* flag: y = res + act(..) instead of act(.. + res)
+                                  (FCmodel.py:34-43: out = x + relu(bn(w2(..))))  */
+
+/* library / ABI version: (major<<16)|minor */
+int egn_version(void);
+/* human readable text for a return code (static storage) */
+const char* egn_strerror(int code);
+
+/* ------------------------------------------------------------------------
+ * Convolution as fp32-MFMA implicit GEMM, fused  y = act(conv(x)*scale+shift
+ * (+res)).  Replaces Conv2d+BatchNorm2d(+add)+ReLU chains:
+ *   hrnet.py:76-92 (BasicBlock), :113-133 (Bottleneck), :232-274 (fuse convs),
+ *   :482-507 (transitions), :318-323 (stem), :365-371/:427-435 (1x1 heads),
+ *   :457 (4x4 valid conv + Sigmoid); FCmodel.py:33-43,92-105 (Linear+BN1d as
+ *   1x1 conv on [N,1,1,C]).
+ *
+ * x      [N,H,W,cs_in]  fp32 NHWC
+ * wpack  weights prepacked by egn_conv_pack_size/egonet_amd.engine.pack_conv:
+ *        [nchunk][KH*KW][CK/4][CoutP][4] fp32, CK = 16 input channels per chunk,
+ *        CoutP = Cout rounded up to 16, zero padded
+ * scale, shift  [CoutP] fp32 (folded BatchNorm / bias), zero padded
+ * res    optional residual [N,Ho,Wo,cs_out] (NULL = none), added before act
+ * y      [N,Ho,Wo,cs_out] NHWC, or [N,Cout,Ho,Wo] when out_nchw != 0
+ * cfg    tile configuration id (0 = choose automatically)
+ * ---------------------------------------------------------------------- */
+int egn_conv2d_f32(const float* x, const float* wpack, const float* scale,
+                   const float* shift, const float* res, float* y,
+                   int N, int H, int W, int Cin, int cs_in,
+                   int Cout, int cs_out, int KH, int KW, int stride, int pad,
+                   int act, int out_nchw, int cfg, void* stream);
+
+/* number of tile configurations compiled in; valid ids are 1..count */
+int egn_conv_num_configs(void);
+/* describe config id: tile_m (output pixels), tile_n (output channels) */
+int egn_conv_config_info(int cfg, int* tile_m, int* tile_n);
+
+/* ------------------------------------------------------------------------
+ * Multi-resolution fuse: y = relu( ((t0 + up(t1)) + up(t2)) + up(t3) ),
+ * left-associated in the order given (hrnet.py:291-298); up() = nearest
+ * neighbour by 2^shift (hrnet.py:241), shift 0 = same resolution.
+ * All tensors NHWC with channel stride cs; y is [N,H,W,cs]; t_i is
+ * [N,H>>s_i,W>>s_i,cs].  nterms in 1..4.
+ * ---------------------------------------------------------------------- */
+int egn_fuse_sum_relu_f32(float* y, int N, int H, int W, int C, int cs,
+                          int nterms, const float* const* terms,
+                          const int* shifts, int relu, void* stream);
+
+/* layout helpers at the module boundary (reference tensors are NCHW) */
+int egn_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int H, int W,
+                         int cs, void* stream);
+int egn_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int H, int W,
+                         int cs, void* stream);
+/* write the two coordinate ramps linspace(0,1) (hrnet.py:461-467) into
+ * channels [c0, c0+1] of an NHWC tensor */
+int egn_fill_coord_ramps_f32(float* y, int N, int H, int W, int cs, int c0,
+                             void* stream);
+
+/* ------------------------------------------------------------------------
+ * Key-point decode, one wavefront per (n,k) map (img_proc.py:608-637 hard
+ * arg-max, :678-707 soft-arg-max).  hm is NCHW [N,K,H,W].
+ *   out_xy   [N,K,2] fp32   (x,y) in heat-map pixels
+ *   out_max  [N,K]   fp32   raw maximum
+ *   out_idx  [N,K]   int32  flat arg-max index (first max on ties); may be NULL
+ * mode 0 = hard arg-max (coordinates zeroed where max <= 0),
+ * mode 1 = soft-arg-max (softmax over H*W, no mask).
+ * ---------------------------------------------------------------------- */
+int egn_decode_heatmaps_f32(const float* hm, int N, int K, int H, int W,
+                            int mode, float* out_xy, float* out_max,
+                            int32_t* out_idx, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Crop-local key-points -> screen coordinates -> normalised lifter input
+ * (egonet.py:436-453 + img_proc.py:26-78 with rot=0, operations.py:20-47).
+ *   local   [n,K,2] fp32, multiplied by (mul_x, mul_y) first
+ *           (coords head: resolution; soft-arg-max: input/heatmap size)
+ *   center  [n,2] f64, scale [n,2] f64 (modify_bbox outputs), crop size (cw,ch)
+ *   screen  [n,K*2] f64 out (records['kpts_2d_pred'])
+ *   mean_in, std_in [K*2] f64;  lifter_in [n, ld_in] fp32 out (may be NULL)
+ * ---------------------------------------------------------------------- */
+int egn_keypoints_to_screen_f64(const float* local, int n, int K,
+                                double mul_x, double mul_y,
+                                const double* center, const double* scale,
+                                int crop_w, int crop_h, double* screen,
+                                const double* mean_in, const double* std_in,
+                                float* lifter_in, int ld_in, void* stream);
+
+/* pred3d[n,D] f64 = y[n,ld] fp32 * std_out + mean_out  (operations.py:49-51) */
+int egn_unnormalize_f64(const float* y, int n, int D, int ld,
+                        const double* mean_out, const double* std_out,
+                        double* pred3d, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Batched pose solve (egonet.py:238-295, transformation.py:99-134,
+ * egonet.py:203-236): cuboid template from mean edge lengths, Kabsch
+ * rotation by 3x3 SVD, euler 'yxz' -> (x,y,z) order, observation angle.
+ *   pred3d [n,32,3] f64;  kpt_x [n] f64 = screen x of key-point 0 (proj mode)
+ *   euler [n,3] f64, alpha [n] f64;  alpha_mode 0 = 'proj' (needs fx,cx),
+ *   1 = 'trans'
+ * ---------------------------------------------------------------------- */
+int egn_pose_solve_f64(const double* pred3d, int n, const double* kpt_x,
+                       double fx, double cx, int alpha_mode,
+                       double* euler, double* alpha, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Programs: a recorded sequence of the launches above with every pointer
+ * expressed as (slot, byte offset).  Slots are bound to base addresses before
+ * a run (slot 0 = activation arena, 1 = packed weights, 2.. = user tensors),
+ * so one recording serves every forward of a model at a fixed batch shape.
+ * ---------------------------------------------------------------------- */
+typedef struct egn_program egn_program;
+typedef struct { int32_t slot; int64_t off; } egn_ref;   /* slot < 0: NULL */
+
+egn_program* egn_program_create(int nslots);
+void egn_program_destroy(egn_program* p);
+int egn_program_bind(egn_program* p, int slot, void* base);
+int egn_program_num_ops(const egn_program* p);
+
+int egn_program_add_conv2d(egn_program* p, egn_ref x, egn_ref wpack,
+                           egn_ref scale, egn_ref shift, egn_ref res, egn_ref y,
+                           int N, int H, int W, int Cin, int cs_in,
+                           int Cout, int cs_out, int KH, int KW, int stride,
+                           int pad, int act, int out_nchw, int cfg);
+int egn_program_add_fuse(egn_program* p, egn_ref y, int N, int H, int W, int C,
+                         int cs, int nterms, const egn_ref* terms,
+                         const int* shifts, int relu);
+int egn_program_add_nchw_to_nhwc(egn_program* p, egn_ref x, egn_ref y, int N,
+                                 int C, int H, int W, int cs);
+int egn_program_add_nhwc_to_nchw(egn_program* p, egn_ref x, egn_ref y, int N,
+                                 int C, int H, int W, int cs);
+int egn_program_add_ramps(egn_program* p, egn_ref y, int N, int H, int W,
+                          int cs, int c0);
+int egn_program_add_decode(egn_program* p, egn_ref hm, int N, int K, int H,
+                           int W, int mode, egn_ref out_xy, egn_ref out_max,
+                           egn_ref out_idx);
+/* tag the most recently added op (shown by the profiler); copied */
+int egn_program_tag(egn_program* p, const char* tag, double flops, double bytes);
+
+/* launch every op in order on `stream` */
+int egn_program_run(egn_program* p, void* stream);
+/* same, bracketing every op with hipEvents; ms[i] = duration of op i.
+ * Synchronises the stream before returning. */
+int egn_program_run_timed(egn_program* p, void* stream, float* ms, int n_ms);
+/* capture the op sequence into a hipGraph (bindings frozen) / replay it */
+int egn_program_capture(egn_program* p, void* stream);
+int egn_program_replay(egn_program* p, void* stream);
+/* per-op metadata for reports */
+int egn_program_op_info(const egn_program* p, int i, int* kind, double* flops,
+                        double* bytes, char* tag, int tag_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGONET_HIP_H */

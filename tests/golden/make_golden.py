@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference, which never travels
+to the GPU box).  It imports the reference's own Python:
+
+  libs.model.heatmapModel.hrnet   (torch + numpy only)
+  libs.model.FCmodel              (torch only)
+  libs.common.img_proc, libs.common.transformation, libs.model.egonet
+      (need cv2 / torchvision, absent here: ``cv2.getAffineTransform`` is
+       stubbed by the exact 6x6 float64 solve, torchvision by a MagicMock;
+       ``soft_arg_max`` hard-codes torch.cuda.* tensor types, which are
+       aliased to their CPU counterparts for the call)
+
+and stores inputs + reference outputs as small .npz files.  Weights are either
+stored in full (tiny nets) or regenerated from ``egonet_amd.synth`` (per-key
+seeded, construction-order independent) for the full-size W48 / lifter nets.
+
+Usage:  python tests/golden/make_golden.py            (from the repo root)
+"""
+import json
+import os
+import zlib
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+import torch.cuda.comm
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+
+
+def _install_stubs():
+    cv2 = types.ModuleType('cv2')
+
+    def get_affine(src, dst):
+        src = np.asarray(src, dtype=np.float64)
+        dst = np.asarray(dst, dtype=np.float64)
+        m = np.hstack([src, np.ones((3, 1))])
+        return np.linalg.solve(m, dst).T
+
+    cv2.getAffineTransform = get_affine
+    cv2.INTER_LINEAR = 1
+    sys.modules['cv2'] = cv2
+    for name in ('torchvision', 'torchvision.transforms', 'torchvision.utils'):
+        sys.modules[name] = mock.MagicMock()
+    import matplotlib
+    matplotlib.use('Agg')
+
+
+def main():
+    _install_stubs()
+    sys.path.insert(0, REF)
+    from egonet_amd import configs, synth
+    import libs.model.heatmapModel.hrnet as ref_hrnet
+    import libs.model.FCmodel as ref_fc
+    import libs.common.img_proc as ref_ip
+    import libs.model.egonet as ref_ego
+
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+
+    def save(name, **arrs):
+        path = os.path.join(HERE, name)
+        np.savez_compressed(path, **arrs)
+        print('%-28s %8.1f KB' % (name, os.path.getsize(path) / 1024))
+
+    def sd_np(sd):
+        return {'sd/' + k: v.numpy() for k, v in sd.items()}
+
+    def crc(a):
+        return zlib.crc32(np.ascontiguousarray(a).tobytes())
+
+    def sd_crc(sd):
+        c = 0
+        for k, v in sd.items():
+            c = zlib.crc32(np.ascontiguousarray(v.numpy()).tobytes(), c)
+        return c
+
+    # ---- 1/2/3: tiny HRNets stored in full --------------------------------
+    for tag, cfg, n in (
+            ('tiny_coords', configs.tiny_config('coordinates'), 2),
+            ('tiny_heatmap', configs.tiny_config('heatmap'), 2),
+            ('tiny_ped', configs.tiny_config('coordinates', input_size=(96 * 2, 128 * 2), width=8), 1)):
+        net = ref_hrnet.get_pose_net(cfg, is_train=False).eval()
+        sd = synth.synth_state_dict(net.state_dict(), seed=3)
+        net.load_state_dict(sd)
+        iw, ih = cfg['heatmapModel']['input_size']
+        x = synth.synth_crops(n, 3, ih, iw, seed=5)
+        with torch.no_grad():
+            out = net(x)
+        # weights / inputs are regenerated from egonet_amd.synth (seeded per key);
+        # only their CRCs are stored so a generator mismatch is diagnosed
+        arrs = dict(cfg=np.array(json.dumps(cfg)), n=np.array(n),
+                    x_crc=np.array(crc(x.numpy())), sd_crc=np.array(sd_crc(sd)))
+        if isinstance(out, tuple):
+            arrs.update(maps=out[0].numpy(), coords=out[1].numpy())
+        else:
+            arrs.update(maps=out.numpy())
+        save('hrnet_%s.npz' % tag, **arrs)
+
+    # ---- 4: full W48, weights regenerated from synth ----------------------
+    x = synth.synth_crops(4, 3, 256, 256, seed=11)
+    w48 = {}
+    for head in ('coordinates', 'heatmap'):
+        cfg = configs.w48_config(head)
+        net = ref_hrnet.get_pose_net(cfg, is_train=False).eval()
+        sd = synth.synth_state_dict(net.state_dict(), seed=1)
+        net.load_state_dict(sd)
+        with torch.no_grad():
+            out = net(x)
+        maps = (out[0] if isinstance(out, tuple) else out).numpy()
+        w48[head + '/maps_sub'] = maps[:, :, ::4, ::4].copy()
+        w48[head + '/argmax'] = maps.reshape(4, 33, -1).argmax(axis=2).astype(np.int32)
+        w48[head + '/maxval'] = maps.reshape(4, 33, -1).max(axis=2)
+        w48[head + '/sd_crc'] = np.array(sd_crc(sd))
+        w48[head + '/x_crc'] = np.array(crc(x.numpy()))
+        w48[head + '/n_keys'] = np.array(len(sd))
+        w48[head + '/n_params'] = np.array(sum(p.numel() for p in net.parameters()))
+        w48[head + '/key_crc'] = np.array(
+            __import__('zlib').crc32('\n'.join('%s %s' % (k, tuple(v.shape))
+                                               for k, v in sd.items()).encode()))
+        if isinstance(out, tuple):
+            w48[head + '/coords'] = out[1].numpy()
+        # decode outputs of the reference on these maps
+        p_hard, mv = ref_ip.get_max_preds(maps.copy())
+        w48[head + '/hard_preds'] = p_hard
+        with mock.patch.object(torch.cuda, 'FloatTensor', torch.FloatTensor, create=True), \
+                mock.patch.object(torch.cuda.comm, 'broadcast', lambda t, devices: [t]):
+            p_soft, mv2 = ref_ip.soft_arg_max(torch.from_numpy(maps.copy()))
+        w48[head + '/soft_preds'] = p_soft.numpy()
+        w48[head + '/soft_maxvals'] = mv2.numpy()
+    save('hrnet_w48_outputs.npz', **w48)
+
+    # ---- 5: decode functions on random maps (incl. negative-only maps) ----
+    rng = np.random.RandomState(1)
+    hm = rng.randn(3, 7, 16, 12).astype(np.float32) * 3
+    hm[0, 0] = -np.abs(hm[0, 0]) - 0.1            # max <= 0 -> masked
+    hm[1, 1, 5, 7] = hm[1, 1, 9, 2] = 50.0        # tie: first index wins
+    hm[2, 2] = 0.0                                # all equal
+    p_hard, mv_hard = ref_ip.get_max_preds(hm.copy())
+    pos = np.abs(hm) + 0.01
+    p_np, mv_np = ref_ip.soft_arg_max_np(pos.copy())
+    with mock.patch.object(torch.cuda, 'FloatTensor', torch.FloatTensor, create=True), \
+            mock.patch.object(torch.cuda.comm, 'broadcast', lambda t, devices: [t]):
+        p_soft, mv_soft = ref_ip.soft_arg_max(torch.from_numpy(hm.copy()))
+    save('decode.npz', hm=hm, hard_preds=p_hard, hard_maxvals=mv_hard,
+         pos=pos, np_preds=p_np, np_maxvals=mv_np,
+         soft_preds=p_soft.numpy(), soft_maxvals=mv_soft.numpy())
+
+    # ---- 6: lifter, full size, weights regenerated -------------------------
+    cfg = configs.w48_config()
+    fc = ref_fc.get_fc_model(1, cfg, 66, 96).eval()
+    sd = synth.synth_state_dict(fc.state_dict(), seed=2)
+    fc.load_state_dict(sd)
+    g = torch.Generator().manual_seed(21)
+    xin = torch.randn(64, 66, generator=g)
+    with torch.no_grad():
+        yout = fc(xin)
+    save('lifter_full.npz', x=xin.numpy(), y=yout.numpy(), sd_crc=np.array(sd_crc(sd)),
+         n_keys=np.array(len(sd)),
+         n_params=np.array(sum(p.numel() for p in fc.parameters())))
+    # small lifter stored in full (leaky variant too)
+    for leaky in (False, True):
+        c2 = configs.tiny_config()
+        c2['FCModel']['leaky'] = leaky
+        fc = ref_fc.get_fc_model(1, c2, 10, 12).eval()
+        sd = synth.synth_state_dict(fc.state_dict(), seed=4)
+        fc.load_state_dict(sd)
+        xin = torch.randn(9, 10, generator=g)
+        with torch.no_grad():
+            yout = fc(xin)
+        save('lifter_tiny%s.npz' % ('_leaky' if leaky else ''), x=xin.numpy(),
+             y=yout.numpy(), **sd_np(sd))
+
+    # ---- 7: EgoNet-level pipeline on CPU (tiny HC, 33 joints) --------------
+    cfg = configs.hrnet_config(8, (64, 64), 33, 'coordinates', modules=(1, 1, 1),
+                               num_blocks=1, lifter_neurons=128)
+    ego = ref_ego.EgoNet(cfg, pre_trained=False).eval()
+    hc_sd = synth.synth_state_dict(ego.HC.state_dict(), seed=6)
+    l_sd = synth.synth_state_dict(ego.L.state_dict(), seed=7)
+    ego.HC.load_state_dict(hc_sd)
+    ego.L.load_state_dict(l_sd)
+    ego.LS = synth.synth_lifter_stats(66, 96, seed=1)
+    boxes = synth.synth_boxes(6, seed=2)
+    crops = synth.synth_crops(6, 3, 64, 64, seed=8)
+    records = []
+    for i, b in enumerate(boxes):
+        ret = ref_ip.modify_bbox(b, 1.0)
+        records.append({'path': 'img%d.png' % (i // 3), 'center': ret['c'],
+                        'scale': ret['s'], 'bbox': b, 'bbox_resize': ret['bbox'],
+                        'rotation': 0., 'label': -1, 'score': -1.})
+    with torch.no_grad():
+        rec = ego.get_keypoints(crops, records, is_cuda=False)
+        rec = ego.lift_2d_to_3d(rec, cuda=False)
+    K = np.array([[707.0493, 0., 604.0814], [0., 707.0493, 180.5066], [0., 0., 1.]])
+    kp2d, kp3d, eul, trn, a_proj, a_trans = [], [], [], [], [], []
+    for path in rec:
+        r = rec[path]
+        e, t = ego.get_6d_rep(r['kpts_3d_pred'])
+        kp2d.append(np.concatenate(r['kpts_2d_pred']))
+        kp3d.append(r['kpts_3d_pred'])
+        eul.append(e)
+        trn.append(t)
+        a_proj.append(ego.get_observation_angle_proj(e, r['kpts_2d_pred'], K))
+        a_trans.append(ego.get_observation_angle_trans(e, t))
+    save('egonet_pipeline.npz', cfg=np.array(json.dumps(cfg)), crops_crc=np.array(crc(crops.numpy())),
+         boxes=boxes, K=K,
+         centers=np.stack([r['center'] for r in records]),
+         scales=np.stack([r['scale'] for r in records]),
+         bbox_resize=np.stack([np.array(r['bbox_resize']) for r in records]),
+         kpts_2d=np.concatenate(kp2d), kpts_3d=np.concatenate(kp3d),
+         euler=np.concatenate(eul), translation=np.concatenate(trn),
+         alpha_proj=np.concatenate(a_proj), alpha_trans=np.concatenate(a_trans),
+         hc_crc=np.array(sd_crc(hc_sd)), l_crc=np.array(sd_crc(l_sd)),
+         **{'ls/' + k: v for k, v in ego.LS.items()})
+
+    # ---- 8: pose solve on well-posed cuboids (noisy rotated templates) -----
+    from scipy.spatial.transform import Rotation
+    rng = np.random.RandomState(5)
+    preds = []
+    for i in range(48):
+        h, l, w = rng.uniform(1.2, 2.0), rng.uniform(3.0, 5.0), rng.uniform(1.4, 2.0)
+        xc = np.array([l, l, l, l, 0, 0, 0, 0.]) - l / 2
+        yc = np.array([0, h, 0, h, 0, h, 0, h]) - h
+        zc = np.array([w, w, 0, 0, w, w, 0, 0.]) - w / 2
+        c = np.array([xc, yc, zc])
+        pidx = np.array([1, 3, 5, 7, 1, 2, 3, 4, 1, 2, 5, 6]) - 1
+        cidx = np.array([2, 4, 6, 8, 5, 6, 7, 8, 3, 4, 7, 8]) - 1
+        c = np.hstack([c] + [c[:, pidx] + k * (c[:, cidx] - c[:, pidx]) for k in (0.332, 0.667)])
+        rot = Rotation.from_euler('yxz', [rng.uniform(-np.pi, np.pi), rng.uniform(-0.2, 0.2),
+                                          rng.uniform(-0.2, 0.2)]).as_matrix()
+        p = (rot @ c).T + rng.randn(32, 3) * 0.03
+        preds.append(p)
+    preds = np.stack(preds)
+    e, t = ego.get_6d_rep(preds)
+    kx = [np.array([[rng.uniform(0, 1242)]]) for _ in range(len(preds))]
+    save('pose_solve.npz', preds=preds, euler=e, translation=t, K=K,
+         kpts_x=np.array([k[0, 0] for k in kx]),
+         alpha_proj=ego.get_observation_angle_proj(e, kx, K),
+         alpha_trans=ego.get_observation_angle_trans(e, t))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,149 @@
+"""Pin the CPU oracle (oracle/) against outputs of the REFERENCE itself.
+
+The fixtures under tests/golden/ were produced by tests/golden/make_golden.py,
+which imports /root/reference in the build container.  Weights and inputs are
+regenerated here from egonet_amd.synth (seeded per state_dict key); their CRCs
+are stored in the fixtures.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, fixture_cfg, sd_crc, arr_crc, require_same_rng
+from egonet_amd import configs, synth
+from egonet_amd.model.heatmapModel import hrnet as hip_hrnet
+from egonet_amd.model import FCmodel as hip_fc
+from oracle import hrnet_oracle, decode_oracle, lifter_oracle, geometry_oracle
+
+
+def _synth_hc(cfg, seed):
+    net = hip_hrnet.get_pose_net(cfg, is_train=False)
+    return synth.synth_state_dict(net.state_dict(), seed=seed)
+
+
+@pytest.mark.parametrize('name', ['tiny_coords', 'tiny_heatmap', 'tiny_ped'])
+def test_hrnet_oracle_tiny(name):
+    g = golden('hrnet_%s.npz' % name)
+    cfg = fixture_cfg(g)
+    sd = _synth_hc(cfg, seed=3)
+    require_same_rng(sd_crc(sd), g['sd_crc'], 'weights')
+    iw, ih = cfg['heatmapModel']['input_size']
+    x = synth.synth_crops(int(g['n']), 3, ih, iw, seed=5)
+    require_same_rng(arr_crc(x.numpy()), g['x_crc'], 'input')
+    out = hrnet_oracle.hrnet_forward(sd, cfg, x)
+    if isinstance(out, tuple):
+        np.testing.assert_allclose(out[0].numpy(), g['maps'], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(out[1].numpy(), g['coords'], rtol=0, atol=1e-6)
+    else:
+        np.testing.assert_allclose(out.numpy(), g['maps'], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize('head', ['coordinates', 'heatmap'])
+def test_hrnet_oracle_w48(head):
+    """Full HRNet-W48 @256x256 on 4 crops: heat-map samples, arg-max indices
+    (bit exact), coordinates, and both decodes."""
+    g = golden('hrnet_w48_outputs.npz')
+    cfg = configs.w48_config(head)
+    sd = _synth_hc(cfg, seed=1)
+    assert len(sd) == int(g[head + '/n_keys'])
+    require_same_rng(sd_crc(sd), g[head + '/sd_crc'], 'weights')
+    x = synth.synth_crops(4, 3, 256, 256, seed=11)
+    require_same_rng(arr_crc(x.numpy()), g[head + '/x_crc'], 'input')
+    torch.set_num_threads(max(torch.get_num_threads(), 4))
+    out = hrnet_oracle.hrnet_forward(sd, cfg, x)
+    maps = (out[0] if isinstance(out, tuple) else out).numpy()
+    np.testing.assert_allclose(maps[:, :, ::4, ::4], g[head + '/maps_sub'], rtol=0, atol=2e-4)
+    idx, mv = decode_oracle.argmax_index(maps)
+    assert np.array_equal(idx, g[head + '/argmax'])
+    np.testing.assert_allclose(mv[..., 0], g[head + '/maxval'], rtol=0, atol=2e-4)
+    if isinstance(out, tuple):
+        np.testing.assert_allclose(out[1].numpy(), g[head + '/coords'], rtol=0, atol=1e-5)
+    hard, _ = decode_oracle.get_max_preds(maps)
+    assert np.array_equal(hard, g[head + '/hard_preds'])
+    soft, smv = decode_oracle.soft_arg_max(maps)
+    np.testing.assert_allclose(soft, g[head + '/soft_preds'], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(smv, g[head + '/soft_maxvals'], rtol=0, atol=2e-4)
+
+
+def test_decode_oracle_edge_cases():
+    g = golden('decode.npz')
+    hm = g['hm']
+    hard, mv = decode_oracle.get_max_preds(hm)
+    assert np.array_equal(hard, g['hard_preds'])           # masked map, tie, all-equal map
+    assert np.array_equal(mv, g['hard_maxvals'])
+    soft, smv = decode_oracle.soft_arg_max(hm)
+    np.testing.assert_allclose(soft, g['soft_preds'], rtol=0, atol=1e-4)
+    assert np.array_equal(smv, g['soft_maxvals'])
+    p, pm = decode_oracle.soft_arg_max_np(g['pos'])
+    np.testing.assert_allclose(p, g['np_preds'], rtol=0, atol=1e-4)
+    assert np.array_equal(pm, g['np_maxvals'])
+
+
+def test_lifter_oracle_full():
+    g = golden('lifter_full.npz')
+    cfg = configs.w48_config()
+    net = hip_fc.get_fc_model(1, cfg, 66, 96)
+    sd = synth.synth_state_dict(net.state_dict(), seed=2)
+    assert len(sd) == int(g['n_keys']) == 37
+    assert sum(p.numel() for p in net.parameters()) == int(g['n_params']) == 4375648
+    require_same_rng(sd_crc(sd), g['sd_crc'], 'weights')
+    y = lifter_oracle.lifter_forward(sd, torch.from_numpy(g['x']))
+    np.testing.assert_allclose(y.numpy(), g['y'], rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize('leaky', [False, True])
+def test_lifter_oracle_tiny_stored_weights(leaky):
+    g = golden('lifter_tiny%s.npz' % ('_leaky' if leaky else ''))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd/')}
+    y = lifter_oracle.lifter_forward(sd, torch.from_numpy(g['x']), leaky=leaky)
+    np.testing.assert_allclose(y.numpy(), g['y'], rtol=0, atol=1e-5)
+
+
+def test_pipeline_oracle():
+    """EgoNet.get_keypoints -> lift_2d_to_3d -> get_6d_rep -> alpha of the
+    reference (CPU run, tiny HC, 33 joints)."""
+    g = golden('egonet_pipeline.npz')
+    cfg = fixture_cfg(g)
+    hc_sd = _synth_hc(cfg, seed=6)
+    lnet = hip_fc.get_fc_model(1, cfg, 66, 96)
+    l_sd = synth.synth_state_dict(lnet.state_dict(), seed=7)
+    require_same_rng(sd_crc(hc_sd), g['hc_crc'], 'HC weights')
+    require_same_rng(sd_crc(l_sd), g['l_crc'], 'L weights')
+    crops = synth.synth_crops(6, 3, 64, 64, seed=8)
+    require_same_rng(arr_crc(crops.numpy()), g['crops_crc'], 'crops')
+    boxes = synth.synth_boxes(6, seed=2)
+    np.testing.assert_array_equal(boxes, g['boxes'])
+    stats = {k[3:]: g[k] for k in g.files if k.startswith('ls/')}
+    _, coords = hrnet_oracle.hrnet_forward(hc_sd, cfg, crops)
+    local = decode_oracle.coords_head_to_pixels(coords.numpy(), cfg['heatmapModel']['input_size'])
+    kp2d = []
+    for i, b in enumerate(boxes):
+        ret = geometry_oracle.modify_bbox(b, 1.0)
+        np.testing.assert_allclose(ret['c'], g['centers'][i], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(ret['s'], g['scales'][i], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(ret['bbox'], g['bbox_resize'][i], rtol=0, atol=1e-10)
+        kp2d.append(geometry_oracle.crop_to_screen(local[i], ret['c'], ret['s'], (64, 64)).reshape(1, -1))
+    kp2d = np.concatenate(kp2d)
+    np.testing.assert_allclose(kp2d, g['kpts_2d'], rtol=0, atol=1e-3)
+    kp3d = lifter_oracle.lift_2d_to_3d(l_sd, stats, kp2d)
+    np.testing.assert_allclose(kp3d, g['kpts_3d'], rtol=0, atol=1e-3)
+    # pose solve on the reference's own 3D predictions
+    euler, trans = geometry_oracle.six_dof(g['kpts_3d'])
+    np.testing.assert_allclose(np.cos(euler), np.cos(g['euler']), atol=1e-9)
+    np.testing.assert_allclose(np.sin(euler), np.sin(g['euler']), atol=1e-9)
+    np.testing.assert_allclose(trans, g['translation'], atol=1e-12)
+    a = geometry_oracle.observation_angle_proj(g['euler'], g['kpts_2d'][:, 0], g['K'])
+    np.testing.assert_allclose(a, g['alpha_proj'], atol=1e-12)
+    a = geometry_oracle.observation_angle_trans(g['euler'], g['translation'])
+    np.testing.assert_allclose(a, g['alpha_trans'], atol=1e-12)
+
+
+def test_pose_oracle_cuboids():
+    g = golden('pose_solve.npz')
+    euler, trans = geometry_oracle.six_dof(g['preds'])
+    np.testing.assert_allclose(euler, g['euler'], atol=1e-9)
+    np.testing.assert_allclose(trans, g['translation'], atol=0)
+    np.testing.assert_allclose(geometry_oracle.observation_angle_proj(euler, g['kpts_x'], g['K']),
+                               g['alpha_proj'], atol=1e-9)
+    np.testing.assert_allclose(geometry_oracle.observation_angle_trans(euler, trans),
+                               g['alpha_trans'], atol=1e-9)
