@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Benchmark of the EgoNet hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One *step* = one batch of B synthetic 256x256 crops per GPU through the whole
+hot path with inputs resident in HBM:
+    HRNet-W48 heat-map forward -> soft-arg-max decode -> crop-to-screen affine
+    -> lifter (66 -> 96) -> un-normalise -> pose solve
+(BASELINE.json configs[1] "Batch=64 256x256 crops, heatmap forward +
+soft-argmax", extended by the lift so that the number is the headline metric
+crops/s "heatmap+decode+lift").  Crops shard across ranks with no data-path
+collective (weak scaling, B per GPU fixed).
+
+Prints ONE JSON line (rank 0).  Besides the contract fields it carries
+  roofline      the dominant kernel class (by time) of the forward, measured
+                live with hipEvents per launch inside the native program
+  kernels       the same for every kernel class (time share, TFLOP/s, GB/s)
+  cpu_baseline  the CPU oracle (same graph the reference's PyTorch-CPU path
+                executes) timed on this host on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=10)
+    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--batch', type=int, default=64, help='crops per GPU per step')
+    p.add_argument('--head', default='heatmap', choices=['heatmap', 'coordinates'])
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-seconds', type=float, default=15.0)
+    p.add_argument('--profile-json', default='', help='write the per-op timing table here')
+    return p.parse_args()
+
+
+def build_model(head, device):
+    from egonet_amd import configs, synth
+    from egonet_amd.model.egonet import EgoNet
+    cfg = configs.w48_config(head)
+    ego = EgoNet(cfg, pre_trained=False)
+    hc_sd = synth.synth_state_dict(ego.HC.state_dict(), seed=1)
+    l_sd = synth.synth_state_dict(ego.L.state_dict(), seed=2)
+    ego.HC.load_state_dict(hc_sd)
+    ego.L.load_state_dict(l_sd)
+    ego.LS = synth.synth_lifter_stats(66, 96, seed=1)
+    return cfg, ego.eval().to(device), hc_sd, l_sd
+
+
+def kernel_table(prog, ms):
+    """Aggregate per-op hipEvent durations by kernel class."""
+    agg = {}
+    for meta, t in zip(prog.meta, ms):
+        a = agg.setdefault(meta['klass'], dict(klass=meta['klass'], kind=meta['kind'], launches=0, ms=0.0,
+                                               flops=0.0, bytes=0.0))
+        a['launches'] += 1
+        a['ms'] += float(t)
+        a['flops'] += meta['flops']
+        a['bytes'] += meta['bytes']
+    rows = sorted(agg.values(), key=lambda a: -a['ms'])
+    total = sum(a['ms'] for a in rows)
+    for a in rows:
+        a['share'] = a['ms'] / total if total else 0.0
+        a['tflops'] = a['flops'] / (a['ms'] * 1e-3) / 1e12 if a['ms'] else 0.0
+        a['gbps'] = a['bytes'] / (a['ms'] * 1e-3) / 1e9 if a['ms'] else 0.0
+        a['avg_us'] = a['ms'] * 1e3 / a['launches']
+    return rows, total
+
+
+def cpu_baseline(cfg, hc_sd, l_sd, stats, head, seconds):
+    """The oracle on this host's cores, bounded sample of the same workload."""
+    from egonet_amd import synth
+    from oracle import hrnet_oracle, decode_oracle, lifter_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    b = 8
+    x = synth.synth_crops(b, 3, 256, 256, seed=3)
+
+    def one():
+        out = hrnet_oracle.hrnet_forward(hc_sd, cfg, x)
+        maps = (out[0] if isinstance(out, tuple) else out).numpy()
+        xy, _ = decode_oracle.soft_arg_max(maps)
+        kp = (xy * 4.0).reshape(b, -1).astype(np.float64) + 300.0
+        lifter_oracle.lift_2d_to_3d(l_sd, stats, kp)
+
+    one()                                   # warm-up (oneDNN primitive creation)
+    t0 = time.time()
+    reps = 0
+    while True:
+        one()
+        reps += 1
+        if time.time() - t0 >= seconds or reps >= 50:
+            break
+    dt = time.time() - t0
+    return {'value': b * reps / dt, 'unit': 'crops/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d x batch %d crops, HRNet-W48 %s head + soft-arg-max + lifter, torch CPU fp32 '
+                      '(%d threads), %.1f s' % (reps, b, head, cores, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device('cuda', local if world > 1 else 0)
+
+    from egonet_amd import synth
+    from egonet_amd.parallel import shard_range
+    cfg, ego, hc_sd, l_sd = build_model(args.head, dev)
+    B = args.batch
+    # weak scaling: the global batch is world*B crops; this rank owns its contiguous shard
+    lo, hi = shard_range(world * B, world, rank)
+    crops = synth.synth_crops(B, 3, 256, 256, seed=100 + rank).to(dev)
+    boxes = synth.synth_boxes(world * B, seed=5)[lo:hi]
+    from egonet_amd.common.img_proc import modify_bbox
+    rets = [modify_bbox(b, 1.0) for b in boxes]
+    centers = torch.tensor(np.stack([r['c'] for r in rets]), dtype=torch.float64, device=dev)
+    scales = torch.tensor(np.stack([r['s'] for r in rets]), dtype=torch.float64, device=dev)
+    K = np.array([[707.0493, 0., 604.0814], [0., 707.0493, 180.5066], [0., 0., 1.]])
+    decode = 'soft' if args.head == 'heatmap' else 'coords'
+
+    def step():
+        return ego.infer_crops(crops, centers, scales, K=K, decode=decode, to_host=False)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out['kpts_3d']).all()
+
+    result = None
+    if rank == 0:
+        # per-kernel timing of the backbone program (hipEvents around every launch,
+        # on the stream the kernels run on), outside the timed region
+        eng = ego.HC._hip_engine()
+        mode = 1 if decode == 'soft' else None
+        samples = []
+        for it in range(5):
+            eng.forward(crops, decode_mode=mode, timed=True)
+            if it >= 2:
+                samples.append(eng.last_ms)
+        ms = np.mean(samples, axis=0)
+        prog = eng.program(crops, mode)
+        rows, total_ms = kernel_table(prog, ms)
+        dom = rows[0]
+        if dom['flops'] > 0 and dom['flops'] / max(dom['bytes'], 1) > 20:
+            roof = {'bound': 'mfma', 'kernel': dom['klass'], 'achieved': dom['tflops'],
+                    'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_FP32_MFMA_TFLOPS,
+                    'traffic': None, 'launches': dom['launches'], 'avg_us': dom['avg_us'],
+                    'time_share': dom['share']}
+        else:
+            roof = {'bound': 'hbm', 'kernel': dom['klass'], 'achieved': dom['gbps'], 'peak': PEAK_HBM_GBPS,
+                    'unit': 'GB/s', 'frac': dom['gbps'] / PEAK_HBM_GBPS, 'traffic': None,
+                    'launches': dom['launches'], 'avg_us': dom['avg_us'], 'time_share': dom['share']}
+        conv_flops = sum(a['flops'] for a in rows)
+        kernels = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()
+                    if k in ('klass', 'launches', 'ms', 'share', 'tflops', 'gbps', 'avg_us')} for a in rows[:12]]
+        value = world * B * args.steps / dt
+        result = {
+            'metric': 'crops/sec (256x256, heatmap+decode+lift)', 'value': value, 'unit': 'crops/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'configs[1]: batch=%d 256x256 crops/GPU, HRNet-W48 %s head forward + '
+                                   '%s decode + affine + FC lifter + pose solve' % (B, args.head, decode),
+                       'global_batch': world * B, 'weights': 'synthetic (egonet_amd.synth, seeded per key)',
+                       'parallelism': 'replicas x%d, crops sharded by rank, no collective' % world},
+            'roofline': roof,
+            'backbone': {'ms_sum_of_kernels': total_ms, 'gflop_per_crop': conv_flops / B / 1e9,
+                         'tflops_overall': conv_flops / (total_ms * 1e-3) / 1e12,
+                         'frac_of_fp32_peak': conv_flops / (total_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         'launches': len(ms), 'arena_mb': prog.arena_bytes / 2 ** 20,
+                         'weights_mb': prog.weight_bytes / 2 ** 20},
+            'kernels': kernels,
+        }
+        if args.profile_json:
+            with open(args.profile_json, 'w') as f:
+                json.dump({'ops': [dict(m, ms=float(t)) for m, t in zip(prog.meta, ms)], 'classes': rows}, f, indent=1)
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(cfg, hc_sd, l_sd, ego.LS, args.head, args.cpu_seconds)
+        print(json.dumps(result), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -32,6 +32,7 @@ SIGNATURES = {
     'egn_version': (_i, []),
     'egn_strerror': (C.c_char_p, [_i]),
     'egn_conv2d_f32': (_i, [_p] * 6 + [_i] * 14 + [_p]),
+    'egn_conv_plan_query': (_i, [_i] * 13 + [C.POINTER(_i)]),
     'egn_conv_num_configs': (_i, []),
     'egn_conv_config_info': (_i, [_i, C.POINTER(_i), C.POINTER(_i)]),
     'egn_fuse_sum_relu_f32': (_i, [_p, _i, _i, _i, _i, _i, _i, C.POINTER(_p), C.POINTER(_i), _i, _p]),

@@ -152,19 +152,36 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
 
   const int act = a.act & EGN_ACT_MASK;
   const bool res_after = (a.act & EGN_ACT_RES_AFTER) != 0;
-  // epilogue: lane owns rows 4*kq + r (4 consecutive pixels of one output row,
-  // TW % 4 == 0) and column li of every 16x16 sub-tile
+  // epilogue: lane owns rows 4*kq + r (r = 0..3) and column li of every 16x16
+  // sub-tile.  With TW % 4 == 0 the 4 rows are consecutive pixels of one output
+  // row (one decomposition); otherwise each row is decomposed on its own.
+  const int howo = a.Ho * a.Wo;
+  const bool tw4 = (a.TW & 3) == 0;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int m = (wm * MT + mt) * 16 + kq * 4;
-    const int b = m / tile_px;
-    const int rem = m - b * tile_px;
-    const int y = rem / a.TW;
-    const int x = rem - y * a.TW;
-    const int n = n_base + b;
-    const int oy = oy0 + y;
-    const int ox = ox0 + x;
-    if (b >= a.TNB || n >= a.N || oy >= a.Ho) continue;
+    const int m0 = (wm * MT + mt) * 16 + kq * 4;
+    int on[4], sp[4];  // image index and oy*Wo+ox of each row, sp < 0 = not stored
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (r == 0 || !tw4) {
+        const int m = m0 + r;
+        const int b = m / tile_px;
+        const int rem = m - b * tile_px;
+        const int y = rem / a.TW;
+        const int x = rem - y * a.TW;
+        const int oy = oy0 + y;
+        const int ox = ox0 + x;
+        on[r] = n_base + b;
+        sp[r] = (b < a.TNB && on[r] < a.N && oy < a.Ho && ox < a.Wo) ? oy * a.Wo + ox : -1;
+        if (tw4) {  // rows 1..3 follow in x
+#pragma unroll
+          for (int q = 1; q < 4; ++q) {
+            on[q] = on[0];
+            sp[q] = (sp[0] >= 0 && ox + q < a.Wo) ? sp[0] + q : -1;
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int co = n0 + (wn * NT + nt) * 16 + li;
@@ -173,20 +190,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_mfma_kernel(ConvArgs a) {
       const float sh = a.shift[co];
       if (a.out_nchw) {
         if (co >= a.Cout) continue;
-        const size_t base = (((size_t)n * a.Cout + co) * a.Ho + oy) * a.Wo + ox;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (ox + r >= a.Wo) break;
-          float v = acc[mt][nt][r] * sc + sh;
-          a.y[base + r] = egn_act(v, act);
+          if (sp[r] < 0) continue;
+          const size_t idx = ((size_t)on[r] * a.Cout + co) * howo + sp[r];
+          a.y[idx] = egn_act(acc[mt][nt][r] * sc + sh, act);
         }
       } else {
         if (co >= a.cs_out) continue;
-        const size_t base = (((size_t)n * a.Ho + oy) * a.Wo + ox) * a.cs_out + co;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (ox + r >= a.Wo) break;
-          const size_t idx = base + (size_t)r * a.cs_out;
+          if (sp[r] < 0) continue;
+          const size_t idx = ((size_t)on[r] * howo + sp[r]) * a.cs_out + co;
           float v = acc[mt][nt][r] * sc + sh;
           if (a.res && !res_after) v += a.res[idx];
           v = egn_act(v, act);
@@ -217,6 +232,9 @@ static const ConvConfig kConfigs[] = {
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
 extern "C" int egn_conv_num_configs(void) { return kNumConfigs; }
+const ConvConfig* egn_conv_config(int cfg) {
+  return (cfg >= 1 && cfg <= kNumConfigs) ? &kConfigs[cfg - 1] : nullptr;
+}
 extern "C" int egn_conv_config_info(int cfg, int* tile_m, int* tile_n) {
   if (cfg < 1 || cfg > kNumConfigs) return EGN_E_BADARG;
   if (tile_m) *tile_m = kConfigs[cfg - 1].tile_m();
@@ -237,14 +255,14 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
   const int tn = cf.tile_n();
   double best = -1.0;
   ConvArgs bestA = a;
-  for (int tw = 4; tw <= 64 && tw <= tm; tw *= 2) {
+  for (int tw = 1; tw <= 64 && tw <= tm; tw *= 2) {
+    if (tw < 4 && tw < a.Wo) continue;  // narrow tiles only for maps that narrow
     for (int th = 1; th * tw <= tm; th *= 2) {
       const int tnb = tm / (tw * th);
       if (tnb * tw * th != tm) continue;
       // no point in tiles much larger than the map
-      if (tw >= 2 * a.Wo && tw > 4) continue;
+      if (tw >= 2 * a.Wo && tw > 1) continue;
       if (th >= 2 * a.Ho && th > 1) continue;
-      if (tnb >= 2 * a.N && tnb > 1) continue;
       ConvArgs c = a;
       c.TH = th; c.TW = tw; c.TNB = tnb;
       c.HH = (th - 1) * a.stride + a.KH;
@@ -265,7 +283,8 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
       const double tiles = (double)c.tiles_x * c.tiles_y * tiles_b * cdiv(a.CoutP, tn);
       const double mfma = (double)tm * tn * a.taps * EGN_CK;           // per chunk per tile
       const double fill = (double)c.npix * EGN_CK * 24.0 + (double)a.taps * EGN_CK * tn * 12.0;
-      const double cost = tiles * (mfma + fill + 4000.0 * nst);
+      // ties (1x1 convs have no halo): prefer contiguous pixels over many images
+      const double cost = tiles * (mfma + fill + 4000.0 * nst + 64.0 * tnb + 8.0 * th);
       if (best < 0 || cost < best) { best = cost; bestA = c; }
     }
   }

@@ -42,3 +42,4 @@ struct ConvConfig {
 
 int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream);
 int egn_conv_plan(ConvArgs& a, int& cfg_id, size_t& lds_bytes);
+const ConvConfig* egn_conv_config(int cfg);

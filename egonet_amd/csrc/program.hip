@@ -47,6 +47,26 @@ extern "C" int egn_conv2d_f32(const float* x, const float* wpack, const float* s
   return egn_conv_launch(a, cfg, (hipStream_t)stream);
 }
 
+extern "C" int egn_conv_plan_query(int N, int H, int W, int Cin, int cs_in, int Cout, int cs_out, int KH,
+                                   int KW, int stride, int pad, int out_nchw, int cfg, int* out) {
+  if (!out) return EGN_E_BADARG;
+  ConvArgs a;
+  int rc = fill_conv_args(a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, cs_in, Cout,
+                          cs_out, KH, KW, stride, pad, 0, out_nchw);
+  if (rc) return rc;
+  size_t lds;
+  rc = egn_conv_plan(a, cfg, lds);
+  if (rc) return rc;
+  int tm, tn;
+  egn_conv_config_info(cfg, &tm, &tn);
+  const ConvConfig* cf = egn_conv_config(cfg);
+  out[0] = cfg; out[1] = cf->wm; out[2] = cf->wn; out[3] = cf->mt; out[4] = cf->nt;
+  out[5] = a.TH; out[6] = a.TW; out[7] = a.TNB; out[8] = a.tps; out[9] = (int)lds;
+  out[10] = a.tiles_x * a.tiles_y * ((a.N + a.TNB - 1) / a.TNB);
+  out[11] = (a.CoutP + tn - 1) / tn;
+  return 0;
+}
+
 // ---------------------------------------------------------------------------
 // programs
 // ---------------------------------------------------------------------------

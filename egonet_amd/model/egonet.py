@@ -34,6 +34,8 @@ import egonet_amd.model as models  # noqa: F401  (eval() lookup below, like the 
 
 
 def _dev_f64(a, device):
+    if torch.is_tensor(a):      # already resident (benchmarks keep inputs in HBM)
+        return a.to(device=device, dtype=torch.float64).contiguous()
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(device)
 
 

@@ -65,6 +65,13 @@ int egn_conv2d_f32(const float* x, const float* wpack, const float* scale,
                    int Cout, int cs_out, int KH, int KW, int stride, int pad,
                    int act, int out_nchw, int cfg, void* stream);
 
+/* Host-only: the launch plan egn_conv2d_f32 would use (no GPU needed).
+ * out[0..11] = cfg, wm, wn, mt, nt, TH, TW, TNB, taps_per_stage, lds_bytes,
+ *              grid_x, grid_y */
+int egn_conv_plan_query(int N, int H, int W, int Cin, int cs_in, int Cout,
+                        int cs_out, int KH, int KW, int stride, int pad,
+                        int out_nchw, int cfg, int* out);
+
 /* number of tile configurations compiled in; valid ids are 1..count */
 int egn_conv_num_configs(void);
 /* describe config id: tile_m (output pixels), tile_n (output channels) */

@@ -1,0 +1,103 @@
+"""CPU checks of the conv kernel DESIGN: the product's weight packing
+(egonet_amd.engine.pack_conv_weight / fold_scale_shift), the library's host
+tile planner (egn_conv_plan_query) and the lane-level dataflow restated in
+tests/conv_emulator.py, against torch.nn.functional.conv2d."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import conv_emulator
+from egonet_amd import engine, _lib
+
+
+def _plan(args, cfg=0):
+    out = (C.c_int * 12)()
+    rc = _lib.lib().egn_conv_plan_query(*args, cfg, out)
+    assert rc == 0, rc
+    return list(out)
+
+
+CASES = [
+    # N  H   W  Cin Cout k  s  p  act res  nchw  cfg
+    (2, 8, 8, 20, 24, 3, 1, 1, 1, True, False, 0),     # ragged channels, residual, relu
+    (1, 9, 7, 16, 16, 3, 2, 1, 0, False, False, 0),    # odd map, stride 2
+    (3, 4, 4, 6, 10, 4, 1, 0, 2, False, True, 0),      # 4x4 valid conv + sigmoid, NCHW out
+    (2, 6, 10, 35, 7, 1, 1, 0, 0, False, True, 0),     # 1x1 head with bias, NCHW out
+    (5, 1, 1, 10, 40, 1, 1, 0, 0x11, True, False, 0),  # Linear with residual-after-act
+    (1, 12, 12, 8, 48, 3, 1, 1, 1, False, False, 6),   # forced config (128x48)
+    (1, 8, 8, 4, 64, 3, 2, 1, 1, False, False, 8),     # stem-like, forced 64x64
+]
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_emulated_kernel_matches_conv2d(case):
+    n, h, w, cin, cout, k, s, p, act, use_res, nchw, cfg = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    cs_in = (cin + 3) // 4 * 4
+    cs_out = cout if nchw else (cout + 3) // 4 * 4
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / np.sqrt(cin * k * k)
+    bias = torch.randn(cout, generator=g)
+    bn = torch.nn.BatchNorm2d(cout)
+    bn.weight.data = 0.5 + torch.rand(cout, generator=g)
+    bn.bias.data = torch.randn(cout, generator=g) * 0.2
+    bn.running_mean = torch.randn(cout, generator=g) * 0.2
+    bn.running_var = 0.5 + torch.rand(cout, generator=g)
+    bn.eval()
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    res = torch.randn(n, cout, ho, wo, generator=g) if use_res else None
+
+    with torch.no_grad():
+        ref = bn(F.conv2d(x, wt, bias, s, p))
+        a = act & 0xf
+        f = {0: lambda t: t, 1: F.relu, 2: torch.sigmoid, 3: lambda t: F.leaky_relu(t, 0.01)}[a]
+        if res is not None and not (act & 0x10):
+            ref = ref + res
+        ref = f(ref)
+        if res is not None and (act & 0x10):
+            ref = res + ref
+
+    x_nhwc = np.zeros((n, h, w, cs_in), np.float32)
+    x_nhwc[..., :cin] = x.permute(0, 2, 3, 1).numpy()
+    res_nhwc = None
+    if res is not None:
+        res_nhwc = np.zeros((n, ho, wo, cs_out), np.float32)
+        res_nhwc[..., :cout] = res.permute(0, 2, 3, 1).numpy()
+    wpack = engine.pack_conv_weight(wt).numpy()
+    scale, shift = engine.fold_scale_shift(cout, bias, bn)
+    plan = _plan((n, h, w, cin, cs_in, cout, cs_out, k, k, s, p, int(nchw)), cfg)
+    y = conv_emulator.emulate(x_nhwc, wpack, scale.numpy(), shift.numpy(), res_nhwc, plan, n, h, w, cin,
+                              cs_in, cout, cs_out, k, k, s, p, act, nchw)
+    if nchw:
+        got = y
+    else:
+        assert np.all(y[..., cout:] == 0.0), 'pad channels must be written as zeros'
+        got = y[..., :cout].transpose(0, 3, 1, 2)
+    assert not np.isnan(got).any(), 'every output element must be written exactly by some lane'
+    np.testing.assert_allclose(got, ref.numpy(), rtol=0, atol=2e-5)
+
+
+def test_pack_layout_is_chunk_tap_quad_cout_4():
+    wt = torch.arange(2 * 5 * 3 * 3, dtype=torch.float32).reshape(2, 5, 3, 3)
+    p = engine.pack_conv_weight(wt).reshape(1, 9, 4, 16, 4)      # [chunk][tap][quad][CoutP][r]
+    for co in range(2):
+        for ci in range(5):
+            for t in range(9):
+                assert p[0, t, ci // 4, co, ci % 4] == wt[co, ci, t // 3, t % 3]
+    assert p[0, :, :, 2:, :].abs().sum() == 0 and p[0, :, 1, :, 1:].abs().sum() == 0
+
+
+def test_planner_limits():
+    # every HRNet-W48 layer class fits the default 64 KB LDS budget and keeps TW sane
+    for args in [(64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0), (64, 8, 8, 384, 384, 384, 384, 3, 3, 1, 1, 0),
+                 (64, 256, 256, 3, 4, 64, 64, 3, 3, 2, 1, 0), (64, 1, 1, 66, 68, 1024, 1024, 1, 1, 1, 0, 0)]:
+        plan = _plan(args)
+        assert plan[9] <= 64 * 1024
+        wm, wn, mt, nt, th, tw, tnb = plan[1:8]
+        assert th * tw * tnb == wm * mt * 16
+    # bad arguments are reported, not crashed on
+    out = (C.c_int * 12)()
+    assert _lib.lib().egn_conv_plan_query(1, 8, 8, 6, 6, 8, 8, 3, 3, 1, 1, 0, 0, out) == -1   # cs_in % 4

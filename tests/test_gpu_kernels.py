@@ -1,0 +1,211 @@
+"""Kernel-level parity on a real MI355X: every HIP kernel, called through the C
+ABI, against the CPU oracle (torch fp32 / numpy restatements) on seeded inputs.
+
+Tolerances: fp32 conv / GEMM outputs 2e-4 abs on O(1) activations (the budget
+of BASELINE.json is 1e-3 on key-points), arg-max indices bit exact.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import golden
+from oracle import decode_oracle, geometry_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _bn(cout, g):
+    bn = torch.nn.BatchNorm2d(cout)
+    bn.weight.data = 0.5 + torch.rand(cout, generator=g)
+    bn.bias.data = torch.randn(cout, generator=g) * 0.2
+    bn.running_mean = torch.randn(cout, generator=g) * 0.2
+    bn.running_var = 0.5 + torch.rand(cout, generator=g)
+    return bn.eval()
+
+
+def _conv_case(n, h, w, cin, cout, k, s, p, act=1, use_res=False, nchw=False, cfg=0, seed=0, bias=False):
+    from egonet_amd import ops
+    g = torch.Generator().manual_seed(1000 + seed)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = (torch.rand(cout, cin, k, k, generator=g) * 2 - 1) / np.sqrt(cin * k * k) * 1.7
+    b = torch.randn(cout, generator=g) * 0.3 if bias else None
+    bn = _bn(cout, g)
+    ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+    res = torch.randn(n, cout, ho, wo, generator=g) if use_res else None
+    with torch.no_grad():
+        ref = bn(F.conv2d(x, wt, b, s, p))
+        a = act & 0xf
+        f = {0: lambda t: t, 1: F.relu, 2: torch.sigmoid, 3: lambda t: F.leaky_relu(t, 0.01)}[a]
+        if res is not None and not (act & 0x10):
+            ref = ref + res
+        ref = f(ref)
+        if res is not None and (act & 0x10):
+            ref = res + ref
+    pc = ops.PackedConv(wt, b, bn)
+    xd = ops.nchw_to_nhwc(x.cuda())
+    rd = ops.nchw_to_nhwc(res.cuda()) if res is not None else None
+    y = ops.conv2d_nhwc(xd, pc, cin, s, p, act, rd, out_nchw=nchw, cfg=cfg)
+    torch.cuda.synchronize()
+    if nchw:
+        got = y.cpu()
+    else:
+        assert float(y[..., cout:].abs().max() if y.shape[-1] > cout else 0.0) == 0.0
+        got = ops.nhwc_to_nchw(y, cout).cpu()
+    err = (got - ref).abs().max().item()
+    assert torch.isfinite(got).all()
+    return err
+
+
+# the shape classes of HRNet-W48 @256x256 at small batch + edge shapes
+HRNET_SHAPES = [
+    # n   h    w   cin  cout k  s  p
+    (2, 64, 64, 48, 48, 3, 1, 1),
+    (2, 32, 32, 96, 96, 3, 1, 1),
+    (2, 16, 16, 192, 192, 3, 1, 1),
+    (3, 8, 8, 384, 384, 3, 1, 1),
+    (2, 64, 64, 64, 64, 3, 1, 1),
+    (1, 64, 64, 256, 48, 3, 1, 1),
+    (1, 64, 64, 256, 96, 3, 2, 1),
+    (2, 256, 256, 3, 64, 3, 2, 1),
+    (2, 128, 128, 64, 64, 3, 2, 1),
+    (2, 64, 64, 48, 96, 3, 2, 1),
+    (2, 16, 16, 192, 384, 3, 2, 1),
+    (2, 64, 64, 64, 256, 1, 1, 0),
+    (2, 64, 64, 256, 64, 1, 1, 0),
+    (2, 32, 32, 96, 48, 1, 1, 0),
+    (2, 8, 8, 384, 48, 1, 1, 0),
+    (2, 64, 64, 35, 66, 3, 2, 1),
+    (2, 64, 64, 35, 66, 1, 2, 0),
+    (3, 4, 4, 66, 66, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize('shape', HRNET_SHAPES)
+def test_conv_hrnet_shapes(shape):
+    n, h, w, cin, cout, k, s, p = shape
+    err = _conv_case(n, h, w, cin, cout, k, s, p, act=1, use_res=(s == 1 and k == 3), seed=cin + cout)
+    assert err < 2e-4, err
+
+
+@pytest.mark.parametrize('cfg', list(range(1, 11)))
+def test_conv_every_tile_config(cfg):
+    # odd sizes: partial tiles in x, y, batch and channels
+    err = _conv_case(3, 19, 13, 20, 40, 3, 1, 1, act=1, use_res=True, cfg=cfg, seed=cfg)
+    assert err < 2e-4, (cfg, err)
+    err = _conv_case(2, 11, 9, 37, 70, 3, 2, 1, act=0, cfg=cfg, seed=50 + cfg)
+    assert err < 2e-4, (cfg, err)
+
+
+def test_conv_heads_and_linear():
+    assert _conv_case(2, 64, 64, 48, 33, 1, 1, 0, act=0, nchw=True, bias=True, seed=1) < 2e-4
+    assert _conv_case(5, 4, 4, 66, 66, 4, 1, 0, act=2, nchw=True, bias=True, seed=2) < 2e-5     # 4x4 valid + sigmoid
+    assert _conv_case(3, 4, 3, 10, 10, 4, 1, 0, act=2, nchw=True, bias=True, seed=3) < 2e-5     # non-square valid
+    assert _conv_case(64, 1, 1, 66, 1024, 1, 1, 0, act=1, bias=True, seed=4) < 2e-4             # Linear 66->1024
+    assert _conv_case(64, 1, 1, 1024, 1024, 1, 1, 0, act=0x11, use_res=True, bias=True, seed=5) < 3e-4
+    assert _conv_case(7, 1, 1, 1024, 96, 1, 1, 0, act=0, nchw=True, bias=True, seed=6) < 3e-4
+    assert _conv_case(1, 1, 1, 10, 12, 1, 1, 0, act=3, bias=True, seed=7) < 2e-5                # leaky, N=1
+
+
+def test_fuse_sum_relu_and_layouts():
+    from egonet_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n, c = 2, 48
+    t0 = torch.randn(n, c, 32, 32, generator=g)
+    t1 = torch.randn(n, c, 16, 16, generator=g)
+    t2 = torch.randn(n, c, 8, 8, generator=g)
+    t3 = torch.randn(n, c, 4, 4, generator=g)
+    ref = F.relu(((t0 + F.interpolate(t1, scale_factor=2, mode='nearest'))
+                  + F.interpolate(t2, scale_factor=4, mode='nearest'))
+                 + F.interpolate(t3, scale_factor=8, mode='nearest'))
+    d = [ops.nchw_to_nhwc(t.cuda()) for t in (t0, t1, t2, t3)]
+    y = ops.fuse_sum_relu(d, [0, 1, 2, 3], c)
+    assert torch.equal(ops.nhwc_to_nchw(y, c).cpu(), ref)          # same association order -> bit exact
+    # term order with the identity in the middle (branch 1 of a 3-branch module)
+    ref = F.relu((t1 + t1 * 2) + F.interpolate(t2, scale_factor=2, mode='nearest'))
+    y = ops.fuse_sum_relu([d[1], ops.nchw_to_nhwc((t1 * 2).cuda()), d[2]], [0, 0, 1], c)
+    assert torch.equal(ops.nhwc_to_nchw(y, c).cpu(), ref)
+    # layout round trip with channel padding (35 -> 36) and pad zeroing
+    x = torch.randn(3, 35, 5, 7, generator=g)
+    xn = ops.nchw_to_nhwc(x.cuda())
+    assert xn.shape == (3, 5, 7, 36) and float(xn[..., 35].abs().max()) == 0.0
+    assert torch.equal(ops.nhwc_to_nchw(xn, 35).cpu(), x)
+    # coordinate ramps == the reference's linspace maps (hrnet.py:461-467)
+    from oracle.hrnet_oracle import coordinate_ramps
+    buf = torch.zeros(2, 64, 48, 36, device='cuda')
+    ops.fill_coord_ramps(buf, 33)
+    ramps = coordinate_ramps(48, 64)
+    assert torch.equal(buf[..., 33:35].permute(0, 3, 1, 2).cpu(), ramps.expand(2, -1, -1, -1))
+
+
+def test_decode_kernels_edge_cases_and_golden():
+    from egonet_amd.common import img_proc
+    g = golden('decode.npz')
+    hm = torch.from_numpy(g['hm']).cuda()
+    xy, mx, idx = img_proc.hard_arg_max(hm)
+    assert np.array_equal(xy.cpu().numpy(), g['hard_preds'])        # masked / tie / all-equal maps
+    assert np.array_equal(mx.cpu().numpy(), g['hard_maxvals'])
+    want_idx, _ = decode_oracle.argmax_index(g['hm'])
+    assert np.array_equal(idx.cpu().numpy(), want_idx)
+    sxy, smx = img_proc.soft_arg_max(hm)
+    np.testing.assert_allclose(sxy.cpu().numpy(), g['soft_preds'], rtol=0, atol=1e-4)
+    assert np.array_equal(smx.cpu().numpy(), g['soft_maxvals'])
+    # numpy contract of get_max_preds
+    p, m = img_proc.get_max_preds(g['hm'])
+    assert isinstance(p, np.ndarray) and np.array_equal(p, g['hard_preds'])
+    # large random batch vs the oracle (full-size maps)
+    rng = np.random.RandomState(0)
+    big = (rng.randn(64, 33, 64, 64) * 4).astype(np.float32)
+    t = torch.from_numpy(big).cuda()
+    xy, mx, idx = img_proc.hard_arg_max(t)
+    oi, om = decode_oracle.argmax_index(big)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(mx.cpu().numpy(), om)
+    sxy, _ = img_proc.soft_arg_max(t)
+    want, _ = decode_oracle.soft_arg_max(big)
+    np.testing.assert_allclose(sxy.cpu().numpy(), want, rtol=0, atol=1e-3)
+    # empty batch
+    e = torch.zeros(0, 33, 64, 64, device='cuda')
+    xy, mx, idx = img_proc.hard_arg_max(e)
+    assert xy.shape == (0, 33, 2)
+
+
+def test_geometry_kernels_vs_fixtures():
+    import ctypes as C
+    from egonet_amd import _lib
+    L = _lib.lib()
+    g = golden('pose_solve.npz')
+    n = len(g['preds'])
+    p = torch.from_numpy(g['preds'].reshape(n, -1)).cuda()
+    kx = torch.from_numpy(g['kpts_x']).cuda()
+    e = torch.empty(n, 3, dtype=torch.float64, device='cuda')
+    a = torch.empty(n, dtype=torch.float64, device='cuda')
+    K = g['K']
+    st = _lib.current_stream()
+    _lib.check(L.egn_pose_solve_f64(_lib.ptr(p), n, _lib.ptr(kx), K[0, 0], K[0, 2], 0, _lib.ptr(e), _lib.ptr(a), st))
+    np.testing.assert_allclose(e.cpu().numpy(), g['euler'], atol=1e-9)
+    np.testing.assert_allclose(a.cpu().numpy(), g['alpha_proj'], atol=1e-9)
+    _lib.check(L.egn_pose_solve_f64(_lib.ptr(p), n, None, 1.0, 0.0, 1, _lib.ptr(e), _lib.ptr(a), st))
+    np.testing.assert_allclose(a.cpu().numpy(), g['alpha_trans'], atol=1e-9)
+    assert L.egn_pose_solve_f64(_lib.ptr(p), n, None, 1.0, 0.0, 0, _lib.ptr(e), _lib.ptr(a), st) == -1
+    # crop -> screen -> normalise
+    from egonet_amd import synth
+    boxes = synth.synth_boxes(50, seed=4)
+    rets = [geometry_oracle.modify_bbox(b, 1.0) for b in boxes]
+    c = np.stack([r['c'] for r in rets])
+    s = np.stack([r['s'] for r in rets])
+    rng = np.random.RandomState(1)
+    local = rng.uniform(0, 1, (50, 33, 2)).astype(np.float32)
+    stats = synth.synth_lifter_stats()
+    scr = torch.empty(50, 66, dtype=torch.float64, device='cuda')
+    lin = torch.zeros(50, 68, dtype=torch.float32, device='cuda')
+    d = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).cuda()
+    ld, cd, sd, mi, si = torch.from_numpy(local).cuda(), d(c), d(s), d(stats['mean_in'].ravel()), d(stats['std_in'].ravel())
+    _lib.check(L.egn_keypoints_to_screen_f64(_lib.ptr(ld), 50, 33, 256.0, 256.0, _lib.ptr(cd), _lib.ptr(sd), 256, 256,
+                                             _lib.ptr(scr), _lib.ptr(mi), _lib.ptr(si), _lib.ptr(lin), 68, st))
+    want = np.stack([geometry_oracle.crop_to_screen((local[i] * 256).astype(np.float32), c[i], s[i], (256, 256)).reshape(-1)
+                     for i in range(50)])
+    np.testing.assert_allclose(scr.cpu().numpy(), want, rtol=0, atol=1e-9)
+    want_in = ((want - stats['mean_in']) / stats['std_in']).astype(np.float32)
+    np.testing.assert_allclose(lin.cpu().numpy()[:, :66], want_in, rtol=0, atol=1e-6)
+    assert float(lin[:, 66:].abs().max()) == 0.0

@@ -1,0 +1,74 @@
+"""Drop-in boundary on CPU: checkpoint layout, factory behaviour and the
+torch-functional (CPU tensor) forward of the module mirrors vs the oracle."""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from egonet_amd import configs, synth
+from egonet_amd.model.heatmapModel import hrnet
+from egonet_amd.model import FCmodel
+from oracle import hrnet_oracle, lifter_oracle
+
+
+def _key_crc(sd):
+    return zlib.crc32('\n'.join('%s %s' % (k, tuple(v.shape)) for k, v in sd.items()).encode())
+
+
+@pytest.mark.parametrize('head', ['coordinates', 'heatmap'])
+def test_checkpoint_layout_equals_reference(head):
+    g = golden('hrnet_w48_outputs.npz')
+    net = hrnet.get_pose_net(configs.w48_config(head), is_train=False)
+    sd = net.state_dict()
+    assert len(sd) == int(g[head + '/n_keys']) == (1828 if head == 'coordinates' else 1754)
+    assert sum(p.numel() for p in net.parameters()) == int(g[head + '/n_params'])
+    assert _key_crc(sd) == int(g[head + '/key_crc'])        # names, shapes AND order
+    assert 'coor_maps' not in sd and not any('coor_maps' in k for k in sd)
+
+
+def test_cpu_forward_matches_oracle_and_factory_side_effects(capsys):
+    cfg = configs.tiny_config('coordinates')
+    cfg['heatmapModel']['extra']['freeze_layers'] = ['conv1', 'layer1']
+    net = hrnet.get_pose_net(cfg, is_train=True)           # init_weights path (N(0,1e-3) convs, BN 1/0)
+    assert 'conv1.weight freezed during training.' in capsys.readouterr().out
+    assert not net.conv1.weight.requires_grad and net.conv2.weight.requires_grad
+    assert abs(float(net.conv2.weight.std()) - 1e-3) < 3e-4 and float(net.bn2.weight.min()) == 1.0
+    sd = synth.synth_state_dict(net.state_dict(), seed=3)
+    net.load_state_dict(sd)
+    net.eval()
+    x = synth.synth_crops(2, 3, 64, 64, seed=5)
+    with torch.no_grad():
+        maps, coords = net(x)
+    om, oc = hrnet_oracle.hrnet_forward(sd, cfg, x)
+    assert torch.equal(maps, om) and torch.equal(coords, oc)
+    with pytest.raises(ValueError):
+        c2 = configs.tiny_config()
+        c2['heatmapModel']['pretrained'] = '/nonexistent/HC.pth'
+        hrnet.get_pose_net(c2, is_train=True)
+    with pytest.raises(NotImplementedError):
+        c3 = configs.tiny_config()
+        c3['heatmapModel']['head_type'] = 'bogus'
+        hrnet.get_pose_net(c3, is_train=False)
+    # add_xy widens conv1 to 5 input channels keeping the RGB filters
+    c4 = configs.tiny_config()
+    c4['heatmapModel']['add_xy'] = True
+    assert hrnet.get_pose_net(c4, is_train=False).conv1.weight.shape == (64, 5, 3, 3)
+
+
+def test_lifter_mirror_cpu_and_training_mode():
+    cfg = configs.w48_config()
+    net = FCmodel.get_fc_model(1, cfg, 66, 96)
+    sd = synth.synth_state_dict(net.state_dict(), seed=2)
+    net.load_state_dict(sd)
+    assert list(sd)[:4] == ['w1.weight', 'w1.bias', 'batch_norm1.weight', 'batch_norm1.bias']
+    net.eval()
+    x = torch.randn(5, 66, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        assert torch.allclose(net(x), lifter_oracle.lifter_forward(sd, x), atol=1e-6)
+    net.train()                                            # dropout + batch statistics: autograd path works
+    y = net(x)
+    y.sum().backward()
+    assert net.w1.weight.grad is not None
+    assert len(FCmodel.get_cascade()) == 0
