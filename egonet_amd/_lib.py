@@ -72,6 +72,10 @@ def lib():
     """Load (once) and return the ctypes handle; raises if it is not built."""
     global _LIB
     if _LIB is None:
+        # torch bundles its own libamdhip64; it must be the HIP runtime of the
+        # process, so torch is imported BEFORE the library is dlopen'ed (loading
+        # /opt/rocm's copy first gives two runtimes and "no ROCm-capable device")
+        import torch  # noqa: F401
         if not os.path.isfile(LIB_PATH):
             raise EgonetHipError(
                 'egonet_amd: %s is missing -- build it with `python -m egonet_amd.build` '

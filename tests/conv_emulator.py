@@ -49,13 +49,22 @@ def emulate(x, wpack, scale, shift, res, plan, N, H, W, Cin, cs_in, Cout, cs_out
     for tile in range(gx):
         tx, ty, tb = tile % tiles_x, (tile // tiles_x) % tiles_y, tile // (tiles_x * tiles_y)
         n_base, oy0, ox0 = tb * TNB, ty * TH, tx * TW
-        sOff = np.full(npix, -1, dtype=np.int64)
-        for p in range(npix):
-            hx, r = p % HW, p // HW
-            hy, b = r % HH, r // HH
-            n, iy, ix = n_base + b, oy0 * stride - pad + hy, ox0 * stride - pad + hx
-            if n < N and 0 <= iy < H and 0 <= ix < W:
-                sOff[p] = ((n * H + iy) * W + ix) * cs_in
+        # per-lane staging offsets (element units here; bytes in the kernel), None = OOB -> zeros
+        tids = np.arange(256)
+        A_IT = -(-npix * CKQ // 256)
+        aoff = {}
+        for tid in tids:
+            q, p0 = tid & 3, tid >> 2
+            for it in range(A_IT):
+                p = p0 + it * 64
+                off = None
+                if p < npix:
+                    hx, r = p % HW, p // HW
+                    hy, b = r % HH, r // HH
+                    n, iy, ix = n_base + b, oy0 * stride - pad + hy, ox0 * stride - pad + hx
+                    if n < N and 0 <= iy < H and 0 <= ix < W:
+                        off = ((n * H + iy) * W + ix) * cs_in + q * 4
+                aoff[(tid, it)] = off
         for by in range(gy):
             n0 = by * TN
             acc = np.zeros((WM * WN, MT, NT, 16, 16), dtype=np.float32)
@@ -64,20 +73,24 @@ def emulate(x, wpack, scale, shift, res, plan, N, H, W, Cin, cs_in, Cout, cs_out
                 for t0 in range(0, taps, tps):
                     if t0 == 0:
                         sA[:] = np.nan
-                        for e in range(npix * CKQ):
-                            q, p = e & 3, e >> 2
-                            ci = c * CK + q * 4
-                            v = np.zeros(4, np.float32)
-                            if sOff[p] >= 0 and ci < cs_in:
-                                v = xf[sOff[p] + ci: sOff[p] + ci + 4]
-                            sA[q, p ^ (q << 1)] = v
+                        for tid in tids:
+                            q, p0 = tid & 3, tid >> 2
+                            cpad = (c * CK + q * 4) >= cs_in
+                            for it in range(A_IT):
+                                p = p0 + it * 64
+                                if p >= npix:
+                                    continue
+                                off = aoff[(tid, it)]
+                                v = np.zeros(4, np.float32)
+                                if off is not None and not cpad:
+                                    v = xf[off + c * CK: off + c * CK + 4]
+                                sA[q, p ^ (q << 1)] = v
                     nts = min(tps, taps - t0)
-                    sB = np.zeros((nts * CKQ * TN, 4), dtype=np.float32)
+                    sB = np.full((nts * CKQ * TN, 4), np.nan, dtype=np.float32)
                     wbase = (c * taps + t0) * CKQ * CoutP
-                    for e in range(nts * CKQ * TN):
+                    for e in range(nts * CKQ * TN):        # e = tid + it*256
                         j, tq = e % TN, e // TN
-                        if n0 + j < CoutP:
-                            sB[e] = w4[wbase + tq * CoutP + n0 + j]
+                        sB[e] = w4[wbase + tq * CoutP + n0 + j] if n0 + j < CoutP else 0.0
                     for wave in range(WM * WN):
                         wm, wn = wave // WN, wave % WN
                         for tt in range(nts):
@@ -100,6 +113,52 @@ def emulate(x, wpack, scale, shift, res, plan, N, H, W, Cin, cs_in, Cout, cs_out
                                     for s in range(4):
                                         mfma_16x16x4(af[mt][:, s], bf[nt][:, s], acc[wave, mt, nt])
             # epilogue
+            if not out_nchw:
+                TNW = NT * 16
+                SC_LD = TNW + 4
+                TMb = WM * MT * 16
+                sPix = np.full(TMb, -1, dtype=np.int64)
+                for m in range(TMb):
+                    b = m // tile_px
+                    rem = m - b * tile_px
+                    yy, xx = rem // TW, rem % TW
+                    n, oy, ox = n_base + b, oy0 + yy, ox0 + xx
+                    if b < TNB and n < N and oy < Ho and ox < Wo:
+                        sPix[m] = (n * Ho + oy) * Wo + ox
+                yf = y.reshape(-1)
+                rf = res.reshape(-1) if res is not None else None
+                for wave in range(WM * WN):
+                    wm, wn = wave // WN, wave % WN
+                    sC = np.full((MT * 16, SC_LD), np.nan, dtype=np.float32)
+                    for lane in range(64):
+                        l_i, k_q = lane & 15, lane >> 4
+                        for nt in range(NT):
+                            co = n0 + (wn * NT + nt) * 16 + l_i
+                            sc, sh = (scale[co], shift[co]) if co < CoutP else (0.0, 0.0)
+                            for mt in range(MT):
+                                for r in range(4):
+                                    sC[mt * 16 + k_q * 4 + r, nt * 16 + l_i] = \
+                                        np.float32(acc[wave, mt, nt][k_q * 4 + r, l_i] * sc + sh)
+                    C4 = TNW // 4
+                    for idx in range(MT * 16 * C4):
+                        row, c4 = idx // C4, idx % C4
+                        pix = sPix[wm * MT * 16 + row]
+                        co = n0 + wn * TNW + c4 * 4
+                        if pix < 0 or co >= cs_out:
+                            continue
+                        v = sC[row, c4 * 4: c4 * 4 + 4].copy()
+                        g0 = pix * cs_out + co
+                        if rf is not None and not res_after:
+                            v = v + rf[g0:g0 + 4]
+                        v = np.array([_act(t, act_id) for t in v], dtype=np.float32)
+                        if rf is not None and res_after:
+                            v = rf[g0:g0 + 4] + v
+                        for k in range(4):
+                            if co + k >= Cout:
+                                v[k] = 0.0
+                        assert np.all(np.isnan(yf[g0:g0 + 4])), 'element stored twice'
+                        yf[g0:g0 + 4] = v
+                continue
             for wave in range(WM * WN):
                 wm, wn = wave // WN, wave % WN
                 for mt in range(MT):
@@ -114,23 +173,10 @@ def emulate(x, wpack, scale, shift, res, plan, N, H, W, Cin, cs_in, Cout, cs_out
                                 continue
                             for nt in range(NT):
                                 co = n0 + (wn * NT + nt) * 16 + (lane & 15)
-                                if co >= CoutP:
+                                if co >= Cout:
                                     continue
                                 v = acc[wave, mt, nt][(lane >> 4) * 4 + r, lane & 15] * scale[co] + shift[co]
-                                if out_nchw:
-                                    if co < Cout:
-                                        y[n, co, oy, ox] = _act(v, act_id)
-                                    continue
-                                if co >= cs_out:
-                                    continue
-                                if res is not None and not res_after:
-                                    v = v + res[n, oy, ox, co]
-                                v = _act(v, act_id)
-                                if res is not None and res_after:
-                                    v = res[n, oy, ox, co] + v
-                                if co >= Cout:
-                                    v = 0.0
-                                y[n, oy, ox, co] = v
+                                y[n, co, oy, ox] = _act(v, act_id)
     return y
 
 
