@@ -3,8 +3,12 @@
     python -m egonet_amd.build [--force]
 
 hipcc cross-compiles without a GPU.  The shared object is git-ignored but
-travels with the repo snapshot to the GPU box.
+travels with the repo snapshot to the GPU box.  The library is linked to a
+temporary name, dlopen'ed (catches undefined symbols such as a kernel stub the
+compiler silently dropped) and only then moved into place, so a failed build
+never leaves a stale library behind.
 """
+import ctypes
 import glob
 import os
 import subprocess
@@ -33,11 +37,22 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    tmp = OUT + '.tmp'
     cmd = [hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-shared', '-fPIC',
-           '-Wno-unused-result', '-o', OUT] + sources()
+           '-Wno-unused-result', '-Wno-unused-value', '-o', tmp] + sources()
     if verbose:
         print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        import torch  # noqa: F401  (its libamdhip64 must be the process' HIP runtime)
+        ctypes.CDLL(tmp)
+    except Exception:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        if os.path.exists(OUT):
+            os.remove(OUT)
+        raise
+    os.replace(tmp, OUT)
     return OUT
 
 

@@ -1,0 +1,164 @@
+// conv_plan.hip -- host side of the convolution: tile configurations, the launch
+// planner (spatial tile, taps per stage, LDS budget) and the dispatcher.
+//
+// Two kernel families share the tile shapes:
+//   ids  1..10  "staged": global -> registers -> LDS, one LDS buffer, 2 barriers
+//               per stage, ~50 KB LDS -> 3 blocks per CU   (conv_mfma.hip)
+//   ids 11..20  "dma":    buffer_load ... lds straight into a double-buffered
+//               LDS stage, 1 barrier per stage, register double-buffered
+//               fragments                                   (conv_dma.hip)
+// The engine's tuner times the candidates on the real shape; cfg 0 = cost model.
+#include "egn_internal.h"
+
+int egn_conv_launch_staged(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
+int egn_conv_launch_dma(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
+
+static const ConvConfig kConfigs[] = {
+    // id wm wn mt nt ai bi dma (ai / bi = staging depth in dwordx4 per lane)
+    {1, 4, 1, 4, 3, 6, 7, 0},   // 256 x 48   (C = 48 layers)
+    {2, 2, 2, 4, 3, 6, 8, 0},   // 128 x 96   (C = 96)
+    {3, 2, 2, 4, 2, 8, 8, 0},   // 128 x 64   (C = 64, 192, 256, 384)
+    {4, 4, 1, 4, 1, 8, 8, 0},   // 256 x 16
+    {5, 4, 1, 4, 2, 8, 8, 0},   // 256 x 32
+    {6, 4, 1, 2, 3, 8, 8, 0},   // 128 x 48
+    {7, 2, 2, 2, 3, 8, 8, 0},   //  64 x 96
+    {8, 2, 2, 2, 2, 8, 8, 0},   //  64 x 64
+    {9, 1, 4, 4, 1, 8, 8, 0},   //  64 x 64 (one M strip, N across waves)
+    {10, 1, 4, 2, 3, 8, 8, 0},  //  32 x 192
+    {11, 4, 1, 4, 3, 8, 8, 1},  // the same tile shapes, LDS-DMA pipeline
+    {12, 2, 2, 4, 3, 8, 8, 1},
+    {13, 2, 2, 4, 2, 8, 8, 1},
+    {14, 4, 1, 4, 1, 8, 8, 1},
+    {15, 4, 1, 4, 2, 8, 8, 1},
+    {16, 4, 1, 2, 3, 8, 8, 1},
+    {17, 2, 2, 2, 3, 8, 8, 1},
+    {18, 2, 2, 2, 2, 8, 8, 1},
+    {19, 1, 4, 4, 1, 8, 8, 1},
+    {20, 1, 4, 2, 3, 8, 8, 1},
+};
+static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
+
+extern "C" int egn_conv_num_configs(void) { return kNumConfigs; }
+const ConvConfig* egn_conv_config(int cfg) {
+  return (cfg >= 1 && cfg <= kNumConfigs) ? &kConfigs[cfg - 1] : nullptr;
+}
+extern "C" int egn_conv_config_info(int cfg, int* tile_m, int* tile_n) {
+  if (cfg < 1 || cfg > kNumConfigs) return EGN_E_BADARG;
+  if (tile_m) *tile_m = kConfigs[cfg - 1].tile_m();
+  if (tile_n) *tile_n = kConfigs[cfg - 1].tile_n();
+  return 0;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
+  size_t main_loop = (size_t)(EGN_CKQ * a.npixp + a.tps * EGN_CKQ * cf.tile_n()) * 16;
+  if (cf.dma) main_loop *= 2;  // double-buffered stage
+  // epilogue: 4 waves x (MT*16 rows) x (NT*16 + 4) floats + TM pixel indices
+  const size_t epi = a.out_nchw ? 0 : (size_t)4 * cf.mt * 16 * (cf.nt * 16 + 4) * 4 + (size_t)cf.tile_m() * 4;
+  return main_loop > epi ? main_loop : epi;
+}
+
+// Choose the spatial tile for a config: minimise (MFMA work incl. padding +
+// LDS fill work) over power-of-two tile shapes, subject to the LDS budget and
+// to the per-lane staging depth (ai / bi dwordx4 loads per stage).
+static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, double* cost_out) {
+  const int tm = cf.tile_m();
+  const int tn = cf.tile_n();
+  double best = -1.0;
+  ConvArgs bestA = a;
+  for (int tw = 1; tw <= 64 && tw <= tm; tw *= 2) {
+    if (tw < 4 && tw < a.Wo) continue;  // narrow tiles only for maps that narrow
+    for (int th = 1; th * tw <= tm; th *= 2) {
+      const int tnb = tm / (tw * th);
+      if (tnb * tw * th != tm) continue;
+      // no point in tiles much larger than the map
+      if (tw >= 2 * a.Wo && tw > 1) continue;
+      if (th >= 2 * a.Ho && th > 1) continue;
+      ConvArgs c = a;
+      c.TH = th; c.TW = tw; c.TNB = tnb;
+      c.HH = (th - 1) * a.stride + a.KH;
+      c.HW = (tw - 1) * a.stride + a.KW;
+      c.npix = tnb * c.HH * c.HW;
+      c.npixp = (c.npix + 15) & ~15;
+      if (c.npix * EGN_CKQ > cf.ai * 256) continue;
+      c.tiles_x = cdiv(a.Wo, tw);
+      c.tiles_y = cdiv(a.Ho, th);
+      const int tiles_b = cdiv(a.N, tnb);
+      // taps per stage: as many as fit the LDS budget and the staging depth
+      int tps = a.taps;
+      c.tps = tps;
+      while (tps > 1 && (lds_bytes_for(c, cf) > lds_budget || tps * EGN_CKQ * tn > cf.bi * 256)) {
+        --tps;
+        c.tps = tps;
+      }
+      if (lds_bytes_for(c, cf) > lds_budget || tps * EGN_CKQ * tn > cf.bi * 256) continue;
+      // balance the stages (e.g. 9 taps -> 5+4 instead of 8+1)
+      const int nst = cdiv(a.taps, tps);
+      c.tps = cdiv(a.taps, nst);
+      const double tiles = (double)c.tiles_x * c.tiles_y * tiles_b * cdiv(a.CoutP, tn);
+      const double mfma = (double)tm * tn * a.taps * EGN_CK;  // per chunk per tile
+      const double fill = (double)c.npix * EGN_CK * 24.0 + (double)a.taps * EGN_CK * tn * 12.0;
+      // ties (1x1 convs have no halo): prefer contiguous pixels over many images
+      const double cost = tiles * (mfma + fill + 4000.0 * nst + 64.0 * tnb + 8.0 * th);
+      if (best < 0 || cost < best) { best = cost; bestA = c; }
+    }
+  }
+  if (best < 0) return false;
+  a = bestA;
+  if (cost_out) *cost_out = best;
+  return true;
+}
+
+static size_t budget_for(const ConvConfig& cf) {
+  // staged: 3 blocks / CU; dma: 2 blocks / CU of the 160 KiB LDS
+  return cf.dma ? 80 * 1024 : 64 * 1024;
+}
+
+int egn_conv_plan(ConvArgs& a, int& cfg_id, size_t& lds_bytes) {
+  if (a.N <= 0 || a.H <= 0 || a.W <= 0 || a.Cin <= 0 || a.Cout <= 0) return EGN_E_BADARG;
+  if (a.cs_in % 4 || a.cs_in < a.Cin) return EGN_E_BADARG;
+  if (!a.out_nchw && (a.cs_out % 4 || a.cs_out < a.Cout)) return EGN_E_BADARG;
+  if (a.KH < 1 || a.KW < 1 || a.stride < 1 || a.pad < 0) return EGN_E_BADARG;
+  a.Ho = (a.H + 2 * a.pad - a.KH) / a.stride + 1;
+  a.Wo = (a.W + 2 * a.pad - a.KW) / a.stride + 1;
+  if (a.Ho <= 0 || a.Wo <= 0) return EGN_E_BADARG;
+  // 32-bit byte offsets into x (buffer loads) and 32-bit pixel indices
+  if ((double)a.N * a.H * a.W * a.cs_in * 4.0 >= 2147483648.0) return EGN_E_BADARG;
+  if ((double)a.N * a.Ho * a.Wo >= 2147483648.0) return EGN_E_BADARG;
+  a.CoutP = (a.Cout + 15) & ~15;
+  a.nchunk = cdiv(a.Cin, EGN_CK);
+  a.taps = a.KH * a.KW;
+  if (cfg_id >= 1 && cfg_id <= kNumConfigs) {
+    const ConvConfig& cf = kConfigs[cfg_id - 1];
+    if (!plan_tile(a, cf, budget_for(cf), nullptr)) return EGN_E_LDS;
+  } else {
+    // cost model over the staged family (the tuner explores both families)
+    double best = -1.0;
+    int best_id = 0;
+    ConvArgs bestA = a;
+    for (int k = 0; k < kNumConfigs; ++k) {
+      const ConvConfig& cf = kConfigs[k];
+      if (cf.dma) continue;
+      ConvArgs c = a;
+      double cost;
+      if (!plan_tile(c, cf, budget_for(cf), &cost)) continue;
+      // mild preference for filling the chip: penalise grids below 256 blocks
+      const double blocks = (double)c.tiles_x * c.tiles_y * cdiv(a.N, c.TNB) * cdiv(a.CoutP, cf.tile_n());
+      if (blocks < 256.0) cost *= 256.0 / blocks > 4.0 ? 4.0 : 256.0 / blocks;
+      if (best < 0 || cost < best) { best = cost; best_id = cf.id; bestA = c; }
+    }
+    if (best < 0) return EGN_E_LDS;
+    a = bestA;
+    cfg_id = best_id;
+  }
+  lds_bytes = lds_bytes_for(a, kConfigs[cfg_id - 1]);
+  return 0;
+}
+
+int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {
+  if (cfg_id < 1 || cfg_id > kNumConfigs) return EGN_E_BADARG;
+  const ConvConfig& cf = kConfigs[cfg_id - 1];
+  const size_t lds = lds_bytes_for(a, cf);
+  return cf.dma ? egn_conv_launch_dma(a, cfg_id - 10, lds, stream) : egn_conv_launch_staged(a, cfg_id, lds, stream);
+}

@@ -36,6 +36,7 @@ struct ConvConfig {
   int id;
   int wm, wn, mt, nt;  // waves in M/N, 16x16 sub-tiles per wave in M/N
   int ai, bi;          // dwordx4 staging loads per lane: halo tile / weights of a stage
+  int dma;             // 1 = LDS-DMA double-buffered pipeline (conv_dma.hip)
   int tile_m() const { return wm * mt * 16; }
   int tile_n() const { return wn * nt * 16; }
   int threads() const { return 64 * wm * wn; }

@@ -256,6 +256,11 @@ class Program(object):
             x, y = op['x'], op['y']
             res = op['res'].ref() if op['res'] is not None else NULL_REF
             cs_out = y.cs if not op['out_nchw'] else op['cout']
+            if 'cfg' not in op:
+                from . import tuner
+                op['cfg'] = tuner.choose(self.device, (
+                    x.n, x.h, x.w, op['cin'], x.cs, op['cout'], cs_out, op['kh'], op['kw'], op['stride'],
+                    op['pad'], op['res'] is not None, bool(op['out_nchw'])))
             _lib.check(L.egn_program_add_conv2d(
                 h, x.ref(), op['w'], op['scale'], op['shift'], res, y.ref(),
                 x.n, x.h, x.w, op['cin'], x.cs, op['cout'], cs_out, op['kh'], op['kw'],
@@ -298,7 +303,8 @@ class Program(object):
         else:
             raise ValueError(kind)
         L.egn_program_tag(h, (op.get('tag') or klass).encode(), flops, nbytes)
-        self.meta.append(dict(kind=kind, klass=klass, tag=op.get('tag', ''), flops=flops, bytes=nbytes))
+        self.meta.append(dict(kind=kind, klass=klass, tag=op.get('tag', ''), flops=flops, bytes=nbytes,
+                              cfg=op.get('cfg', 0) if kind == 'conv' else 0))
 
     def bind(self, slot, tensor):
         _lib.check(self.lib.egn_program_bind(self.handle, slot, _lib.ptr(tensor)))

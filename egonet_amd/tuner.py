@@ -1,0 +1,137 @@
+"""Measured choice of the conv tile configuration ("measure, don't guess").
+
+For every distinct convolution shape of a program the engine asks ``choose``:
+  1. a shipped table (``tuned/gfx950.json``, measured on MI355X, committed) and
+     the in-process cache are consulted;
+  2. on a miss -- unless ``EGONET_AMD_AUTOTUNE=0`` -- every compiled tile
+     configuration that the host planner accepts is timed on the real shape
+     (scratch tensors, hipEvents on the current stream, min of 5 after 2
+     warm-ups) and the fastest is kept;
+  3. with autotuning off the library's cost-model planner decides (cfg 0).
+``EGONET_AMD_TUNE_DUMP=<path>`` writes everything tuned in this process as
+JSON at exit (that is how the shipped table is produced).
+"""
+import atexit
+import ctypes as C
+import json
+import os
+
+import torch
+
+from . import _lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+TABLE_PATH = os.path.join(_HERE, 'tuned', 'gfx950.json')
+_table = None
+_tuned_here = {}
+
+
+def _load():
+    global _table
+    if _table is None:
+        _table = {}
+        if os.path.isfile(TABLE_PATH) and os.environ.get('EGONET_AMD_RETUNE', '0') != '1':
+            try:
+                with open(TABLE_PATH) as f:
+                    _table = {k: v for k, v in json.load(f).items() if not k.startswith('_')}
+            except (OSError, ValueError):
+                _table = {}
+    return _table
+
+
+def shape_key(n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, has_res, out_nchw):
+    return 'n%d_h%d_w%d_ci%d.%d_co%d.%d_k%dx%d_s%d_p%d_r%d_o%d' % (
+        n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, int(has_res), int(out_nchw))
+
+
+def autotune_enabled():
+    return os.environ.get('EGONET_AMD_AUTOTUNE', '1') != '0'
+
+
+def _time_cfg(L, args, cfg, stream, x, w, sc, sh, res, y):
+    n, h, wd, cin, cs_in, cout, cs_out, kh, kw, stride, pad, has_res, out_nchw = args
+
+    def launch():
+        return L.egn_conv2d_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(sc), _lib.ptr(sh),
+                                _lib.ptr(res) if has_res else None, _lib.ptr(y), n, h, wd, cin, cs_in,
+                                cout, cs_out, kh, kw, stride, pad, 1, int(out_nchw), cfg, stream)
+    if launch() != 0:
+        return None
+    launch()
+    best = None
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        best = t if best is None or t < best else best
+    return best
+
+
+def tune(device, args):
+    """Time every tile configuration on the real shape; returns (cfg, {cfg: ms})."""
+    L = _lib.lib()
+    n, h, wd, cin, cs_in, cout, cs_out, kh, kw, stride, pad, has_res, out_nchw = args
+    ho = (h + 2 * pad - kh) // stride + 1
+    wo = (wd + 2 * pad - kw) // stride + 1
+    coutp = (cout + 15) // 16 * 16
+    nchunk = (cin + 15) // 16
+    g = torch.Generator(device='cpu').manual_seed(1)
+    with torch.cuda.device(device):
+        x = torch.randn(n * h * wd * cs_in, device=device)
+        w = torch.randn(nchunk * kh * kw * 4 * coutp * 4, device=device) * 0.05
+        sc = torch.ones(coutp, device=device)
+        sh = torch.zeros(coutp, device=device)
+        ny = n * ho * wo * (cout if out_nchw else cs_out)
+        y = torch.empty(ny, device=device)
+        res = torch.randn(ny, device=device) if has_res else None
+        stream = _lib.current_stream(device)
+        times = {}
+        for cfg in range(1, L.egn_conv_num_configs() + 1):
+            out = (C.c_int * 12)()
+            if L.egn_conv_plan_query(n, h, wd, cin, cs_in, cout, cs_out, kh, kw, stride, pad,
+                                     int(out_nchw), cfg, out) != 0:
+                continue
+            t = _time_cfg(L, args, cfg, stream, x, w, sc, sh, res, y)
+            if t is not None:
+                times[cfg] = t
+        torch.cuda.synchronize(device)
+    del g
+    if not times:
+        return 0, {}
+    return min(times, key=times.get), times
+
+
+def choose(device, args):
+    key = shape_key(*args)
+    tab = _load()
+    if key in tab:
+        return int(tab[key]['cfg'])
+    if key in _tuned_here:
+        return _tuned_here[key]['cfg']
+    if not autotune_enabled():
+        return 0
+    cfg, times = tune(device, args)
+    _tuned_here[key] = {'cfg': cfg, 'ms': {str(k): round(v, 5) for k, v in times.items()}}
+    return cfg
+
+
+def tuned_in_process():
+    return dict(_tuned_here)
+
+
+def _dump():
+    path = os.environ.get('EGONET_AMD_TUNE_DUMP')
+    if path and _tuned_here:
+        merged = dict(_load())
+        merged.update(_tuned_here)
+        try:
+            with open(path, 'w') as f:
+                json.dump(merged, f, indent=0, sort_keys=True)
+        except OSError:
+            pass
+
+
+atexit.register(_dump)

@@ -28,6 +28,7 @@ def mfma_16x16x4(a_lane, b_lane, c_tile):
 def emulate(x, wpack, scale, shift, res, plan, N, H, W, Cin, cs_in, Cout, cs_out, KH, KW, stride, pad,
             act, out_nchw):
     cfg, WM, WN, MT, NT, TH, TW, TNB, tps, lds, gx, gy = plan
+    dma = cfg > 10          # LDS-DMA family: pixel-major halo tile sA[p][q], no swizzle, pre-zeroed
     TN = WN * NT * 16
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
@@ -72,7 +73,7 @@ def emulate(x, wpack, scale, shift, res, plan, N, H, W, Cin, cs_in, Cout, cs_out
             for c in range(nchunk):
                 for t0 in range(0, taps, tps):
                     if t0 == 0:
-                        sA[:] = np.nan
+                        sA[:] = 0.0 if dma else np.nan
                         for tid in tids:
                             q, p0 = tid & 3, tid >> 2
                             cpad = (c * CK + q * 4) >= cs_in
@@ -84,7 +85,11 @@ def emulate(x, wpack, scale, shift, res, plan, N, H, W, Cin, cs_in, Cout, cs_out
                                 v = np.zeros(4, np.float32)
                                 if off is not None and not cpad:
                                     v = xf[off + c * CK: off + c * CK + 4]
-                                sA[q, p ^ (q << 1)] = v
+                                if dma:
+                                    if off is not None and not cpad:
+                                        sA[q, p] = v          # slot p*4+q; padding lanes never DMA (pre-zeroed)
+                                else:
+                                    sA[q, p ^ (q << 1)] = v
                     nts = min(tps, taps - t0)
                     sB = np.full((nts * CKQ * TN, 4), np.nan, dtype=np.float32)
                     wbase = (c * taps + t0) * CKQ * CoutP
@@ -105,7 +110,7 @@ def emulate(x, wpack, scale, shift, res, plan, N, H, W, Cin, cs_in, Cout, cs_out
                                 yy, xx = rem // TW, rem % TW
                                 b = np.where(b >= TNB, 0, b)
                                 pixbase = (b * HH + yy * stride) * HW + xx * stride
-                                af.append(sA[kq, (pixbase + dpix) ^ (kq << 1)])      # [64,4]
+                                af.append(sA[kq, pixbase + dpix] if dma else sA[kq, (pixbase + dpix) ^ (kq << 1)])
                             for nt in range(NT):
                                 bf.append(sB[(tt * CKQ + kq) * TN + (wn * NT + nt) * 16 + li])
                             for mt in range(MT):

@@ -29,6 +29,8 @@ CASES = [
     (5, 1, 1, 10, 40, 1, 1, 0, 0x11, True, False, 0),  # Linear with residual-after-act
     (1, 12, 12, 8, 48, 3, 1, 1, 1, False, False, 6),   # forced config (128x48)
     (1, 8, 8, 4, 64, 3, 2, 1, 1, False, False, 8),     # stem-like, forced 64x64
+    (2, 8, 8, 20, 24, 3, 1, 1, 1, True, False, 16),    # LDS-DMA family (pixel-major halo tile)
+    (1, 9, 7, 16, 16, 3, 2, 1, 0, False, False, 18),   # LDS-DMA family, stride 2
 ]
 
 

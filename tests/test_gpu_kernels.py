@@ -88,13 +88,23 @@ def test_conv_hrnet_shapes(shape):
     assert err < 2e-4, err
 
 
-@pytest.mark.parametrize('cfg', list(range(1, 11)))
+@pytest.mark.parametrize('cfg', list(range(1, 21)))      # 1..10 staged family, 11..20 LDS-DMA family
 def test_conv_every_tile_config(cfg):
     # odd sizes: partial tiles in x, y, batch and channels
+    import ctypes as C
+    from egonet_amd import _lib
     err = _conv_case(3, 19, 13, 20, 40, 3, 1, 1, act=1, use_res=True, cfg=cfg, seed=cfg)
     assert err < 2e-4, (cfg, err)
-    err = _conv_case(2, 11, 9, 37, 70, 3, 2, 1, act=0, cfg=cfg, seed=50 + cfg)
-    assert err < 2e-4, (cfg, err)
+    # stride 2: the halo of a 128/256-row tile exceeds the per-lane staging depth
+    # (8 dwordx4); the planner must then refuse the forced config cleanly (-2)
+    out = (C.c_int * 12)()
+    rc = _lib.lib().egn_conv_plan_query(2, 11, 9, 37, 40, 70, 72, 3, 3, 2, 1, 0, cfg, out)
+    assert rc in (0, -2)
+    if rc == 0:
+        err = _conv_case(2, 11, 9, 37, 70, 3, 2, 1, act=0, cfg=cfg, seed=50 + cfg)
+        assert err < 2e-4, (cfg, err)
+    else:
+        assert (cfg - 1) % 10 < 6      # only the >= 128-row tiles overflow
 
 
 def test_conv_heads_and_linear():
