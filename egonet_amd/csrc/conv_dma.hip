@@ -16,6 +16,8 @@
 //     padding (the same lanes for every chunk) never issue a DMA;
 //   * with the staging registers gone the A/B fragments are double-buffered in
 //     registers: the ds_reads of tap t+1 are in flight under the MFMAs of tap t.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -28,7 +30,10 @@ __device__ __forceinline__ void egn_dma16(__amdgpu_buffer_rsrc_t r, float4* dst,
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, voff, soff, 0, 0);
 }
 
-template <int WM, int WN, int MT, int NT, int A_IT, int B_IT>
+// ABL != 0 are timing ablations (wrong results by construction, never planned):
+//   1 no DMA / no barrier in the K loop, 2 = 1 + fragments read once per stage,
+//   3 full K loop but no epilogue
+template <int WM, int WN, int MT, int NT, int A_IT, int B_IT, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
   static_assert(WM * WN == 4, "256-thread workgroups");
   constexpr int NTHREADS = 256;
@@ -113,8 +118,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
   const int nspc = (a.taps + a.tps - 1) / a.tps;  // stages per chunk
   const int nstages = a.nchunk * nspc;
 
-  // clear both halo buffers once: padding slots are never written afterwards
+  // clear both halo buffers once: padding slots are never written afterwards;
+  // tile row -> output pixel table for the epilogue
   for (int i = tid; i < 2 * a_slots; i += NTHREADS) sA[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!a.out_nchw) conv_epi_pixels<WM, MT>(a, smem, tid, n_base, oy0, ox0);
   __syncthreads();
 
 // LDS-DMA of stage S: halo tile of a new chunk into sA[chunk & 1], weight slab
@@ -162,32 +169,73 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF[mt].w, BF[nt].w, acc[mt][nt], 0, 0, 0);    \
   }
 
-  EGN_DMA(0)
-  for (int s = 0; s < nstages; ++s) {
-    // stage s has landed (vmcnt(0) is part of the barrier while a DMA is in
-    // flight) and every wave is done with the buffers stage s+1 overwrites
-    __syncthreads();
-    if (s + 1 < nstages) EGN_DMA(s + 1)
-
-    const int c = s / nspc;
-    const int g = s - c * nspc;
-    const int t0 = g * a.tps;
-    const int nts = min(a.tps, a.taps - t0);
-    const float4* curA = sA + (c & 1) * a_slots;
-    const float4* curB = sB + (s & 1) * b_slots;
-    float4 afA[MT], bfA[NT], afB[MT], bfB[NT];
-    EGN_LOADF(afA, bfA, 0)
-    for (int tt = 0; tt < nts; tt += 2) {
-      if (tt + 1 < nts) EGN_LOADF(afB, bfB, tt + 1)
-      EGN_MFMA(afA, bfA)
-      if (tt + 1 < nts) {
-        if (tt + 2 < nts) EGN_LOADF(afA, bfA, tt + 2)
-        EGN_MFMA(afB, bfB)
-      }
-    }
+// MFMA loop of stage S on sA[chunk & 1] / sB[S & 1]; the ds_reads of tap t+1 are
+// issued before the MFMAs of tap t (register double buffer afA/afB)
+#define EGN_COMPUTE(S)                                                  \
+  {                                                                     \
+    const int c = (S) / nspc;                                           \
+    const int g = (S) - c * nspc;                                       \
+    const int t0 = g * a.tps;                                           \
+    const int nts = min(a.tps, a.taps - t0);                            \
+    const float4* curA = sA + (c & 1) * a_slots;                        \
+    const float4* curB = sB + ((S)&1) * b_slots;                        \
+    float4 afA[MT], bfA[NT], afB[MT], bfB[NT];                          \
+    EGN_LOADF(afA, bfA, 0)                                              \
+    for (int tt = 0; tt < nts; tt += 2) {                               \
+      if constexpr (ABL == 2) {                                         \
+        EGN_MFMA(afA, bfA)                                              \
+        if (tt + 1 < nts) EGN_MFMA(afA, bfA)                            \
+        continue;                                                       \
+      }                                                                 \
+      if (tt + 1 < nts) EGN_LOADF(afB, bfB, tt + 1)                     \
+      EGN_MFMA(afA, bfA)                                                \
+      if (tt + 1 < nts) {                                               \
+        if (tt + 2 < nts) EGN_LOADF(afA, bfA, tt + 2)                   \
+        EGN_MFMA(afB, bfB)                                              \
+      }                                                                 \
+    }                                                                   \
   }
 
-  conv_epilogue<WM, WN, MT, NT>(a, acc, smem, tid, n_base, oy0, ox0, n0);
+  constexpr bool kStage = (ABL != 1 && ABL != 2);
+  if constexpr (kStage) EGN_DMA(0)
+  for (int s = 0; s + 1 < nstages; ++s) {
+    // stage s has landed (vmcnt(0) is part of the barrier while a DMA is in
+    // flight) and every wave is done with the buffers stage s+1 overwrites
+    if constexpr (kStage) {
+      __syncthreads();
+      EGN_DMA(s + 1)
+    }
+    EGN_COMPUTE(s)
+  }
+  // last stage (peeled): the residual loads of the epilogue go out first and
+  // are in flight under its MFMAs
+  if constexpr (kStage) __syncthreads();
+  ConvEpiRegs<MT, NT> er;
+  const bool nhwc = !a.out_nchw && ABL != 3;
+  if (nhwc) conv_epi_prefetch<WM, WN, MT, NT>(a, smem, tid, n0, er);
+  EGN_COMPUTE(nstages - 1)
+
+  if constexpr (ABL == 3) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) asm volatile("" ::"v"(acc[mt][nt]));
+    return;
+  }
+  if (nhwc)
+    conv_epi_finish<WM, WN, MT, NT>(a, acc, smem, tid, n0, er);
+  else
+    conv_epi_nchw<WM, WN, MT, NT>(a, acc, tid, n_base, oy0, ox0, n0);
+}
+
+template <int WM, int WN, int MT, int NT, int ABL>
+static int launch_abl(const ConvArgs& a, size_t lds, hipStream_t stream) {
+  EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN, MT, NT, 8, 8, ABL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+  const int tiles_b = (a.N + a.TNB - 1) / a.TNB;
+  dim3 grid(a.tiles_x * a.tiles_y * tiles_b, (a.CoutP + WN * NT * 16 - 1) / (WN * NT * 16));
+  hipLaunchKernelGGL((conv_dma_kernel<WM, WN, MT, NT, 8, 8, ABL>), grid, dim3(256), lds, stream, a);
+  return (int)hipGetLastError();
 }
 
 template <int WM, int WN, int MT, int NT>
@@ -206,6 +254,19 @@ static int launch_one(const ConvArgs& a, size_t lds, hipStream_t stream) {
 
 // dma family: local ids 1..10 = config ids 11..20 (table in conv_plan.hip)
 int egn_conv_launch_dma(const ConvArgs& a, int local_id, size_t lds, hipStream_t stream) {
+  // timing ablations of the 128x48 / 128x96 tiles (tools/conv_probe.py); never set in production
+  static const int abl = getenv("EGN_CONV_ABLATE") ? atoi(getenv("EGN_CONV_ABLATE")) : 0;
+  if (abl && (local_id == 2 || local_id == 6)) {
+    if (local_id == 2) {
+      if (abl == 1) return launch_abl<2, 2, 4, 3, 1>(a, lds, stream);
+      if (abl == 2) return launch_abl<2, 2, 4, 3, 2>(a, lds, stream);
+      if (abl == 3) return launch_abl<2, 2, 4, 3, 3>(a, lds, stream);
+    } else {
+      if (abl == 1) return launch_abl<4, 1, 2, 3, 1>(a, lds, stream);
+      if (abl == 2) return launch_abl<4, 1, 2, 3, 2>(a, lds, stream);
+      if (abl == 3) return launch_abl<4, 1, 2, 3, 3>(a, lds, stream);
+    }
+  }
   switch (local_id) {
     case 1: return launch_one<4, 1, 4, 3>(a, lds, stream);
     case 2: return launch_one<2, 2, 4, 3>(a, lds, stream);

@@ -102,6 +102,9 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
        ? (unsigned)((((tid + (IT)*NTHREADS) / TN) * a.CoutP) + n0 + ((tid + (IT)*NTHREADS) % TN)) * 16u \
        : OOB)
 
+  // tile row -> output pixel table for the epilogue (ordered by the K loop's first barrier)
+  if (!a.out_nchw) conv_epi_pixels<WM, MT>(a, smem, tid, n_base, oy0, ox0);
+
   // A-fragment base pixel (tap 0,0) of this lane for each 16-row sub-tile
   int pixbase[MT];
 #pragma unroll
@@ -192,7 +195,14 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(ConvArgs a) {
     }
   }
 
-  conv_epilogue<WM, WN, MT, NT>(a, acc, smem, tid, n_base, oy0, ox0, n0);
+  if (a.out_nchw) {
+    conv_epi_nchw<WM, WN, MT, NT>(a, acc, tid, n_base, oy0, ox0, n0);
+  } else {
+    // the staging registers are dead here: all residual loads go out together
+    ConvEpiRegs<MT, NT> er;
+    conv_epi_prefetch<WM, WN, MT, NT>(a, smem, tid, n0, er);
+    conv_epi_finish<WM, WN, MT, NT>(a, acc, smem, tid, n0, er);
+  }
 }
 
 template <int WM, int WN, int MT, int NT, int AI, int BI>

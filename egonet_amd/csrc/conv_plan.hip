@@ -35,6 +35,16 @@ static const ConvConfig kConfigs[] = {
     {18, 2, 2, 2, 2, 8, 8, 1},
     {19, 1, 4, 4, 1, 8, 8, 1},
     {20, 1, 4, 2, 3, 8, 8, 1},
+    {21, 4, 1, 4, 3, 8, 8, 2},  // LDS-DMA pipeline with a 53 KB LDS budget (3 blocks / CU:
+    {22, 2, 2, 4, 3, 8, 8, 2},  // fewer taps per stage, more barriers, more waves to hide
+    {23, 2, 2, 4, 2, 8, 8, 2},  // per-block prologue / epilogue)
+    {24, 4, 1, 4, 1, 8, 8, 2},
+    {25, 4, 1, 4, 2, 8, 8, 2},
+    {26, 4, 1, 2, 3, 8, 8, 2},
+    {27, 2, 2, 2, 3, 8, 8, 2},
+    {28, 2, 2, 2, 2, 8, 8, 2},
+    {29, 1, 4, 4, 1, 8, 8, 2},
+    {30, 1, 4, 2, 3, 8, 8, 2},
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -51,12 +61,16 @@ extern "C" int egn_conv_config_info(int cfg, int* tile_m, int* tile_n) {
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
+// LDS layout: [ K-loop stage buffers | epilogue sC (aliases them) ][ sPix: TM ints ]
+static size_t lds_stage_bytes(const ConvArgs& a, const ConvConfig& cf) {
   size_t main_loop = (size_t)(EGN_CKQ * a.npixp + a.tps * EGN_CKQ * cf.tile_n()) * 16;
   if (cf.dma) main_loop *= 2;  // double-buffered stage
-  // epilogue: 4 waves x (MT*16 rows) x (NT*16 + 4) floats + TM pixel indices
-  const size_t epi = a.out_nchw ? 0 : (size_t)4 * cf.mt * 16 * (cf.nt * 16 + 4) * 4 + (size_t)cf.tile_m() * 4;
-  return main_loop > epi ? main_loop : epi;
+  // epilogue: 4 waves x (MT*16 rows) x (NT*16 + 4) floats
+  const size_t epi = a.out_nchw ? 0 : (size_t)4 * cf.mt * 16 * (cf.nt * 16 + 4) * 4;
+  return ((main_loop > epi ? main_loop : epi) + 15) & ~(size_t)15;
+}
+static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
+  return lds_stage_bytes(a, cf) + (size_t)cf.tile_m() * 4;
 }
 
 // Choose the spatial tile for a config: minimise (MFMA work incl. padding +
@@ -111,8 +125,8 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
 }
 
 static size_t budget_for(const ConvConfig& cf) {
-  // staged: 3 blocks / CU; dma: 2 blocks / CU of the 160 KiB LDS
-  return cf.dma ? 80 * 1024 : 64 * 1024;
+  // staged: 3 blocks / CU; dma: 2 (ids 11..20) or 3 (ids 21..30) blocks / CU of the 160 KiB LDS
+  return cf.dma == 1 ? 80 * 1024 : (cf.dma == 2 ? 53 * 1024 : 64 * 1024);
 }
 
 int egn_conv_plan(ConvArgs& a, int& cfg_id, size_t& lds_bytes) {
@@ -152,7 +166,10 @@ int egn_conv_plan(ConvArgs& a, int& cfg_id, size_t& lds_bytes) {
     a = bestA;
     cfg_id = best_id;
   }
+  a.spix_off = (int)(lds_stage_bytes(a, kConfigs[cfg_id - 1]) / 16);
   lds_bytes = lds_bytes_for(a, kConfigs[cfg_id - 1]);
+  // 32-bit byte offsets into y / res (buffer stores in the NHWC epilogue)
+  if (!a.out_nchw && (double)a.N * a.Ho * a.Wo * a.cs_out * 4.0 >= 2147483648.0) return EGN_E_BADARG;
   return 0;
 }
 
@@ -160,5 +177,6 @@ int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {
   if (cfg_id < 1 || cfg_id > kNumConfigs) return EGN_E_BADARG;
   const ConvConfig& cf = kConfigs[cfg_id - 1];
   const size_t lds = lds_bytes_for(a, cf);
-  return cf.dma ? egn_conv_launch_dma(a, cfg_id - 10, lds, stream) : egn_conv_launch_staged(a, cfg_id, lds, stream);
+  return cf.dma ? egn_conv_launch_dma(a, (cfg_id - 1) % 10 + 1, lds, stream)
+                : egn_conv_launch_staged(a, cfg_id, lds, stream);
 }

@@ -30,6 +30,7 @@ struct ConvArgs {
   int tiles_x, tiles_y;
   int nchunk, taps, tps;  // K chunks, taps = KH*KW, taps per LDS stage
   int act, out_nchw;
+  int spix_off;  // LDS offset (float4 units) of the tile-row -> output-pixel table
 };
 
 struct ConvConfig {

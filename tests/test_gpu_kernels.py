@@ -88,7 +88,7 @@ def test_conv_hrnet_shapes(shape):
     assert err < 2e-4, err
 
 
-@pytest.mark.parametrize('cfg', list(range(1, 21)))      # 1..10 staged family, 11..20 LDS-DMA family
+@pytest.mark.parametrize('cfg', list(range(1, 31)))      # 1..10 staged family, 11..30 LDS-DMA family
 def test_conv_every_tile_config(cfg):
     # odd sizes: partial tiles in x, y, batch and channels
     import ctypes as C
