@@ -65,6 +65,8 @@ def kernel_table(prog, ms):
     """Aggregate per-op hipEvent durations by kernel class."""
     agg = {}
     for meta, t in zip(prog.meta, ms):
+        if meta['kind'] in ('fork', 'join'):
+            continue
         a = agg.setdefault(meta['klass'], dict(klass=meta['klass'], kind=meta['kind'], launches=0, ms=0.0,
                                                flops=0.0, bytes=0.0))
         a['launches'] += 1

@@ -53,6 +53,9 @@ SIGNATURES = {
     'egn_program_add_nhwc_to_nchw': (_i, [_p, Ref, Ref, _i, _i, _i, _i, _i]),
     'egn_program_add_ramps': (_i, [_p, Ref, _i, _i, _i, _i, _i]),
     'egn_program_add_decode': (_i, [_p, Ref, _i, _i, _i, _i, _i, Ref, Ref, Ref]),
+    'egn_program_fork': (_i, [_p]),
+    'egn_program_join': (_i, [_p]),
+    'egn_program_set_lane': (_i, [_p, _i]),
     'egn_program_tag': (_i, [_p, C.c_char_p, _d, _d]),
     'egn_program_run': (_i, [_p, _p]),
     'egn_program_run_timed': (_i, [_p, _p, C.POINTER(C.c_float), _i]),

@@ -70,10 +70,13 @@ extern "C" int egn_conv_plan_query(int N, int H, int W, int Cin, int cs_in, int 
 // ---------------------------------------------------------------------------
 // programs
 // ---------------------------------------------------------------------------
-enum OpKind { OP_CONV = 1, OP_FUSE = 2, OP_NCHW2NHWC = 3, OP_NHWC2NCHW = 4, OP_RAMPS = 5, OP_DECODE = 6 };
+enum OpKind { OP_CONV = 1, OP_FUSE = 2, OP_NCHW2NHWC = 3, OP_NHWC2NCHW = 4, OP_RAMPS = 5, OP_DECODE = 6,
+              OP_FORK = 7, OP_JOIN = 8 };
+constexpr int kMaxLanes = 4;  // concurrent launch lanes (HRNet has at most 4 branches)
 
 struct Op {
   int kind;
+  int lane = 0;  // launch lane (0 = the caller's stream, 1.. = side streams) inside a fork/join region
   // conv
   ConvArgs conv;
   int cfg;
@@ -89,6 +92,11 @@ struct egn_program {
   std::vector<Op> ops;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  int cur_lane = 0;
+  // side streams / events for fork-join regions (created on first use)
+  hipStream_t side[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr;
+  hipEvent_t ev_join[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 static inline void* resolve(const egn_program* p, const egn_ref& r) {
@@ -110,6 +118,11 @@ extern "C" void egn_program_destroy(egn_program* p) {
   if (!p) return;
   if (p->exec) hipGraphExecDestroy(p->exec);
   if (p->graph) hipGraphDestroy(p->graph);
+  for (int k = 1; k < kMaxLanes; ++k) {
+    if (p->side[k]) hipStreamDestroy(p->side[k]);
+    if (p->ev_join[k]) hipEventDestroy(p->ev_join[k]);
+  }
+  if (p->ev_fork) hipEventDestroy(p->ev_fork);
   delete p;
 }
 
@@ -145,6 +158,7 @@ extern "C" int egn_program_add_conv2d(egn_program* p, egn_ref x, egn_ref wpack, 
   for (int k = 0; k < 6; ++k)
     if (!ref_ok(p, op.r[k])) return EGN_E_BADARG;
   op.flops = 2.0 * N * op.conv.Ho * op.conv.Wo * (double)Cout * Cin * KH * KW;
+  op.lane = p->cur_lane;
   p->ops.push_back(op);
   return 0;
 }
@@ -162,6 +176,7 @@ extern "C" int egn_program_add_fuse(egn_program* p, egn_ref y, int N, int H, int
     if (!ref_ok(p, terms[k])) return EGN_E_BADARG;
   }
   op.i[0] = N; op.i[1] = H; op.i[2] = W; op.i[3] = C; op.i[4] = cs; op.i[5] = nterms; op.i[10] = relu;
+  op.lane = p->cur_lane;
   p->ops.push_back(op);
   return 0;
 }
@@ -174,6 +189,7 @@ static int add_simple(egn_program* p, int kind, egn_ref a, egn_ref b, int i0, in
   op.flops = op.bytes = 0;
   op.r[0] = a; op.r[1] = b;
   op.i[0] = i0; op.i[1] = i1; op.i[2] = i2; op.i[3] = i3; op.i[4] = i4; op.i[5] = i5;
+  op.lane = p->cur_lane;
   p->ops.push_back(op);
   return 0;
 }
@@ -201,7 +217,32 @@ extern "C" int egn_program_add_decode(egn_program* p, egn_ref hm, int N, int K, 
   op.flops = op.bytes = 0;
   op.r[0] = hm; op.r[1] = out_xy; op.r[2] = out_max; op.r[3] = out_idx;
   op.i[0] = N; op.i[1] = K; op.i[2] = H; op.i[3] = W; op.i[4] = mode;
+  op.lane = p->cur_lane;
   p->ops.push_back(op);
+  return 0;
+}
+
+extern "C" int egn_program_fork(egn_program* p) {
+  if (!p) return EGN_E_BADARG;
+  Op op;
+  op.kind = OP_FORK;
+  op.flops = op.bytes = 0;
+  p->cur_lane = 0;
+  p->ops.push_back(op);
+  return 0;
+}
+extern "C" int egn_program_join(egn_program* p) {
+  if (!p) return EGN_E_BADARG;
+  Op op;
+  op.kind = OP_JOIN;
+  op.flops = op.bytes = 0;
+  p->cur_lane = 0;
+  p->ops.push_back(op);
+  return 0;
+}
+extern "C" int egn_program_set_lane(egn_program* p, int lane) {
+  if (!p || lane < 0 || lane >= kMaxLanes) return EGN_E_BADARG;
+  p->cur_lane = lane;
   return 0;
 }
 
@@ -267,10 +308,51 @@ static int launch_op(egn_program* p, Op& op, hipStream_t s) {
   return EGN_E_BADARG;
 }
 
+static int ensure_lanes(egn_program* p) {
+  if (p->ev_fork) return 0;
+  EGN_CHECK_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+  for (int k = 1; k < kMaxLanes; ++k) {
+    EGN_CHECK_HIP(hipStreamCreateWithFlags(&p->side[k], hipStreamNonBlocking));
+    EGN_CHECK_HIP(hipEventCreateWithFlags(&p->ev_join[k], hipEventDisableTiming));
+  }
+  return 0;
+}
+
+// Launch every op.  Ops between FORK and JOIN go to their lane's stream: lane 0
+// is the caller's stream, lanes 1.. are side streams that wait for the fork
+// point and are waited for at the join (the HRNet branches / fuse outputs are
+// independent, so their kernels fill each other's prologue, epilogue and tail
+// gaps).  Works unchanged under stream capture (the events become graph edges).
 extern "C" int egn_program_run(egn_program* p, void* stream) {
   if (!p) return EGN_E_BADARG;
+  hipStream_t main = (hipStream_t)stream;
+  bool used[kMaxLanes] = {false, false, false, false};
   for (Op& op : p->ops) {
-    int rc = launch_op(p, op, (hipStream_t)stream);
+    if (op.kind == OP_FORK) {
+      int rc = ensure_lanes(p);
+      if (rc) return rc;
+      EGN_CHECK_HIP(hipEventRecord(p->ev_fork, main));
+      for (int k = 1; k < kMaxLanes; ++k) used[k] = false;
+      continue;
+    }
+    if (op.kind == OP_JOIN) {
+      for (int k = 1; k < kMaxLanes; ++k)
+        if (used[k]) {
+          EGN_CHECK_HIP(hipEventRecord(p->ev_join[k], p->side[k]));
+          EGN_CHECK_HIP(hipStreamWaitEvent(main, p->ev_join[k], 0));
+          used[k] = false;
+        }
+      continue;
+    }
+    hipStream_t s = main;
+    if (op.lane > 0 && p->ev_fork) {
+      if (!used[op.lane]) {
+        EGN_CHECK_HIP(hipStreamWaitEvent(p->side[op.lane], p->ev_fork, 0));
+        used[op.lane] = true;
+      }
+      s = p->side[op.lane];
+    }
+    int rc = launch_op(p, op, s);
     if (rc) return rc;
   }
   return 0;
@@ -284,8 +366,8 @@ extern "C" int egn_program_run_timed(egn_program* p, void* stream, float* ms, in
   for (auto& e : ev) EGN_CHECK_HIP(hipEventCreate(&e));
   int rc = 0;
   EGN_CHECK_HIP(hipEventRecord(ev[0], s));
-  for (size_t i = 0; i < n && !rc; ++i) {
-    rc = launch_op(p, p->ops[i], s);
+  for (size_t i = 0; i < n && !rc; ++i) {  // serial on the caller's stream: clean per-kernel times
+    if (p->ops[i].kind != OP_FORK && p->ops[i].kind != OP_JOIN) rc = launch_op(p, p->ops[i], s);
     if (!rc) rc = (int)hipEventRecord(ev[i + 1], s);
   }
   if (!rc) rc = (int)hipStreamSynchronize(s);
@@ -304,6 +386,12 @@ extern "C" int egn_program_capture(egn_program* p, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (p->exec) { hipGraphExecDestroy(p->exec); p->exec = nullptr; }
   if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
+  for (const Op& op : p->ops)  // side streams / events must exist before the capture starts
+    if (op.kind == OP_FORK) {
+      int rc0 = ensure_lanes(p);
+      if (rc0) return rc0;
+      break;
+    }
   EGN_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   int rc = egn_program_run(p, stream);
   hipGraph_t g = nullptr;

@@ -81,7 +81,7 @@ def fold_scale_shift(cout, bias=None, bn=None):
 class Buf(object):
     """Symbolic fp32 tensor.  NHWC [n,h,w,cs] (cs = channel stride) in the arena,
     or an external user tensor bound to ``slot``."""
-    __slots__ = ('n', 'h', 'w', 'c', 'cs', 'slot', 'off', 'nbytes', 'first', 'last', 'name')
+    __slots__ = ('n', 'h', 'w', 'c', 'cs', 'slot', 'off', 'nbytes', 'first', 'last', 'uses', 'name')
 
     def __init__(self, n, h, w, c, cs=None, slot=SLOT_ARENA, nbytes=None, name=''):
         self.n, self.h, self.w, self.c = n, h, w, c
@@ -90,6 +90,7 @@ class Buf(object):
         self.off = 0
         self.nbytes = nbytes if nbytes is not None else n * h * w * self.cs * 4
         self.first = self.last = -1
+        self.uses = []          # indices of every op that reads or writes the buffer
         self.name = name
 
     def ref(self):
@@ -102,6 +103,33 @@ class _Recorder(object):
         self.blobs = []        # list of 1-D fp32 tensors -> weights blob
         self.blob_off = 0
         self.bufs = []
+        self.region = 0        # fork/join regions are totally ordered
+        self.cur_lane = 0      # launch lane inside the current region
+
+    def _push(self, kind, op):
+        op['region'], op['lane'] = self.region, self.cur_lane
+        self.ops.append((kind, op))
+
+    def fork(self):
+        """Ops recorded until ``join`` may run concurrently when they are on
+        different lanes (``lane(k)``); they must be independent."""
+        self.region += 1
+        self.cur_lane = 0
+        self._push('fork', {})
+
+    def lane(self, k):
+        self.cur_lane = k % 4
+
+    def join(self):
+        self.cur_lane = 0
+        self._push('join', {})
+        self.region += 1
+
+    def happens_before(self, u, d):
+        """Op u is complete before op d starts: earlier region, or same region
+        and same lane (stream order)."""
+        (ru, lu), (rd, ld) = [(self.ops[i][1]['region'], self.ops[i][1]['lane']) for i in (u, d)]
+        return ru < rd or (ru == rd and lu == ld and u < d)
 
     # -- storage --
     def new(self, n, h, w, c, name=''):
@@ -123,6 +151,7 @@ class _Recorder(object):
             if b.first < 0:
                 b.first = i
             b.last = i
+            b.uses.append(i)
 
     # -- ops --
     def conv(self, x, weight, bias=None, bn=None, act=ACT_NONE, res=None, stride=1, pad=0,
@@ -141,7 +170,7 @@ class _Recorder(object):
                   shift=self.weight(shift), res=res, y=dst, cin=cin, cout=cout, kh=kh, kw=kw,
                   stride=stride, pad=pad, act=act, out_nchw=int(out_nchw), ho=ho, wo=wo, tag=tag)
         self._touch(x, res, dst)
-        self.ops.append(('conv', op))
+        self._push('conv', op)
         return dst
 
     def fuse(self, terms, relu, tag=''):
@@ -149,30 +178,32 @@ class _Recorder(object):
         base = [t for t, s in terms if s == 0][0]
         y = self.new(base.n, base.h, base.w, base.c, name=tag)
         self._touch(y, *[t for t, _ in terms])
-        self.ops.append(('fuse', dict(y=y, terms=terms, relu=int(relu), tag=tag)))
+        self._push('fuse', dict(y=y, terms=terms, relu=int(relu), tag=tag))
         return y
 
     def nchw_to_nhwc(self, x_ext, n, c, h, w, tag=''):
         y = self.new(n, h, w, c, name=tag)
         self._touch(y)
-        self.ops.append(('to_nhwc', dict(x=x_ext, y=y, tag=tag)))
+        self._push('to_nhwc', dict(x=x_ext, y=y, tag=tag))
         return y
 
     def nhwc_to_nchw(self, x, c, dst_ext, tag=''):
         self._touch(x)
-        self.ops.append(('to_nchw', dict(x=x, y=dst_ext, c=c, tag=tag)))
+        self._push('to_nchw', dict(x=x, y=dst_ext, c=c, tag=tag))
 
     def ramps(self, y, c0, tag=''):
         self._touch(y)
-        self.ops.append(('ramps', dict(y=y, c0=c0, tag=tag)))
+        self._push('ramps', dict(y=y, c0=c0, tag=tag))
 
     def decode(self, hm_ext, n, k, h, w, mode, xy, mx, idx, tag=''):
-        self.ops.append(('decode', dict(hm=hm_ext, n=n, k=k, h=h, w=w, mode=mode, xy=xy, mx=mx,
-                                        idx=idx, tag=tag)))
+        self._push('decode', dict(hm=hm_ext, n=n, k=k, h=h, w=w, mode=mode, xy=xy, mx=mx, idx=idx, tag=tag))
 
     # -- finalisation --
     def plan_arena(self):
-        """Greedy best-fit packing of arena buffers by lifetime; returns bytes."""
+        """Greedy best-fit packing of arena buffers by lifetime; returns bytes.
+        A buffer's storage is re-used only by a buffer whose defining op starts
+        after EVERY use of the old one has completed (``happens_before``), so
+        concurrent lanes never alias each other's live tensors."""
         live = [b for b in self.bufs if b.slot == SLOT_ARENA and b.first >= 0]
         events = sorted(live, key=lambda b: b.first)
         free = []              # (off, size)
@@ -182,7 +213,7 @@ class _Recorder(object):
             # release buffers whose last use is before this definition
             still = []
             for last, ab in active:
-                if last < b.first:
+                if all(self.happens_before(u, b.first) for u in ab.uses):
                     free.append((ab.off, _round_up(ab.nbytes, 256)))
                 else:
                     still.append((last, ab))
@@ -252,6 +283,11 @@ class Program(object):
     def _emit(self, kind, op):
         L, h = self.lib, self.handle
         flops, nbytes = 0.0, 0.0
+        if kind in ('fork', 'join'):
+            _lib.check(L.egn_program_fork(h) if kind == 'fork' else L.egn_program_join(h))
+            self.meta.append(dict(kind=kind, klass=kind, tag='', flops=0.0, bytes=0.0, cfg=0))
+            return
+        _lib.check(L.egn_program_set_lane(h, op.get('lane', 0)))
         if kind == 'conv':
             x, y = op['x'], op['y']
             res = op['res'].ref() if op['res'] is not None else NULL_REF
@@ -344,9 +380,11 @@ class HRNetEngine(object):
     """Runs ``PoseHighResolutionNet`` (eval mode) on one GPU as HIP kernels."""
 
     def __init__(self, model):
+        import os
         self.model = model
         self.programs = {}        # (device, N, H, W, decode) -> Program
         self._stamp = None
+        self.lanes = os.environ.get('EGONET_AMD_LANES', '1') != '0'   # branch-level concurrency
 
     # -- recording ---------------------------------------------------------
     def _block(self, r, x, blk, tag):
@@ -380,13 +418,27 @@ class HRNetEngine(object):
 
     def _module(self, r, xs, mod, tag):
         xs = list(xs)
+        # the resolution branches are independent (hrnet.py:286-287): one launch
+        # lane each, so their kernels overlap each other's prologue / epilogue /
+        # tail and the small coarse-branch grids do not leave the chip idle
+        lanes = self.lanes and mod.num_branches > 1
+        if lanes:
+            r.fork()
         for b, branch in enumerate(mod.branches):
+            if lanes:
+                r.lane(b)
             for k, blk in enumerate(branch):
                 xs[b] = self._block(r, xs[b], blk, '%s.branches.%d.%d' % (tag, b, k))
+        if lanes:
+            r.join()
         if mod.fuse_layers is None:
             return xs
         outs = []
+        if lanes:                       # the fuse outputs are independent too (hrnet.py:291-298)
+            r.fork()
         for i, row in enumerate(mod.fuse_layers):
+            if lanes:
+                r.lane(i)
             terms = []
             for j in range(mod.num_branches):
                 q = '%s.fuse_layers.%d.%d' % (tag, i, j)
@@ -399,6 +451,8 @@ class HRNetEngine(object):
                 else:
                     terms.append((self._unit_chain(r, xs[j], row[j], q), 0))
             outs.append(r.fuse(terms, True, tag='%s.fuse%d' % (tag, i)))
+        if lanes:
+            r.join()
         return outs
 
     def _record(self, n, cin, h, w, decode_mode):

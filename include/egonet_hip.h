@@ -175,6 +175,15 @@ int egn_program_add_ramps(egn_program* p, egn_ref y, int N, int H, int W,
 int egn_program_add_decode(egn_program* p, egn_ref hm, int N, int K, int H,
                            int W, int mode, egn_ref out_xy, egn_ref out_max,
                            egn_ref out_idx);
+/* Concurrency: ops added between egn_program_fork and egn_program_join run on
+ * the launch lane selected by egn_program_set_lane (0 = the caller's stream,
+ * 1..3 = internal side streams that start at the fork point and are waited for
+ * at the join).  Ops on different lanes of one region must be independent and
+ * must not share scratch buffers.  HRNet: one lane per resolution branch
+ * (hrnet.py:286-287) and per fuse output (hrnet.py:291-298). */
+int egn_program_fork(egn_program* p);
+int egn_program_join(egn_program* p);
+int egn_program_set_lane(egn_program* p, int lane);
 /* tag the most recently added op (shown by the profiler); copied */
 int egn_program_tag(egn_program* p, const char* tag, double flops, double bytes);
 

@@ -1,0 +1,75 @@
+"""Host logic of the engine without a GPU: the recorded launch program of an
+HRNet (op list, launch lanes, fork/join regions) and the activation-arena
+packing.  Two tensors may share arena bytes only if every use of one
+happens-before the definition of the other -- also across concurrent lanes."""
+import itertools
+
+import pytest
+import torch
+
+from egonet_amd import configs, engine
+from egonet_amd.model.heatmapModel import hrnet
+from egonet_amd.model import FCmodel
+
+
+def _record(cfg, n=2, lanes=True):
+    net = hrnet.get_pose_net(cfg, is_train=False).eval()
+    eng = engine.HRNetEngine(net)
+    eng.lanes = lanes
+    iw, ih = cfg['heatmapModel']['input_size']
+    rec, nslots, shapes = eng._record(n, 3, ih, iw, None)
+    return rec, nslots, shapes
+
+
+@pytest.mark.parametrize('head', ['coordinates', 'heatmap'])
+@pytest.mark.parametrize('lanes', [True, False])
+def test_arena_never_aliases_live_tensors(head, lanes):
+    rec, nslots, shapes = _record(configs.tiny_config(head), lanes=lanes)
+    total = rec.plan_arena()
+    bufs = [b for b in rec.bufs if b.slot == engine.SLOT_ARENA and b.first >= 0]
+    assert total > 0 and all(b.off + b.nbytes <= total for b in bufs)
+    for a, b in itertools.combinations(bufs, 2):
+        if a.off < b.off + b.nbytes and b.off < a.off + a.nbytes:      # byte ranges overlap
+            a_then_b = all(rec.happens_before(u, b.first) for u in a.uses)
+            b_then_a = all(rec.happens_before(u, a.first) for u in b.uses)
+            assert a_then_b or b_then_a, (a.name, b.name)
+    # packing really re-uses memory
+    assert total < 0.5 * sum(b.nbytes for b in bufs)
+
+
+def test_program_structure_w48():
+    """HRNet-W48, coordinates head: one fused launch per conv (+ layout/fuse/ramps
+    helpers) instead of ~1050 unfused ATen kernels."""
+    rec, nslots, shapes = _record(configs.w48_config('coordinates'), n=1)
+    kinds = [k for k, _ in rec.ops]
+    convs = [op for k, op in rec.ops if k == 'conv']
+    assert len(convs) == 306 - 1 + 1          # 306 Conv2d modules: every one is exactly one launch
+    assert kinds.count('fuse') == 2 + 4 * 3 + 2 * 4 + 1      # one per fuse output of the 8 HR modules
+    assert kinds.count('fork') == kinds.count('join') == 16  # branches + fuse outputs of 8 modules
+    assert shapes['maps'] == (1, 33, 64, 64) and shapes['coords'] == (1, 33, 2)
+    flops = sum(2.0 * op['ho'] * op['wo'] * op['cout'] * op['cin'] * op['kh'] * op['kw'] for op in convs)
+    assert abs(flops / 1e9 - 42.035) < 0.02   # GFLOP per crop
+    # every lane index stays inside the 4 launch lanes and lanes > 0 only occur inside regions
+    inside = False
+    for k, op in rec.ops:
+        if k == 'fork':
+            inside = True
+        elif k == 'join':
+            inside = False
+        else:
+            assert 0 <= op['lane'] < 4 and (inside or op['lane'] == 0)
+
+
+def test_lifter_program_and_weight_blob():
+    cfg = configs.w48_config()
+    net = FCmodel.get_fc_model(1, cfg, 66, 96).eval()
+    eng = engine.LifterEngine(net)
+    rec = eng._record(7)
+    convs = [op for k, op in rec.ops if k == 'conv']
+    assert [(c['cin'], c['cout']) for c in convs] == [(66, 1024)] + [(1024, 1024)] * 4 + [(1024, 96)]
+    assert convs[2]['act'] == (engine.ACT_RELU | engine.ACT_RES_AFTER) and convs[2]['res'] is not None
+    blob = rec.weights_blob('cpu')
+    # first packed weight: [nchunk=5][1][4][1024][4], chunk 0 / quad 0 / co 3 = w1.weight[3, 0:4]
+    w = blob[:5 * 4 * 1024 * 4].view(5, 1, 4, 1024, 4)
+    assert torch.equal(w[0, 0, 0, 3], net.w1.weight[3, 0:4].detach())
+    assert float(w[4, 0, 0, :, 2:].abs().sum()) == 0.0      # input channels 66, 67 are padding
