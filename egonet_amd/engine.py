@@ -206,47 +206,57 @@ class _Recorder(object):
         concurrent lanes never alias each other's live tensors."""
         live = [b for b in self.bufs if b.slot == SLOT_ARENA and b.first >= 0]
         events = sorted(live, key=lambda b: b.first)
-        free = []              # (off, size)
-        active = []            # (last, buf)
+        free = []              # [off, size, uses]: uses = op indices that touched the bytes
+        active = []
         top = 0
         for b in events:
-            # release buffers whose last use is before this definition
+            d = b.first
+            region_d = self.ops[d][1]['region']
+            # retire buffers with no later use: their bytes become candidates, tagged
+            # with the uses a new owner has to wait for
             still = []
-            for last, ab in active:
-                if all(self.happens_before(u, b.first) for u in ab.uses):
-                    free.append((ab.off, _round_up(ab.nbytes, 256)))
+            for ab in active:
+                if ab.last < d:
+                    free.append([ab.off, _round_up(ab.nbytes, 256), list(ab.uses)])
                 else:
-                    still.append((last, ab))
+                    still.append(ab)
             active = still
-            # coalesce
-            free.sort()
+            # uses in earlier regions are ordered before everything from here on
+            for blk in free:
+                blk[2] = [u for u in blk[2] if self.ops[u][1]['region'] >= region_d]
+            free.sort(key=lambda blk: blk[0])
             merged = []
-            for off, sz in free:
+            for off, sz, uses in free:
                 if merged and merged[-1][0] + merged[-1][1] == off:
-                    merged[-1] = (merged[-1][0], merged[-1][1] + sz)
+                    merged[-1][1] += sz
+                    merged[-1][2] = merged[-1][2] + uses
                 else:
-                    merged.append((off, sz))
+                    merged.append([off, sz, uses])
             free = merged
+
+            def usable(blk):
+                return all(self.happens_before(u, d) for u in blk[2])
+
             need = _round_up(b.nbytes, 256)
             best = None
-            for i, (off, sz) in enumerate(free):
-                if sz >= need and (best is None or sz < free[best][1]):
+            for i, blk in enumerate(free):
+                if blk[1] >= need and usable(blk) and (best is None or blk[1] < free[best][1]):
                     best = i
             if best is None:
-                # grow: extend a free block that ends at the top if there is one
-                if free and free[-1][0] + free[-1][1] == top:
-                    off, sz = free.pop()
+                # grow: extend a usable free block that ends at the top if there is one
+                if free and free[-1][0] + free[-1][1] == top and usable(free[-1]):
+                    off, sz, uses = free.pop()
                     b.off = off
                     top = off + need
                 else:
                     b.off = top
                     top += need
             else:
-                off, sz = free.pop(best)
+                off, sz, uses = free.pop(best)
                 b.off = off
                 if sz > need:
-                    free.append((off + need, sz - need))
-            active.append((b.last, b))
+                    free.append([off + need, sz - need, uses])
+            active.append(b)
         return top
 
     def weights_blob(self, device):

@@ -23,8 +23,12 @@ def _record(cfg, n=2, lanes=True):
 
 @pytest.mark.parametrize('head', ['coordinates', 'heatmap'])
 @pytest.mark.parametrize('lanes', [True, False])
-def test_arena_never_aliases_live_tensors(head, lanes):
-    rec, nslots, shapes = _record(configs.tiny_config(head), lanes=lanes)
+@pytest.mark.parametrize('model', ['tiny', 'w48'])
+def test_arena_never_aliases_live_tensors(model, head, lanes):
+    # (the W48 topology -- 4 blocks per branch, several modules per stage -- is
+    # what exposes bytes freed by one lane being handed to another lane)
+    cfg = configs.tiny_config(head) if model == 'tiny' else configs.w48_config(head)
+    rec, nslots, shapes = _record(cfg, lanes=lanes)
     total = rec.plan_arena()
     bufs = [b for b in rec.bufs if b.slot == engine.SLOT_ARENA and b.first >= 0]
     assert total > 0 and all(b.off + b.nbytes <= total for b in bufs)
