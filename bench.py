@@ -13,13 +13,17 @@ crops/s "heatmap+decode+lift").  Crops shard across ranks with no data-path
 collective (weak scaling, B per GPU fixed).
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
-  roofline      the dominant kernel class (by time) of the forward, measured
-                live with hipEvents per launch inside the native program
-  kernels       the same for every kernel class (time share, TFLOP/s, GB/s)
+  roofline      the dominant kernel (by time; keyed by the kernel SYMBOL that
+                rocprofv3 prints) of the backbone, measured live with hipEvents
+                around every launch of the native program on the stream the
+                kernels run on; `traffic` = measured HBM bytes per launch from
+                the committed PMC passes (profiles/), null if absent
+  kernels       the same per shape class (time share, TFLOP/s, GB/s)
   cpu_baseline  the CPU oracle (same graph the reference's PyTorch-CPU path
                 executes) timed on this host on a bounded sample
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -33,13 +37,14 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_HBM_GBPS = 8000.0
+TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic.json')
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=10)
-    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=5)
     p.add_argument('--batch', type=int, default=64, help='crops per GPU per step')
     p.add_argument('--head', default='heatmap', choices=['heatmap', 'coordinates'])
     p.add_argument('--no-cpu-baseline', action='store_true')
@@ -61,26 +66,50 @@ def build_model(head, device):
     return cfg, ego.eval().to(device), hc_sd, l_sd
 
 
-def kernel_table(prog, ms):
-    """Aggregate per-op hipEvent durations by kernel class."""
-    agg = {}
+def _symbol(cfg):
+    from egonet_amd import _lib
+    buf = C.create_string_buffer(128)
+    if cfg and _lib.lib().egn_conv_config_name(cfg, buf, 128) == 0:
+        return buf.value.decode()
+    return None
+
+
+def kernel_tables(prog, ms):
+    """Aggregate per-op hipEvent durations (a) by shape class, (b) by kernel symbol."""
+    by_class, by_symbol = {}, {}
     for meta, t in zip(prog.meta, ms):
         if meta['kind'] in ('fork', 'join'):
             continue
-        a = agg.setdefault(meta['klass'], dict(klass=meta['klass'], kind=meta['kind'], launches=0, ms=0.0,
-                                               flops=0.0, bytes=0.0))
-        a['launches'] += 1
-        a['ms'] += float(t)
-        a['flops'] += meta['flops']
-        a['bytes'] += meta['bytes']
-    rows = sorted(agg.values(), key=lambda a: -a['ms'])
-    total = sum(a['ms'] for a in rows)
-    for a in rows:
-        a['share'] = a['ms'] / total if total else 0.0
-        a['tflops'] = a['flops'] / (a['ms'] * 1e-3) / 1e12 if a['ms'] else 0.0
-        a['gbps'] = a['bytes'] / (a['ms'] * 1e-3) / 1e9 if a['ms'] else 0.0
-        a['avg_us'] = a['ms'] * 1e3 / a['launches']
-    return rows, total
+        sym = _symbol(meta.get('cfg', 0)) if meta['kind'] == 'conv' else meta['kind'] + '_kernel'
+        for table, key in ((by_class, meta['klass']), (by_symbol, sym)):
+            a = table.setdefault(key, dict(name=key, kind=meta['kind'], launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            a['launches'] += 1
+            a['ms'] += float(t)
+            a['flops'] += meta['flops']
+            a['bytes'] += meta['bytes']
+    out = []
+    for table in (by_class, by_symbol):
+        rows = sorted(table.values(), key=lambda a: -a['ms'])
+        total = sum(a['ms'] for a in rows)
+        for a in rows:
+            a['share'] = a['ms'] / total if total else 0.0
+            a['tflops'] = a['flops'] / (a['ms'] * 1e-3) / 1e12 if a['ms'] else 0.0
+            a['gbps'] = a['bytes'] / (a['ms'] * 1e-3) / 1e9 if a['ms'] else 0.0
+            a['avg_us'] = a['ms'] * 1e3 / a['launches']
+        out.append((rows, total))
+    return out
+
+
+def measured_traffic(symbol):
+    """HBM bytes per launch of `symbol` from the committed PMC passes (see
+    profiles/README.md: FETCH_SIZE and WRITE_SIZE collected in separate
+    rocprofv3 --pmc runs of this benchmark, FETCH_SIZE doubled for gfx950)."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            t = json.load(f)
+        return t['kernels'][symbol]['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(cfg, hc_sd, l_sd, stats, head, seconds):
@@ -186,10 +215,9 @@ def main():
         dt = float(t.item())
     assert torch.isfinite(out['kpts_3d']).all()
 
-    result = None
     if rank == 0:
-        # per-kernel timing of the backbone program (hipEvents around every launch,
-        # on the stream the kernels run on), outside the timed region
+        # per-kernel timing of the backbone program: hipEvents around every launch,
+        # serial on the stream the kernels run on, outside the timed region
         eng = ego.HC._hip_engine()
         mode = 1 if decode == 'soft' else None
         samples = []
@@ -199,20 +227,24 @@ def main():
                 samples.append(eng.last_ms)
         ms = np.mean(samples, axis=0)
         prog = eng.program(crops, mode)
-        rows, total_ms = kernel_table(prog, ms)
-        dom = rows[0]
-        if dom['flops'] > 0 and dom['flops'] / max(dom['bytes'], 1) > 20:
-            roof = {'bound': 'mfma', 'kernel': dom['klass'], 'achieved': dom['tflops'],
-                    'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_FP32_MFMA_TFLOPS,
-                    'traffic': None, 'launches': dom['launches'], 'avg_us': dom['avg_us'],
-                    'time_share': dom['share']}
+        (rows, total_ms), (syms, _) = kernel_tables(prog, ms)
+        dom = syms[0]
+        mfma_bound = dom['flops'] > 0 and dom['flops'] / max(dom['bytes'], 1) > 20
+        traffic = measured_traffic(dom['name'])
+        if mfma_bound:
+            roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': dom['tflops'],
+                    'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_FP32_MFMA_TFLOPS}
         else:
-            roof = {'bound': 'hbm', 'kernel': dom['klass'], 'achieved': dom['gbps'], 'peak': PEAK_HBM_GBPS,
-                    'unit': 'GB/s', 'frac': dom['gbps'] / PEAK_HBM_GBPS, 'traffic': None,
-                    'launches': dom['launches'], 'avg_us': dom['avg_us'], 'time_share': dom['share']}
+            roof = {'bound': 'hbm', 'kernel': dom['name'], 'achieved': dom['gbps'], 'peak': PEAK_HBM_GBPS,
+                    'unit': 'GB/s', 'frac': dom['gbps'] / PEAK_HBM_GBPS}
+        roof.update(traffic=traffic, launches=dom['launches'], avg_us=dom['avg_us'], time_share=dom['share'],
+                    algorithmic_gflop_per_launch=dom['flops'] / dom['launches'] / 1e9,
+                    algorithmic_mb_per_launch=dom['bytes'] / dom['launches'] / 1e6)
         conv_flops = sum(a['flops'] for a in rows)
-        kernels = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()
-                    if k in ('klass', 'launches', 'ms', 'share', 'tflops', 'gbps', 'avg_us')} for a in rows[:12]]
+
+        def slim(a):
+            return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()
+                    if k in ('name', 'launches', 'ms', 'share', 'tflops', 'gbps', 'avg_us')}
         value = world * B * args.steps / dt
         result = {
             'metric': 'crops/sec (256x256, heatmap+decode+lift)', 'value': value, 'unit': 'crops/s',
@@ -222,18 +254,21 @@ def main():
             'config': {'workload': 'configs[1]: batch=%d 256x256 crops/GPU, HRNet-W48 %s head forward + '
                                    '%s decode + affine + FC lifter + pose solve' % (B, args.head, decode),
                        'global_batch': world * B, 'weights': 'synthetic (egonet_amd.synth, seeded per key)',
-                       'parallelism': 'replicas x%d, crops sharded by rank, no collective' % world},
+                       'parallelism': 'replicas x%d, crops sharded by rank, no collective' % world,
+                       'launch_lanes': int(eng.lanes)},
             'roofline': roof,
             'backbone': {'ms_sum_of_kernels': total_ms, 'gflop_per_crop': conv_flops / B / 1e9,
                          'tflops_overall': conv_flops / (total_ms * 1e-3) / 1e12,
                          'frac_of_fp32_peak': conv_flops / (total_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                         'launches': len(ms), 'arena_mb': prog.arena_bytes / 2 ** 20,
+                         'launches': int(sum(a['launches'] for a in rows)), 'arena_mb': prog.arena_bytes / 2 ** 20,
                          'weights_mb': prog.weight_bytes / 2 ** 20},
-            'kernels': kernels,
+            'kernel_symbols': [slim(a) for a in syms[:8]],
+            'kernels': [slim(a) for a in rows[:12]],
         }
         if args.profile_json:
             with open(args.profile_json, 'w') as f:
-                json.dump({'ops': [dict(m, ms=float(t)) for m, t in zip(prog.meta, ms)], 'classes': rows}, f, indent=1)
+                json.dump({'ops': [dict(m, ms=float(t)) for m, t in zip(prog.meta, ms)], 'classes': rows,
+                           'symbols': syms}, f, indent=1)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(cfg, hc_sd, l_sd, ego.LS, args.head, args.cpu_seconds)
         print(json.dumps(result), flush=True)

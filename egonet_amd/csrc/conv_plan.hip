@@ -8,6 +8,8 @@
 //               LDS stage, 1 barrier per stage, register double-buffered
 //               fragments                                   (conv_dma.hip)
 // The engine's tuner times the candidates on the real shape; cfg 0 = cost model.
+#include <stdio.h>
+
 #include "egn_internal.h"
 
 int egn_conv_launch_staged(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
@@ -56,6 +58,19 @@ extern "C" int egn_conv_config_info(int cfg, int* tile_m, int* tile_n) {
   if (cfg < 1 || cfg > kNumConfigs) return EGN_E_BADARG;
   if (tile_m) *tile_m = kConfigs[cfg - 1].tile_m();
   if (tile_n) *tile_n = kConfigs[cfg - 1].tile_n();
+  return 0;
+}
+
+// kernel symbol of a config as rocprofv3 prints it (lets bench.py line its
+// hipEvent timings up with the kernel-trace statistics)
+extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
+  if (cfg < 1 || cfg > kNumConfigs || !buf || len < 8) return EGN_E_BADARG;
+  const ConvConfig& c = kConfigs[cfg - 1];
+  if (c.dma)
+    snprintf(buf, len, "void conv_dma_kernel<%d, %d, %d, %d, 8, 8, 0>(ConvArgs)", c.wm, c.wn, c.mt, c.nt);
+  else
+    snprintf(buf, len, "void conv_mfma_kernel<%d, %d, %d, %d, %d, %d>(ConvArgs)", c.wm, c.wn, c.mt, c.nt, c.ai,
+             c.bi);
   return 0;
 }
 

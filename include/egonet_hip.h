@@ -76,6 +76,8 @@ int egn_conv_plan_query(int N, int H, int W, int Cin, int cs_in, int Cout,
 int egn_conv_num_configs(void);
 /* describe config id: tile_m (output pixels), tile_n (output channels) */
 int egn_conv_config_info(int cfg, int* tile_m, int* tile_n);
+/* kernel symbol of config id as rocprofv3 prints it, NUL terminated into buf */
+int egn_conv_config_name(int cfg, char* buf, int len);
 
 /* ------------------------------------------------------------------------
  * Multi-resolution fuse: y = relu( ((t0 + up(t1)) + up(t2)) + up(t3) ),
