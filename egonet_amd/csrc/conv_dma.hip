@@ -169,6 +169,16 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF[mt].w, BF[nt].w, acc[mt][nt], 0, 0, 0);    \
   }
 
+// Scheduling hint for one tap: an MFMA occupies its pipe for 32 cycles, the
+// wave can issue ~6 other instructions meanwhile.  Ask the scheduler to put one
+// DS-read / VALU / SALU instruction (the next tap's fragment reads and their
+// address math) behind every MFMA instead of a block of them in front.
+#define EGN_INTERLEAVE()                                                             \
+  _Pragma("unroll") for (int k_ = 0; k_ < MT * NT * 4; ++k_) {                       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */                  \
+    __builtin_amdgcn_sched_group_barrier(0x106, 1, 0); /* 1 DS read | VALU | SALU */ \
+  }
+
 // MFMA loop of stage S on sA[chunk & 1] / sB[S & 1]; the ds_reads of tap t+1 are
 // issued before the MFMAs of tap t (register double buffer afA/afB)
 #define EGN_COMPUTE(S)                                                  \
@@ -187,11 +197,15 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
         if (tt + 1 < nts) EGN_MFMA(afA, bfA)                            \
         continue;                                                       \
       }                                                                 \
-      if (tt + 1 < nts) EGN_LOADF(afB, bfB, tt + 1)                     \
+      /* branch-free prefetch (clamped tap) so that the ds_reads and the */ \
+      /* MFMAs share one scheduling region and can be interleaved        */ \
+      EGN_LOADF(afB, bfB, min(tt + 1, nts - 1))                         \
       EGN_MFMA(afA, bfA)                                                \
+      EGN_INTERLEAVE()                                                  \
       if (tt + 1 < nts) {                                               \
-        if (tt + 2 < nts) EGN_LOADF(afA, bfA, tt + 2)                   \
+        EGN_LOADF(afA, bfA, min(tt + 2, nts - 1))                       \
         EGN_MFMA(afB, bfB)                                              \
+        EGN_INTERLEAVE()                                                \
       }                                                                 \
     }                                                                   \
   }

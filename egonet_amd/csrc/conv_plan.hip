@@ -4,9 +4,11 @@
 // Two kernel families share the tile shapes:
 //   ids  1..10  "staged": global -> registers -> LDS, one LDS buffer, 2 barriers
 //               per stage, ~50 KB LDS -> 3 blocks per CU   (conv_mfma.hip)
-//   ids 11..20  "dma":    buffer_load ... lds straight into a double-buffered
+//   ids 11..30  "dma":    buffer_load ... lds straight into a double-buffered
 //               LDS stage, 1 barrier per stage, register double-buffered
 //               fragments                                   (conv_dma.hip)
+//   ids 31..40  "pers":   the dma pipeline in persistent blocks that walk over
+//               several tiles                               (conv_pers.hip)
 // The engine's tuner times the candidates on the real shape; cfg 0 = cost model.
 #include <stdio.h>
 
@@ -14,6 +16,7 @@
 
 int egn_conv_launch_staged(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
 int egn_conv_launch_dma(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
+int egn_conv_launch_pers(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
 
 static const ConvConfig kConfigs[] = {
     // id wm wn mt nt ai bi dma (ai / bi = staging depth in dwordx4 per lane)
@@ -47,6 +50,16 @@ static const ConvConfig kConfigs[] = {
     {28, 2, 2, 2, 2, 8, 8, 2},
     {29, 1, 4, 4, 1, 8, 8, 2},
     {30, 1, 4, 2, 3, 8, 8, 2},
+    {31, 4, 1, 4, 3, 8, 8, 3},  // persistent LDS-DMA pipeline (conv_pers.hip): blocks walk over
+    {32, 2, 2, 4, 3, 8, 8, 3},  // several tiles, next tile's stage 0 prefetched, wave-private
+    {33, 2, 2, 4, 2, 8, 8, 3},  // epilogue without block barriers
+    {34, 4, 1, 4, 1, 8, 8, 3},
+    {35, 4, 1, 4, 2, 8, 8, 3},
+    {36, 4, 1, 2, 3, 8, 8, 3},
+    {37, 2, 2, 2, 3, 8, 8, 3},
+    {38, 2, 2, 2, 2, 8, 8, 3},
+    {39, 1, 4, 4, 1, 8, 8, 3},
+    {40, 1, 4, 2, 3, 8, 8, 3},
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -66,7 +79,9 @@ extern "C" int egn_conv_config_info(int cfg, int* tile_m, int* tile_n) {
 extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (cfg < 1 || cfg > kNumConfigs || !buf || len < 8) return EGN_E_BADARG;
   const ConvConfig& c = kConfigs[cfg - 1];
-  if (c.dma)
+  if (c.dma == 3)
+    snprintf(buf, len, "void conv_pers_kernel<%d, %d, %d, %d, 8, 8>(ConvArgs)", c.wm, c.wn, c.mt, c.nt);
+  else if (c.dma)
     snprintf(buf, len, "void conv_dma_kernel<%d, %d, %d, %d, 8, 8, 0>(ConvArgs)", c.wm, c.wn, c.mt, c.nt);
   else
     snprintf(buf, len, "void conv_mfma_kernel<%d, %d, %d, %d, %d, %d>(ConvArgs)", c.wm, c.wn, c.mt, c.nt, c.ai,
@@ -77,14 +92,18 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // LDS layout: [ K-loop stage buffers | epilogue sC (aliases them) ][ sPix: TM ints ]
+// (persistent family: the wave-private epilogue slabs, 4 waves x 16 rows, live
+//  BEHIND the stage buffers because the next tile's DMA is in flight during an epilogue)
 static size_t lds_stage_bytes(const ConvArgs& a, const ConvConfig& cf) {
   size_t main_loop = (size_t)(EGN_CKQ * a.npixp + a.tps * EGN_CKQ * cf.tile_n()) * 16;
   if (cf.dma) main_loop *= 2;  // double-buffered stage
+  if (cf.dma == 3) return main_loop;
   // epilogue: 4 waves x (MT*16 rows) x (NT*16 + 4) floats
   const size_t epi = a.out_nchw ? 0 : (size_t)4 * cf.mt * 16 * (cf.nt * 16 + 4) * 4;
   return ((main_loop > epi ? main_loop : epi) + 15) & ~(size_t)15;
 }
 static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
+  if (cf.dma == 3) return lds_stage_bytes(a, cf) + (size_t)4 * 16 * (cf.nt * 16 + 4) * 4;
   return lds_stage_bytes(a, cf) + (size_t)cf.tile_m() * 4;
 }
 
@@ -141,7 +160,7 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
 
 static size_t budget_for(const ConvConfig& cf) {
   // staged: 3 blocks / CU; dma: 2 (ids 11..20) or 3 (ids 21..30) blocks / CU of the 160 KiB LDS
-  return cf.dma == 1 ? 80 * 1024 : (cf.dma == 2 ? 53 * 1024 : 64 * 1024);
+  return (cf.dma == 1 || cf.dma == 3) ? 80 * 1024 : (cf.dma == 2 ? 53 * 1024 : 64 * 1024);
 }
 
 int egn_conv_plan(ConvArgs& a, int& cfg_id, size_t& lds_bytes) {
@@ -192,6 +211,7 @@ int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {
   if (cfg_id < 1 || cfg_id > kNumConfigs) return EGN_E_BADARG;
   const ConvConfig& cf = kConfigs[cfg_id - 1];
   const size_t lds = lds_bytes_for(a, cf);
+  if (cf.dma == 3) return egn_conv_launch_pers(a, (cfg_id - 1) % 10 + 1, lds, stream);
   return cf.dma ? egn_conv_launch_dma(a, (cfg_id - 1) % 10 + 1, lds, stream)
                 : egn_conv_launch_staged(a, cfg_id, lds, stream);
 }

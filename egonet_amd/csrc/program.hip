@@ -1,6 +1,7 @@
 // program.hip -- C ABI front-end: direct conv entry point and the "program"
 // recorder/executor (a native launch list with slot-relative pointers, hipEvent
 // per-op timing and hipGraph capture/replay).
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>

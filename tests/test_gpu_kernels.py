@@ -88,7 +88,7 @@ def test_conv_hrnet_shapes(shape):
     assert err < 2e-4, err
 
 
-@pytest.mark.parametrize('cfg', list(range(1, 31)))      # 1..10 staged family, 11..30 LDS-DMA family
+@pytest.mark.parametrize('cfg', list(range(1, 41)))      # 1..10 staged, 11..30 LDS-DMA, 31..40 persistent
 def test_conv_every_tile_config(cfg):
     # odd sizes: partial tiles in x, y, batch and channels
     import ctypes as C
