@@ -1,0 +1,221 @@
+"""Native training step of the FC lifter on MI355X (BASELINE config 3).
+
+Reference hot loop: ``libs/trainer/trainer.py:183-209`` (zero_grad -> forward ->
+loss -> backward -> optim.step) as driven by ``tools/train_lifting.py`` /
+``trainer.train_cascade`` (trainer.py:25-71): FCModel(66 -> 96) in train mode
+(BatchNorm1d on batch statistics, Dropout p), ``MSELoss1D(reduction='mean')``
+(libs/loss/function.py:204-215), Adam(lr 1e-3) (libs/optimizer/optimizer.py).
+
+``LifterTrainStep.step(x, target)`` runs forward, backward and the Adam update
+as HIP launches only (C ABI, include/egonet_hip.h "training step building
+blocks"); autograd is not involved.  Every GEMM -- forward ``z = a W^T``, dgrad
+``da = dz W`` and wgrad ``dW = dz^T a`` -- runs on the fp32-MFMA conv kernel
+with weights packed on the device each step; BatchNorm/ReLU/dropout forward and
+backward, bias/column sums, the MSE and Adam are fused HBM-bound kernels
+(csrc/train_ops.hip).  The module's ``nn.Parameter``s and BatchNorm buffers are
+updated in place, so ``state_dict()`` / ``L.pth`` stay the interface.
+
+Dropout uses a torch-generated keep mask (the reference's mask stream cannot be
+reproduced bit for bit anyway); parity tests run with p = 0.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, tuner
+from .engine import _round_up
+
+
+class _Unit(object):
+    """Linear (+ BatchNorm1d + ReLU + dropout) with everything backward needs."""
+
+    def __init__(self, fc, bn):
+        self.fc, self.bn = fc, bn
+        self.inf, self.outf = fc.in_features, fc.out_features
+
+
+class LifterTrainStep(object):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, dropout=None):
+        p0 = next(model.parameters())
+        if not p0.is_cuda:
+            raise ValueError('LifterTrainStep needs the model on a GPU')
+        if model.leaky:
+            raise NotImplementedError('native training implements ReLU (the shipped configs); leaky=False')
+        self.model = model
+        self.dev = p0.device
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.p = float(model.p_dropout if dropout is None else dropout)
+        self.units = [_Unit(model.w1, model.batch_norm1)]
+        for blk in model.res_blocks:
+            self.units += [_Unit(blk.w1, blk.batch_norm1), _Unit(blk.w2, blk.batch_norm2)]
+        self.final = model.w2
+        self.t = 0
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.grads = {id(p): torch.zeros_like(p) for p in self.params}
+        self.m = {id(p): torch.zeros_like(p) for p in self.params}
+        self.v = {id(p): torch.zeros_like(p) for p in self.params}
+        for p in self.params:
+            p.grad = self.grads[id(p)]
+        self._ws = {}
+        widest = _round_up(max([u.outf for u in self.units] + [u.inf for u in self.units]
+                               + [self.final.out_features]), 16) + 16
+        self.ones = torch.ones(widest, dtype=torch.float32, device=self.dev)     # conv scale (no BN folding here)
+        self.zeros = torch.zeros(widest, dtype=torch.float32, device=self.dev)   # conv shift for dgrad / wgrad
+        self.L = _lib.lib()
+        self.loss_dev = torch.zeros(1, dtype=torch.float64, device=self.dev)
+
+    # -- helpers -----------------------------------------------------------
+    def _buf(self, name, *shape):
+        key = (name,) + shape
+        t = self._ws.get(key)
+        if t is None:
+            t = torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+            self._ws[key] = t
+        return t
+
+    def _st(self):
+        return _lib.current_stream(self.dev)
+
+    def _gemm(self, a, rows, k, ld_a, w_src, ld_w, cout, transpose_w, out, shift=None, tagk=''):
+        """out[rows, cout] (contiguous) = a[rows, :k] @ W^T + shift, W[co][ci] taken from
+        w_src (row-major, ld_w) directly (transpose_w=0) or transposed (1)."""
+        L = self.L
+        coutp = _round_up(cout, 16)
+        nchunk = (k + 15) // 16
+        wp = self._buf('wp' + tagk, nchunk * 4 * coutp * 4)
+        _lib.check(L.egn_pack_matrix_f32(_lib.ptr(w_src), ld_w, cout, k, transpose_w, _lib.ptr(wp), self._st()),
+                   'pack')
+        sc = self.ones
+        if shift is None:
+            sh = self.zeros
+        else:
+            sh = self._buf('shift' + tagk, coutp)
+            sh[:cout].copy_(shift.detach())
+        # a contiguous [rows, cout] result is NHWC with cs = cout when cout % 4 == 0
+        # (float4 row stores); otherwise the NCHW store path writes the same layout
+        nchw = 1 if cout % 4 else 0
+        key = (rows, 1, 1, k, ld_a, cout, cout, 1, 1, 1, 0, False, bool(nchw))
+        cfg = tuner.choose(self.dev, key)
+        _lib.check(L.egn_conv2d_f32(_lib.ptr(a), _lib.ptr(wp), _lib.ptr(sc), _lib.ptr(sh), None, _lib.ptr(out),
+                                    rows, 1, 1, k, ld_a, cout, cout, 1, 1, 1, 0, 0, nchw, cfg, self._st()), 'gemm')
+        return out
+
+    def _transpose(self, src, r, c, ld_src, name):
+        ld_dst = _round_up(r, 4)
+        dst = self._buf(name, c, ld_dst)
+        _lib.check(self.L.egn_transpose_f32(_lib.ptr(src), r, c, ld_src, _lib.ptr(dst), ld_dst, self._st()), 'transpose')
+        return dst, ld_dst
+
+    # -- the step -----------------------------------------------------------
+    @torch.no_grad()
+    def step(self, x, target, update=True):
+        """One zero_grad/forward/loss/backward/Adam iteration.  Returns the loss
+        (Python float is NOT forced: a 1-element float64 device tensor)."""
+        L, dev = self.L, self.dev
+        B = x.shape[0]
+        if B % 4:
+            raise ValueError('batch size must be a multiple of 4 (row stride of the transposed operands)')
+        x = x.contiguous().float()
+        target = target.contiguous().float()
+        ws = self._buf('colws', L.egn_colreduce_ws_bytes(1024 + 16) // 4)
+        st = self._st()
+        keep = 1.0 / (1.0 - self.p) if self.p > 0 else 1.0
+
+        with torch.cuda.device(dev):
+            # input rows padded to a multiple of 4 floats
+            ld0 = _round_up(self.units[0].inf, 4)
+            a = self._buf('a0', B, ld0)
+            _lib.check(L.egn_nchw_to_nhwc_f32(_lib.ptr(x), _lib.ptr(a), B, self.units[0].inf, 1, 1, ld0, st))
+            saved = []
+            ld_a = ld0
+            block_in = None
+            for ui, u in enumerate(self.units):
+                z = self._buf('z%d' % ui, B, u.outf)
+                self._gemm(a, B, u.inf, ld_a, u.fc.weight, u.inf, u.outf, 0, z, shift=u.fc.bias, tagk='f%d' % ui)
+                mean = self._buf('mean%d' % ui, u.outf)
+                istd = self._buf('istd%d' % ui, u.outf)
+                varu = self._buf('varu%d' % ui, u.outf)
+                _lib.check(L.egn_bn_stats_f32(_lib.ptr(z), B, u.outf, u.outf, u.bn.eps, _lib.ptr(mean), _lib.ptr(istd),
+                                              _lib.ptr(varu), _lib.ptr(ws), st), 'bn_stats')
+                mom = u.bn.momentum if u.bn.momentum is not None else 0.1
+                _lib.check(L.egn_ema_f32(_lib.ptr(u.bn.running_mean), _lib.ptr(mean), mom, u.outf, st))
+                _lib.check(L.egn_ema_f32(_lib.ptr(u.bn.running_var), _lib.ptr(varu), mom, u.outf, st))
+                u.bn.num_batches_tracked += 1
+                mask = None
+                if self.p > 0:
+                    mask = self._buf('mask%d' % ui, B, u.outf)
+                    mask.copy_((torch.rand(B, u.outf, device=dev) >= self.p).float())
+                y = self._buf('y%d' % ui, B, u.outf)
+                _lib.check(L.egn_bn_act_fwd_f32(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(u.bn.weight),
+                                                _lib.ptr(u.bn.bias), _lib.ptr(mask), keep, 1, _lib.ptr(y), B,
+                                                u.outf, u.outf, st), 'bn_act_fwd')
+                saved.append((a, ld_a, z, mean, istd, mask))
+                if ui == 0:
+                    block_in = y
+                    a = y
+                elif ui % 2 == 1:          # first unit of a residual block
+                    a = y
+                else:                      # second unit: out = block_in + y   (FCmodel.py:33-43)
+                    out = self._buf('blk%d' % ui, B, u.outf)
+                    _lib.check(L.egn_add_f32(_lib.ptr(block_in), _lib.ptr(y), _lib.ptr(out), B * u.outf, st))
+                    block_in = out
+                    a = out
+                ld_a = u.outf
+            feat = a
+            nf = self.final.in_features
+            no = self.final.out_features
+            pred = self._buf('pred', B, no)
+            self._gemm(feat, B, nf, nf, self.final.weight, nf, no, 0, pred, shift=self.final.bias, tagk='fo')
+            # loss + gradient of the prediction
+            self.loss_dev.zero_()
+            dpred = self._buf('dpred', B, no)
+            _lib.check(L.egn_mse_f32(_lib.ptr(pred), _lib.ptr(target), B, no, no, no, _lib.ptr(dpred),
+                                     _lib.ptr(self.loss_dev), st), 'mse')
+
+            # ---- backward ----
+            g = self.grads
+            dT, ldt = self._transpose(dpred, B, no, no, 'dT_o')            # [no, B]
+            fT, ldf = self._transpose(feat, B, nf, nf, 'aT_o')             # [nf, B]
+            self._gemm(dT, no, B, ldt, fT, ldf, nf, 0, g[id(self.final.weight)], tagk='wo')
+            _lib.check(L.egn_colsum_f32(_lib.ptr(dpred), B, no, no, _lib.ptr(g[id(self.final.bias)]), _lib.ptr(ws), st))
+            dy = self._buf('dy_top', B, nf)
+            self._gemm(dpred, B, no, no, self.final.weight, nf, nf, 1, dy, tagk='do')
+
+            d_block_out = dy              # gradient w.r.t. the output of the current residual block
+            for ui in range(len(self.units) - 1, -1, -1):
+                u = self.units[ui]
+                a_in, ld_in, z, mean, istd, mask = saved[ui]
+                if ui == 0 or ui % 2 == 0:
+                    d_y = d_block_out     # unit 0 and the second unit of a block see the block-output gradient
+                dbeta, dgamma = g[id(u.bn.bias)], g[id(u.bn.weight)]
+                _lib.check(L.egn_bn_bwd_sums_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
+                                                 _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), 1, B,
+                                                 u.outf, u.outf, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(ws), st),
+                           'bn_bwd_sums')
+                dz = self._buf('dz', B, u.outf)
+                _lib.check(L.egn_bn_bwd_dz_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
+                                               _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), 1,
+                                               _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(dz), B, u.outf, u.outf, st),
+                           'bn_bwd_dz')
+                dzT, ldz = self._transpose(dz, B, u.outf, u.outf, 'dzT')                  # [outf, B]
+                aT, lda = self._transpose(a_in, B, u.inf, ld_in, 'aT%d' % (0 if ui == 0 else 1))   # [inf, B]
+                self._gemm(dzT, u.outf, B, ldz, aT, lda, u.inf, 0, g[id(u.fc.weight)], tagk='w%d' % (0 if ui == 0 else 1))
+                _lib.check(L.egn_colsum_f32(_lib.ptr(dz), B, u.outf, u.outf, _lib.ptr(g[id(u.fc.bias)]), _lib.ptr(ws), st))
+                if ui == 0:
+                    break
+                da = self._buf('da%d' % (ui % 2), B, u.inf)
+                self._gemm(dz, B, u.outf, u.outf, u.fc.weight, u.inf, u.inf, 1, da, tagk='d')
+                if ui % 2 == 0:            # second unit of a block: continue into the first unit
+                    d_y = da
+                else:                      # first unit: block input gradient = skip path + branch path
+                    nxt = self._buf('dblk%d' % ((ui // 2) % 2), B, u.inf)
+                    _lib.check(L.egn_add_f32(_lib.ptr(d_block_out), _lib.ptr(da), _lib.ptr(nxt), B * u.inf, st))
+                    d_block_out = nxt
+
+            if update:
+                self.t += 1
+                for p in self.params:
+                    _lib.check(L.egn_adam_step_f32(_lib.ptr(p), _lib.ptr(g[id(p)]), _lib.ptr(self.m[id(p)]),
+                                                   _lib.ptr(self.v[id(p)]), p.numel(), self.lr, self.betas[0],
+                                                   self.betas[1], self.eps, self.t, st), 'adam')
+        return self.loss_dev

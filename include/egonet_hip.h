@@ -147,6 +147,59 @@ int egn_pose_solve_f64(const double* pred3d, int n, const double* kpt_x,
                        double* euler, double* alpha, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Training step building blocks (reference: libs/trainer/trainer.py:183-209
+ * zero_grad / forward / loss / backward / optim.step; FCmodel.py Linear +
+ * BatchNorm1d (batch statistics) + ReLU + Dropout; function.py:204-215
+ * MSELoss1D; optimizer.py:8-40 Adam).  The GEMMs of forward / dgrad / wgrad run
+ * on egn_conv2d_f32 (a Linear is a 1x1 conv); matrices are row-major
+ * [rows, ld] fp32 with ld % 4 == 0.
+ * ---------------------------------------------------------------------- */
+/* conv weights [nchunk][1][4][CoutP][4] from a row-major matrix:
+ * transpose 0: W[co][ci] = src[co*ld+ci]; 1: W[co][ci] = src[ci*ld+co] */
+int egn_pack_matrix_f32(const float* src, int ld, int cout, int cin,
+                        int transpose, float* dst, void* stream);
+/* dst[c][r] = src[r][c]; dst columns R..ld_dst-1 are zeroed */
+int egn_transpose_f32(const float* src, int R, int C, int ld_src, float* dst,
+                      int ld_dst, void* stream);
+/* scratch bytes the column reductions below need for `cols` columns */
+long egn_colreduce_ws_bytes(int cols);
+int egn_colsum_f32(const float* a, int rows, int cols, int ld, float* sum,
+                   void* ws, void* stream);
+/* per-column batch statistics: mean, 1/sqrt(biased var + eps), unbiased var */
+int egn_bn_stats_f32(const float* z, int rows, int cols, int ld, float eps,
+                     float* mean, float* invstd, float* var_unbiased, void* ws,
+                     void* stream);
+/* y = relu?(gamma*(z-mean)*invstd + beta) * (mask ? mask*keep_scale : 1) */
+int egn_bn_act_fwd_f32(const float* z, const float* mean, const float* invstd,
+                       const float* gamma, const float* beta, const float* mask,
+                       float keep_scale, int relu, float* y, int rows, int cols,
+                       int ld, void* stream);
+/* BatchNorm backward, step 1: dbeta = sum dpre, dgamma = sum dpre*xhat with
+ * dpre = dy * dropout-mask * relu-mask */
+int egn_bn_bwd_sums_f32(const float* dy, const float* z, const float* mask,
+                        float keep_scale, const float* mean, const float* invstd,
+                        const float* gamma, const float* beta, int relu, int rows,
+                        int cols, int ld, float* dbeta, float* dgamma, void* ws,
+                        void* stream);
+/* step 2: dz = gamma*invstd*(dpre - dbeta/rows - xhat*dgamma/rows) */
+int egn_bn_bwd_dz_f32(const float* dy, const float* z, const float* mask,
+                      float keep_scale, const float* mean, const float* invstd,
+                      const float* gamma, const float* beta, int relu,
+                      const float* dbeta, const float* dgamma, float* dz, int rows,
+                      int cols, int ld, void* stream);
+int egn_add_f32(const float* a, const float* b, float* y, long n, void* stream);
+/* *loss += mean((pred-tgt)^2) (zero it first); dpred = 2(pred-tgt)/(rows*cols) */
+int egn_mse_f32(const float* pred, const float* tgt, int rows, int cols,
+                int ld_pred, int ld_tgt, float* dpred, double* loss, void* stream);
+/* running = (1-momentum)*running + momentum*batch */
+int egn_ema_f32(float* running, const float* batch, float momentum, int n,
+                void* stream);
+/* torch.optim.Adam (weight_decay 0, no amsgrad), step counted from 1 */
+int egn_adam_step_f32(float* p, const float* g, float* m, float* v, long n,
+                      float lr, float beta1, float beta2, float eps, int step,
+                      void* stream);
+
+/* ------------------------------------------------------------------------
  * Programs: a recorded sequence of the launches above with every pointer
  * expressed as (slot, byte offset).  Slots are bound to base addresses before
  * a run (slot 0 = activation arena, 1 = packed weights, 2.. = user tensors),

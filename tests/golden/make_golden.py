@@ -178,6 +178,28 @@ def main():
         save('lifter_tiny%s.npz' % ('_leaky' if leaky else ''), x=xin.numpy(),
              y=yout.numpy(), **sd_np(sd))
 
+    # ---- 6b: three training iterations of the reference lifter (train mode,
+    #          batch-stat BatchNorm, Dropout p=0, MSELoss(mean), Adam 1e-3) -----
+    c3 = configs.tiny_config()
+    c3['FCModel']['dropout'] = 0.0
+    fc = ref_fc.get_fc_model(1, c3, 10, 12).train()
+    sd = synth.synth_state_dict(fc.state_dict(), seed=9)
+    fc.load_state_dict(sd)
+    opt = torch.optim.Adam(fc.parameters(), lr=1e-3)
+    crit = torch.nn.MSELoss(reduction='mean')
+    xs = torch.randn(3, 16, 10, generator=g)
+    ys = torch.randn(3, 16, 12, generator=g)
+    losses = []
+    for it in range(3):
+        opt.zero_grad()
+        loss = crit(fc(xs[it]), ys[it])
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    save('lifter_train.npz', xs=xs.numpy(), ys=ys.numpy(), losses=np.array(losses),
+         **{'sd0/' + k: v.numpy() for k, v in sd.items()},
+         **{'sd3/' + k: v.detach().numpy() for k, v in fc.state_dict().items()})
+
     # ---- 7: EgoNet-level pipeline on CPU (tiny HC, 33 joints) --------------
     cfg = configs.hrnet_config(8, (64, 64), 33, 'coordinates', modules=(1, 1, 1),
                                num_blocks=1, lifter_neurons=128)

@@ -1,0 +1,93 @@
+"""Native training step of the FC lifter (BASELINE config 3) on MI355X:
+forward + backward + Adam as HIP launches, against (a) the reference's own
+three iterations (tests/golden/lifter_train.npz) and (b) the CPU training
+oracle at full size.
+
+Linear biases that feed a BatchNorm have an analytically ZERO gradient (the
+batch mean removes them); what is left is rounding noise that Adam normalises
+to +-lr steps of random sign -- in the reference too.  Those entries do not
+influence the network function and are compared with a tolerance of 3 steps
+of lr; everything else is compared tightly."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from egonet_amd import configs, synth
+from egonet_amd.model import FCmodel
+from egonet_amd.train_lifter import LifterTrainStep
+from oracle.lifter_train_oracle import LifterTrainOracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _is_dead_bias(k):
+    return k.endswith('.bias') and not k.startswith('w2.') and 'batch_norm' not in k
+
+
+def test_lifter_train_step_vs_reference_iterations():
+    g = golden('lifter_train.npz')
+    sd0 = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd0/')}
+    sd3 = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd3/')}
+    cfg = configs.tiny_config()
+    cfg['FCModel']['dropout'] = 0.0
+    net = FCmodel.get_fc_model(1, cfg, 10, 12)
+    net.load_state_dict(sd0)
+    net = net.cuda().train()
+    tr = LifterTrainStep(net, lr=1e-3)
+    losses = []
+    for i in range(3):
+        loss = tr.step(torch.from_numpy(g['xs'][i]).cuda(), torch.from_numpy(g['ys'][i]).cuda())
+        losses.append(float(loss.item()))
+    np.testing.assert_allclose(losses, g['losses'], rtol=2e-5)
+    got = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    for k, v in sd3.items():
+        tol = 3.5e-3 if _is_dead_bias(k) else 2e-5
+        if k.endswith('num_batches_tracked'):
+            assert int(got[k]) == int(v) == 3
+            continue
+        np.testing.assert_allclose(got[k].numpy(), v.numpy(), rtol=0, atol=tol, err_msg=k)
+
+
+def test_lifter_gradients_full_size_vs_oracle():
+    cfg = configs.w48_config()
+    cfg['FCModel']['dropout'] = 0.0
+    net = FCmodel.get_fc_model(1, cfg, 66, 96)
+    sd = synth.synth_state_dict(net.state_dict(), seed=2)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn(256, 66, generator=g), torch.randn(256, 96, generator=g)
+    orc = LifterTrainOracle(sd, lr=1e-3)
+    want_loss = orc.step(x, y)
+    want = orc.grads()
+    net = net.cuda().train()
+    tr = LifterTrainStep(net, lr=1e-3)
+    loss = tr.step(x.cuda(), y.cuda(), update=False)
+    assert abs(float(loss.item()) - want_loss) < 1e-5 * max(1.0, want_loss)
+    named = dict(net.named_parameters())
+    for k, gw in want.items():
+        got = named[k].grad.cpu()
+        scale = float(gw.abs().max())
+        if _is_dead_bias(k):
+            assert float(got.abs().max()) < 1e-5           # analytically zero
+            continue
+        np.testing.assert_allclose(got.numpy(), gw.numpy(), rtol=0, atol=2e-4 * scale + 1e-8, err_msg=k)
+    # running statistics follow torch's momentum / unbiased-variance rule
+    np.testing.assert_allclose(net.batch_norm1.running_var.cpu().numpy(),
+                               orc.sd['batch_norm1.running_var'].numpy(), rtol=1e-4)
+    np.testing.assert_allclose(net.batch_norm1.running_mean.cpu().numpy(),
+                               orc.sd['batch_norm1.running_mean'].numpy(), atol=1e-5)
+
+
+def test_lifter_training_reduces_loss_with_dropout():
+    cfg = configs.tiny_config()
+    net = FCmodel.get_fc_model(1, cfg, 10, 12).cuda().train()      # dropout 0.5 active
+    tr = LifterTrainStep(net, lr=1e-2)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 10, generator=g).cuda()
+    w = torch.randn(10, 12, generator=g).cuda()
+    y = x @ w
+    first = float(tr.step(x, y).item())
+    for _ in range(60):
+        last = float(tr.step(x, y).item())
+    assert np.isfinite(last) and last < 0.5 * first

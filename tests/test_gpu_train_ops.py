@@ -1,0 +1,174 @@
+"""Building blocks of the native training step (csrc/train_ops.hip) through the
+C ABI, each against plain torch on the same device tensors copied to the host."""
+import numpy as np
+import pytest
+import torch
+
+from egonet_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _st():
+    return _lib.current_stream()
+
+
+def _ws(cols):
+    L = _lib.lib()
+    return torch.zeros(L.egn_colreduce_ws_bytes(cols) // 4, device='cuda')
+
+
+@pytest.mark.parametrize('rows,cols,ld', [(7, 5, 8), (64, 96, 96), (100, 33, 36), (4096, 66, 68)])
+def test_transpose(rows, cols, ld):
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(rows)
+    src = torch.randn(rows, ld, generator=g).cuda()
+    ldd = (rows + 3) // 4 * 4
+    dst = torch.full((cols, ldd), 7.0, device='cuda')
+    _lib.check(L.egn_transpose_f32(_lib.ptr(src), rows, cols, ld, _lib.ptr(dst), ldd, _st()))
+    want = torch.zeros(cols, ldd)
+    want[:, :rows] = src.cpu()[:, :cols].t()
+    assert torch.equal(dst.cpu(), want)        # pad columns are zeroed
+
+
+@pytest.mark.parametrize('cout,cin,transpose', [(12, 10, 0), (12, 10, 1), (1024, 66, 0), (96, 1024, 1), (33, 40, 1)])
+def test_pack_matrix_feeds_the_conv_kernel(cout, cin, transpose):
+    """pack on the device, then run the 1x1 conv: out = a @ W^T exactly as F.linear."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(cout * 7 + cin)
+    w = torch.randn(cout, cin, generator=g) * 0.1
+    src = (w.t().contiguous() if transpose else w).cuda()
+    ld = src.shape[1]
+    coutp, nchunk = (cout + 15) // 16 * 16, (cin + 15) // 16
+    wp = torch.zeros(nchunk * 4 * coutp * 4, device='cuda')
+    _lib.check(L.egn_pack_matrix_f32(_lib.ptr(src), ld, cout, cin, transpose, _lib.ptr(wp), _st()))
+    rows, ld_a = 40, (cin + 3) // 4 * 4
+    a = torch.zeros(rows, ld_a)
+    a[:, :cin] = torch.randn(rows, cin, generator=g)
+    ad = a.cuda()
+    out = torch.zeros(rows, cout, device='cuda')
+    one, zero = torch.ones(coutp, device='cuda'), torch.zeros(coutp, device='cuda')
+    _lib.check(L.egn_conv2d_f32(_lib.ptr(ad), _lib.ptr(wp), _lib.ptr(one), _lib.ptr(zero), None, _lib.ptr(out),
+                                rows, 1, 1, cin, ld_a, cout, cout, 1, 1, 1, 0, 0, 1, 0, _st()))
+    want = a[:, :cin].double() @ w.double().t()
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=0, atol=1e-5 * max(1.0, float(want.abs().max())))
+
+
+@pytest.mark.parametrize('rows,cols', [(4, 12), (16, 128), (250, 96), (4096, 1024)])
+def test_column_reductions(rows, cols):
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(rows + cols)
+    z = (torch.randn(rows, cols, generator=g) * 2 + 0.5).cuda()
+    ws = _ws(cols)
+    s = torch.zeros(cols, device='cuda')
+    _lib.check(L.egn_colsum_f32(_lib.ptr(z), rows, cols, cols, _lib.ptr(s), _lib.ptr(ws), _st()))
+    zd = z.cpu().double()
+    np.testing.assert_allclose(s.cpu().numpy(), zd.sum(0).numpy(), rtol=1e-6, atol=1e-5)
+    mean, istd, varu = (torch.zeros(cols, device='cuda') for _ in range(3))
+    _lib.check(L.egn_bn_stats_f32(_lib.ptr(z), rows, cols, cols, 1e-5, _lib.ptr(mean), _lib.ptr(istd),
+                                  _lib.ptr(varu), _lib.ptr(ws), _st()))
+    np.testing.assert_allclose(mean.cpu().numpy(), zd.mean(0).numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(istd.cpu().numpy(), (zd.var(0, unbiased=False) + 1e-5).rsqrt().numpy(), rtol=2e-6)
+    np.testing.assert_allclose(varu.cpu().numpy(), zd.var(0, unbiased=True).numpy(), rtol=2e-6)
+
+
+@pytest.mark.parametrize('rows,cols,p', [(16, 128, 0.0), (64, 100, 0.5), (512, 1024, 0.5)])
+def test_bn_relu_dropout_forward_backward(rows, cols, p):
+    """bn_act_fwd / bn_bwd_sums / bn_bwd_dz against autograd through
+    batch_norm(training) -> relu -> mask."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(cols)
+    z = torch.randn(rows, cols, generator=g) * 1.5 + 0.2
+    gamma = torch.rand(cols, generator=g) + 0.5
+    beta = torch.randn(cols, generator=g) * 0.3
+    dy = torch.randn(rows, cols, generator=g)
+    mask = (torch.rand(rows, cols, generator=g) >= p).float() if p > 0 else None
+    keep = 1.0 / (1.0 - p) if p > 0 else 1.0
+    # torch (float64 autograd)
+    zz, gg, bb = (t.double().requires_grad_(True) for t in (z, gamma, beta))
+    pre = torch.nn.functional.batch_norm(zz, None, None, gg, bb, True, 0.1, 1e-5)
+    y = torch.relu(pre)
+    if mask is not None:
+        y = y * mask.double() * keep
+    y.backward(dy.double())
+    # native
+    zd, gd, bd, dyd = z.cuda(), gamma.cuda(), beta.cuda(), dy.cuda()
+    md = mask.cuda() if mask is not None else None
+    ws = _ws(cols)
+    mean, istd, varu, dbeta, dgamma = (torch.zeros(cols, device='cuda') for _ in range(5))
+    _lib.check(L.egn_bn_stats_f32(_lib.ptr(zd), rows, cols, cols, 1e-5, _lib.ptr(mean), _lib.ptr(istd),
+                                  _lib.ptr(varu), _lib.ptr(ws), _st()))
+    yd = torch.zeros(rows, cols, device='cuda')
+    _lib.check(L.egn_bn_act_fwd_f32(_lib.ptr(zd), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(gd), _lib.ptr(bd),
+                                    _lib.ptr(md), keep, 1, _lib.ptr(yd), rows, cols, cols, _st()))
+    np.testing.assert_allclose(yd.cpu().numpy(), y.detach().numpy(), rtol=0, atol=2e-5)
+    _lib.check(L.egn_bn_bwd_sums_f32(_lib.ptr(dyd), _lib.ptr(zd), _lib.ptr(md), keep, _lib.ptr(mean), _lib.ptr(istd),
+                                     _lib.ptr(gd), _lib.ptr(bd), 1, rows, cols, cols, _lib.ptr(dbeta),
+                                     _lib.ptr(dgamma), _lib.ptr(ws), _st()))
+    dz = torch.zeros(rows, cols, device='cuda')
+    _lib.check(L.egn_bn_bwd_dz_f32(_lib.ptr(dyd), _lib.ptr(zd), _lib.ptr(md), keep, _lib.ptr(mean), _lib.ptr(istd),
+                                   _lib.ptr(gd), _lib.ptr(bd), 1, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(dz),
+                                   rows, cols, cols, _st()))
+    # an element whose pre-activation is within rounding of 0 may flip its ReLU
+    # gate between fp32 and fp64; exclude columns that hold one
+    safe = (pre.detach().abs() > 1e-5).all(0).numpy()
+    assert safe.mean() > 0.9
+    np.testing.assert_allclose(dbeta.cpu().numpy()[safe], bb.grad.numpy()[safe], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(dgamma.cpu().numpy()[safe], gg.grad.numpy()[safe], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(dz.cpu().numpy()[:, safe], zz.grad.numpy()[:, safe], rtol=0, atol=1e-4)
+
+
+def test_mse_loss_and_gradient():
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(4)
+    pred, tgt = torch.randn(300, 96, generator=g), torch.randn(300, 96, generator=g)
+    pd, td = pred.cuda(), tgt.cuda()
+    dp = torch.zeros_like(pd)
+    loss = torch.zeros(1, dtype=torch.float64, device='cuda')
+    _lib.check(L.egn_mse_f32(_lib.ptr(pd), _lib.ptr(td), 300, 96, 96, 96, _lib.ptr(dp), _lib.ptr(loss), _st()))
+    pp = pred.double().requires_grad_(True)
+    want = torch.nn.functional.mse_loss(pp, tgt.double())
+    want.backward()
+    assert abs(float(loss.item()) - float(want)) < 1e-9
+    np.testing.assert_allclose(dp.cpu().numpy(), pp.grad.numpy(), rtol=1e-6, atol=1e-10)
+
+
+def test_adam_matches_torch_optim():
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(5000, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p = p0.cuda()
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for t in range(1, 6):
+        grad = torch.randn(5000, generator=g) * (10.0 ** (t - 3))
+        ref.grad = grad.clone()
+        opt.step()
+        gd = grad.cuda()
+        _lib.check(L.egn_adam_step_f32(_lib.ptr(p), _lib.ptr(gd), _lib.ptr(m), _lib.ptr(v), 5000, 1e-3, 0.9, 0.999,
+                                       1e-8, t, _st()))
+    np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=0, atol=2e-6)
+
+
+def test_running_stat_update_and_add():
+    L = _lib.lib()
+    r = torch.arange(10, dtype=torch.float32).cuda()
+    b = torch.ones(10, device='cuda') * 2
+    _lib.check(L.egn_ema_f32(_lib.ptr(r), _lib.ptr(b), 0.1, 10, _st()))
+    np.testing.assert_allclose(r.cpu().numpy(), 0.9 * np.arange(10) + 0.2, rtol=1e-6)
+    a = torch.randn(64, 36, device='cuda')
+    c = torch.randn(64, 36, device='cuda')
+    y = torch.zeros_like(a)
+    _lib.check(L.egn_add_f32(_lib.ptr(a), _lib.ptr(c), _lib.ptr(y), a.numel(), _st()))
+    assert torch.equal(y, a + c)
+
+
+def test_bad_arguments_are_refused():
+    L = _lib.lib()
+    a = torch.zeros(16, device='cuda')
+    assert L.egn_add_f32(_lib.ptr(a), _lib.ptr(a), _lib.ptr(a), 6, _st()) != 0           # n % 4
+    assert L.egn_transpose_f32(_lib.ptr(a), 4, 4, 2, _lib.ptr(a), 4, _st()) != 0          # ld_src < C
+    assert L.egn_adam_step_f32(_lib.ptr(a), _lib.ptr(a), _lib.ptr(a), _lib.ptr(a), 16, 1e-3, 0.9, 0.999, 1e-8, 0,
+                               _st()) != 0                                                 # step counts from 1
+    assert L.egn_colsum_f32(_lib.ptr(a), 4, 4, 4, _lib.ptr(a), None, _st()) != 0          # no workspace

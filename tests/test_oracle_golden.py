@@ -147,3 +147,18 @@ def test_pose_oracle_cuboids():
                                g['alpha_proj'], atol=1e-9)
     np.testing.assert_allclose(geometry_oracle.observation_angle_trans(euler, trans),
                                g['alpha_trans'], atol=1e-9)
+
+
+def test_lifter_train_oracle_vs_reference():
+    """Three train-mode iterations (batch-stat BN, MSE(mean), Adam) of the
+    reference's FCModel on CPU."""
+    from oracle.lifter_train_oracle import LifterTrainOracle
+    g = golden('lifter_train.npz')
+    sd0 = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd0/')}
+    sd3 = {k[4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith('sd3/')}
+    orc = LifterTrainOracle(sd0, lr=1e-3)
+    losses = [orc.step(torch.from_numpy(g['xs'][i]), torch.from_numpy(g['ys'][i])) for i in range(3)]
+    np.testing.assert_allclose(losses, g['losses'], rtol=1e-6)
+    for k, v in sd3.items():
+        np.testing.assert_allclose(orc.sd[k].detach().numpy(), v.numpy(), rtol=0, atol=2e-6, err_msg=k)
+    assert int(orc.sd['batch_norm1.num_batches_tracked']) == 3
