@@ -43,6 +43,8 @@ def test_lifter_train_step_vs_reference_iterations():
     got = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     for k, v in sd3.items():
         tol = 3.5e-3 if _is_dead_bias(k) else 2e-5
+        if k.endswith('running_mean'):
+            tol = 1e-3          # the batch mean of z = a W^T + b carries the randomly walking dead bias b
         if k.endswith('num_batches_tracked'):
             assert int(got[k]) == int(v) == 3
             continue
