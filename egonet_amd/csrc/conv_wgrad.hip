@@ -1,0 +1,289 @@
+// conv_wgrad.hip -- weight gradient of a convolution / Linear layer on fp32 MFMA.
+//
+// Reference: the backward pass autograd runs for nn.Conv2d / nn.Linear inside
+// the training hot loop, libs/trainer/trainer.py:183-209 (loss.backward()), for
+// the layers of libs/model/heatmapModel/hrnet.py and libs/model/FCmodel.py:
+//     dW[co][ci][ky][kx] = sum_{n,oy,ox} dy[n][oy][ox][co] * x[n][oy*s+ky-p][ox*s+kx-p][ci]
+//
+// GEMM view: M = Cout, N = Cin (per tap), K = output pixels.  K is the huge
+// dimension (N*Ho*Wo), M x N x taps is small, so the parallelism comes from
+// splitting K: grid = (co-tile x ci-tile, split); every block walks over its
+// range of pixel tiles, keeps its [CW x IW x taps] accumulators in registers and
+// writes ONE partial at the end; a second kernel sums the partials in a fixed
+// order (deterministic, no atomics) into torch's [Cout][Cin][KH][KW] layout.
+//
+// MFMA mapping (v_mfma_f32_16x16x4_f32, k = 4 pixels per instruction).  Both
+// operands are NHWC, i.e. channel-contiguous per pixel, so one ds_read_b128 of
+// a lane brings 4 consecutive CHANNELS of one pixel.  Lane l = (i = l & 15,
+// kq = l >> 4) reads dy[pixel 4s+kq][co 4i..4i+3] and x[shifted pixel][ci 4i..4i+3];
+// element ja of the first and jb of the second feed MFMA (ja, jb), whose 16x16
+// result covers output rows {4m+ja} x columns {4n+jb}: 16 MFMAs per two LDS
+// reads, a 64 x 64 (co x ci) tile per wave and tap.  The filter taps are
+// spread over the waves of a block (3x3: nine waves share one staged dy tile
+// and one x halo tile), so the tap shift is only an LDS address offset.
+#include <algorithm>
+
+#include "egn_internal.h"
+#include "conv_common.h"
+
+struct WgradArgs {
+  const float* x;
+  const float* dy;
+  float* part;  // [nsplit][taps][CoP][CiP]
+  int N, H, W, Cin, cs_in;
+  int Ho, Wo, Cout, cs_out;
+  int KH, KW, stride, pad, taps;
+  int TH, TW, TNB, lg_tw, lg_thw;  // output-pixel tile: TNB images x TH x TW (TW, TH*TW powers of two)
+  int HH, HWd;                     // halo rows / cols per image
+  int TP, NHP;                     // output pixels (multiple of 4) / halo pixels per tile
+  int tiles_x, tiles_y, ntiles, tiles_per_split, nsplit;
+  int co_tiles, ci_tiles, CoP, CiP;
+};
+
+template <int NTAPW, int TPW, int WM, int WN>
+__global__ __launch_bounds__(64 * NTAPW * WM * WN) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int NT = 64 * NTAPW * WM * WN;
+  constexpr int CW = 64 * WM, IW = 64 * WN;
+  constexpr int LDA = CW + 4, LDB = IW + 4;  // +4 floats: rows stay 16 B aligned, banks rotate
+  extern __shared__ float wsm[];
+  float* sA = wsm;                // [TP][LDA]   dy tile
+  float* sB = wsm + a.TP * LDA;   // [NHP][LDB]  x halo tile
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tapw = wave / (WM * WN);
+  const int wm = (wave / WN) % WM;
+  const int wn = wave % WN;
+  const int li = lane & 15;
+  const int kq = lane >> 4;
+
+  const int cot = blockIdx.x % a.co_tiles;
+  const int cit = blockIdx.x / a.co_tiles;
+  const int co0 = cot * CW, ci0 = cit * IW;
+
+  f32x4 acc[TPW][4][4];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) acc[t][ja][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int tap_off[TPW];  // LDS pixel offset of this wave's taps inside the halo tile (-1: no such tap)
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = tapw + t * NTAPW;
+    tap_off[t] = tap < a.taps ? (tap / a.KW) * a.HWd + (tap % a.KW) : -1;
+  }
+
+  const int t_begin = blockIdx.y * a.tiles_per_split;
+  const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+  const int thw_mask = (1 << a.lg_thw) - 1;
+  const int tw_mask = a.TW - 1;
+  const int hpi = a.HH * a.HWd;  // halo pixels per image
+
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int tx = tile % a.tiles_x;
+    const int ty = (tile / a.tiles_x) % a.tiles_y;
+    const int tb = tile / (a.tiles_x * a.tiles_y);
+    const int n_base = tb * a.TNB, oy0 = ty * a.TH, ox0 = tx * a.TW;
+    __syncthreads();  // the previous tile's fragments are consumed
+    // dy tile: rows of pixels outside the image / batch are zero
+    for (int e = tid; e < a.TP * (CW / 4); e += NT) {
+      const int p = e / (CW / 4), c4 = e - p * (CW / 4);
+      const int b = p >> a.lg_thw, rem = p & thw_mask;
+      const int n = n_base + b, oy = oy0 + (rem >> a.lg_tw), ox = ox0 + (rem & tw_mask);
+      const int c = co0 + 4 * c4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b < a.TNB && n < a.N && oy < a.Ho && ox < a.Wo && c < a.cs_out)
+        v = *reinterpret_cast<const float4*>(a.dy + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.cs_out + c);
+      *reinterpret_cast<float4*>(sA + p * LDA + 4 * c4) = v;
+    }
+    // x halo tile: padding and everything outside the image is zero
+    for (int e = tid; e < a.NHP * (IW / 4); e += NT) {
+      const int hp = e / (IW / 4), c4 = e - hp * (IW / 4);
+      const int b = hp / hpi, r = hp - b * hpi;
+      const int hy = r / a.HWd, hx = r - hy * a.HWd;
+      const int n = n_base + b;
+      const int iy = oy0 * a.stride - a.pad + hy, ix = ox0 * a.stride - a.pad + hx;
+      const int c = ci0 + 4 * c4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < a.N && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.cs_in)
+        v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.cs_in + c);
+      *reinterpret_cast<float4*>(sB + hp * LDB + 4 * c4) = v;
+    }
+    __syncthreads();
+    const float* pa = sA + wm * 64 + 4 * li;
+    const float* pb = sB + wn * 64 + 4 * li;
+#pragma unroll 2
+    for (int s = 0; s < a.TP / 4; ++s) {
+      const int p = 4 * s + kq;
+      const int b = p >> a.lg_thw, rem = p & thw_mask;
+      const int hbase = (b * a.HH + (rem >> a.lg_tw) * a.stride) * a.HWd + (rem & tw_mask) * a.stride;
+      const f32x4 av = *reinterpret_cast<const f32x4*>(pa + p * LDA);
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        if (tap_off[t] >= 0) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(pb + (hbase + tap_off[t]) * LDB);
+#pragma unroll
+          for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb)
+              acc[t][ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ja], bv[jb], acc[t][ja][jb], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // partial [split][tap][CoP][CiP]: lane owns rows 4*(4kq+r)+ja, columns 4li..4li+3
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = tapw + t * NTAPW;
+    if (tap < a.taps) {
+      float* dst = a.part + ((size_t)(blockIdx.y * a.taps + tap) * a.CoP + co0 + wm * 64) * a.CiP + ci0 + wn * 64 + 4 * li;
+#pragma unroll
+      for (int ja = 0; ja < 4; ++ja)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * (4 * kq + r) + ja;
+          *reinterpret_cast<float4*>(dst + (size_t)row * a.CiP) =
+              make_float4(acc[t][ja][0][r], acc[t][ja][1][r], acc[t][ja][2][r], acc[t][ja][3][r]);
+        }
+    }
+  }
+}
+
+// dw[co][ci][tap] = sum_s part[s][tap][co][ci]   (fixed order: deterministic)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                           int nsplit, int taps, int Cout, int Cin, int CoP, int CiP) {
+  const size_t total = (size_t)taps * Cout * Cin;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(e % Cin);
+    const int co = (int)((e / Cin) % Cout);
+    const int tap = (int)(e / ((size_t)Cin * Cout));
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += part[((size_t)(k * taps + tap) * CoP + co) * CiP + ci];
+    dw[((size_t)co * Cin + ci) * taps + tap] = s;
+  }
+}
+
+static int ilog2_exact(int v) {
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+static int pow2_ceil(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+struct WgradVariant {
+  int ntapw, tpw, wm, wn;
+};
+
+static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
+  if (a.N <= 0 || a.H <= 0 || a.W <= 0 || a.Cin <= 0 || a.Cout <= 0 || a.KH <= 0 || a.KW <= 0 || a.stride <= 0 ||
+      a.pad < 0 || a.cs_in % 4 || a.cs_out % 4 || a.cs_in < a.Cin || a.cs_out < a.Cout)
+    return EGN_E_BADARG;
+  a.Ho = (a.H + 2 * a.pad - a.KH) / a.stride + 1;
+  a.Wo = (a.W + 2 * a.pad - a.KW) / a.stride + 1;
+  if (a.Ho <= 0 || a.Wo <= 0) return EGN_E_BADARG;
+  a.taps = a.KH * a.KW;
+  if (a.taps == 1) {
+    v = (a.Cout > 64 && a.Cin > 64) ? WgradVariant{1, 1, 2, 2}
+        : (a.Cout > 64)             ? WgradVariant{1, 1, 2, 1}
+        : (a.Cin > 64)              ? WgradVariant{1, 1, 1, 2}
+                                    : WgradVariant{1, 1, 1, 1};
+  } else if (a.taps == 9) {
+    v = WgradVariant{9, 1, 1, 1};
+  } else if (a.taps == 16) {
+    v = WgradVariant{8, 2, 1, 1};
+  } else {
+    return EGN_E_BADARG;
+  }
+  const int CW = 64 * v.wm, IW = 64 * v.wn;
+  a.co_tiles = (a.Cout + CW - 1) / CW;
+  a.ci_tiles = (a.Cin + IW - 1) / IW;
+  a.CoP = a.co_tiles * CW;
+  a.CiP = a.ci_tiles * IW;
+  a.TW = std::min(pow2_ceil(a.Wo), 8);
+  a.TH = std::min(pow2_ceil(a.Ho), 8);
+  a.TNB = std::max(1, 64 / (a.TH * a.TW));
+  const size_t budget = 64 * 1024;
+  for (;;) {
+    if (a.TH * a.TW * a.TNB < 4) a.TNB = 4 / (a.TH * a.TW);
+    a.HH = (a.TH - 1) * a.stride + a.KH;
+    a.HWd = (a.TW - 1) * a.stride + a.KW;
+    a.TP = a.TNB * a.TH * a.TW;
+    a.NHP = a.TNB * a.HH * a.HWd;
+    lds = ((size_t)a.TP * (CW + 4) + (size_t)a.NHP * (IW + 4)) * sizeof(float);
+    if (lds <= budget) break;
+    if (a.TNB > 1 && a.TNB * a.TH * a.TW > 4) a.TNB /= 2;
+    else if (a.TH > 1 && a.TH >= a.TW) a.TH /= 2;
+    else if (a.TW > 1) a.TW /= 2;
+    else if (lds <= 150 * 1024) break;
+    else return EGN_E_BADARG;
+  }
+  a.lg_tw = ilog2_exact(a.TW);
+  a.lg_thw = ilog2_exact(a.TH * a.TW);
+  a.tiles_x = (a.Wo + a.TW - 1) / a.TW;
+  a.tiles_y = (a.Ho + a.TH - 1) / a.TH;
+  const int tiles_b = (a.N + a.TNB - 1) / a.TNB;
+  a.ntiles = a.tiles_x * a.tiles_y * tiles_b;
+  const int base = a.co_tiles * a.ci_tiles;
+  int want = (768 + base - 1) / base;  // ~3 blocks per CU
+  want = std::max(1, std::min(std::min(want, a.ntiles), 64));
+  a.tiles_per_split = (a.ntiles + want - 1) / want;
+  a.nsplit = (a.ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
+  return 0;
+}
+
+template <int NTAPW, int TPW, int WM, int WN>
+static int wgrad_launch(const WgradArgs& a, size_t lds, hipStream_t stream) {
+  auto k = conv_wgrad_kernel<NTAPW, TPW, WM, WN>;
+  if (lds > 64 * 1024) EGN_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, dim3(a.co_tiles * a.ci_tiles, a.nsplit), dim3(64 * NTAPW * WM * WN), lds, stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" long egn_conv2d_wgrad_ws_bytes(int N, int H, int W, int Cin, int cs_in, int Cout, int cs_out, int KH,
+                                          int KW, int stride, int pad) {
+  WgradArgs a = {};
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.cs_in = cs_in; a.Cout = Cout; a.cs_out = cs_out;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+  WgradVariant v;
+  size_t lds;
+  if (wgrad_plan(a, v, lds) != 0) return -1;
+  return (long)((size_t)a.nsplit * a.taps * a.CoP * a.CiP * sizeof(float));
+}
+
+extern "C" int egn_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H, int W, int Cin,
+                                    int cs_in, int Cout, int cs_out, int KH, int KW, int stride, int pad, void* ws,
+                                    long ws_bytes, void* stream) {
+  if (!x || !dy || !dw || !ws) return EGN_E_BADARG;
+  WgradArgs a = {};
+  a.x = x; a.dy = dy; a.part = (float*)ws;
+  a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.cs_in = cs_in; a.Cout = Cout; a.cs_out = cs_out;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+  WgradVariant v;
+  size_t lds;
+  int rc = wgrad_plan(a, v, lds);
+  if (rc != 0) return rc;
+  if ((size_t)ws_bytes < (size_t)a.nsplit * a.taps * a.CoP * a.CiP * sizeof(float)) return EGN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (v.ntapw == 9) rc = wgrad_launch<9, 1, 1, 1>(a, lds, st);
+  else if (v.ntapw == 8) rc = wgrad_launch<8, 2, 1, 1>(a, lds, st);
+  else if (v.wm == 2 && v.wn == 2) rc = wgrad_launch<1, 1, 2, 2>(a, lds, st);
+  else if (v.wm == 2) rc = wgrad_launch<1, 1, 2, 1>(a, lds, st);
+  else if (v.wn == 2) rc = wgrad_launch<1, 1, 1, 2>(a, lds, st);
+  else rc = wgrad_launch<1, 1, 1, 1>(a, lds, st);
+  if (rc != 0) return rc;
+  const size_t total = (size_t)a.taps * Cout * Cin;
+  size_t g = (total + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, a.part, dw, a.nsplit, a.taps, Cout, Cin,
+                     a.CoP, a.CiP);
+  return (int)hipGetLastError();
+}

@@ -57,6 +57,7 @@ class LifterTrainStep(object):
         for p in self.params:
             p.grad = self.grads[id(p)]
         self._ws = {}
+        self._wgrad_floats = 0
         widest = _round_up(max([u.outf for u in self.units] + [u.inf for u in self.units]
                                + [self.final.out_features]), 16) + 16
         self.ones = torch.ones(widest, dtype=torch.float32, device=self.dev)     # conv scale (no BN folding here)
@@ -100,11 +101,17 @@ class LifterTrainStep(object):
                                     rows, 1, 1, k, ld_a, cout, cout, 1, 1, 1, 0, 0, nchw, cfg, self._st()), 'gemm')
         return out
 
-    def _transpose(self, src, r, c, ld_src, name):
-        ld_dst = _round_up(r, 4)
-        dst = self._buf(name, c, ld_dst)
-        _lib.check(self.L.egn_transpose_f32(_lib.ptr(src), r, c, ld_src, _lib.ptr(dst), ld_dst, self._st()), 'transpose')
-        return dst, ld_dst
+    def _wgrad(self, a, ld_a, inf, dz, ld_dz, outf, rows, grad_w):
+        """grad_w[outf, inf] = dz^T a on the split-K MFMA weight-gradient kernel
+        (both operands are read as they lie, row-major)."""
+        L = self.L
+        need = L.egn_conv2d_wgrad_ws_bytes(rows, 1, 1, inf, ld_a, outf, ld_dz, 1, 1, 1, 0)
+        if need < 0:
+            raise _lib.EgonetHipError('wgrad: unsupported shape')
+        ws = self._buf('wgrad_ws', max(need // 4, self._wgrad_floats))
+        self._wgrad_floats = ws.numel()
+        _lib.check(L.egn_conv2d_wgrad_f32(_lib.ptr(a), _lib.ptr(dz), _lib.ptr(grad_w), rows, 1, 1, inf, ld_a, outf,
+                                          ld_dz, 1, 1, 1, 0, _lib.ptr(ws), ws.numel() * 4, self._st()), 'wgrad')
 
     # -- the step -----------------------------------------------------------
     @torch.no_grad()
@@ -174,9 +181,7 @@ class LifterTrainStep(object):
 
             # ---- backward ----
             g = self.grads
-            dT, ldt = self._transpose(dpred, B, no, no, 'dT_o')            # [no, B]
-            fT, ldf = self._transpose(feat, B, nf, nf, 'aT_o')             # [nf, B]
-            self._gemm(dT, no, B, ldt, fT, ldf, nf, 0, g[id(self.final.weight)], tagk='wo')
+            self._wgrad(feat, nf, nf, dpred, no, no, B, g[id(self.final.weight)])
             _lib.check(L.egn_colsum_f32(_lib.ptr(dpred), B, no, no, _lib.ptr(g[id(self.final.bias)]), _lib.ptr(ws), st))
             dy = self._buf('dy_top', B, nf)
             self._gemm(dpred, B, no, no, self.final.weight, nf, nf, 1, dy, tagk='do')
@@ -197,9 +202,7 @@ class LifterTrainStep(object):
                                                _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), 1,
                                                _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(dz), B, u.outf, u.outf, st),
                            'bn_bwd_dz')
-                dzT, ldz = self._transpose(dz, B, u.outf, u.outf, 'dzT')                  # [outf, B]
-                aT, lda = self._transpose(a_in, B, u.inf, ld_in, 'aT%d' % (0 if ui == 0 else 1))   # [inf, B]
-                self._gemm(dzT, u.outf, B, ldz, aT, lda, u.inf, 0, g[id(u.fc.weight)], tagk='w%d' % (0 if ui == 0 else 1))
+                self._wgrad(a_in, ld_in, u.inf, dz, u.outf, u.outf, B, g[id(u.fc.weight)])
                 _lib.check(L.egn_colsum_f32(_lib.ptr(dz), B, u.outf, u.outf, _lib.ptr(g[id(u.fc.bias)]), _lib.ptr(ws), st))
                 if ui == 0:
                     break

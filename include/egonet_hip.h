@@ -154,6 +154,19 @@ int egn_pose_solve_f64(const double* pred3d, int n, const double* kpt_x,
  * on egn_conv2d_f32 (a Linear is a 1x1 conv); matrices are row-major
  * [rows, ld] fp32 with ld % 4 == 0.
  * ---------------------------------------------------------------------- */
+/* Weight gradient of a conv / Linear layer (autograd's backward of nn.Conv2d /
+ * nn.Linear in trainer.py:194 `loss.backward()`):
+ *   dw[co][ci][ky][kx] = sum_{n,oy,ox} dy[n,oy,ox,co] * x[n,oy*s+ky-p,ox*s+kx-p,ci]
+ * x [N,H,W,cs_in], dy [N,Ho,Wo,cs_out] NHWC fp32 (pad channels zero), dw in
+ * torch's [Cout][Cin][KH][KW] layout.  Split-K over pixel tiles with a
+ * deterministic two-pass reduction; ws = scratch of egn_conv2d_wgrad_ws_bytes().
+ * KH*KW in {1, 9, 16}.  A Linear is N = rows, H = W = 1. */
+long egn_conv2d_wgrad_ws_bytes(int N, int H, int W, int Cin, int cs_in, int Cout,
+                               int cs_out, int KH, int KW, int stride, int pad);
+int egn_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H,
+                         int W, int Cin, int cs_in, int Cout, int cs_out, int KH,
+                         int KW, int stride, int pad, void* ws, long ws_bytes,
+                         void* stream);
 /* conv weights [nchunk][1][4][CoutP][4] from a row-major matrix:
  * transpose 0: W[co][ci] = src[co*ld+ci]; 1: W[co][ci] = src[ci*ld+co] */
 int egn_pack_matrix_f32(const float* src, int ld, int cout, int cin,
