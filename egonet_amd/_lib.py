@@ -50,12 +50,18 @@ SIGNATURES = {
     'egn_transpose_f32': (_i, [_p, _i, _i, _i, _p, _i, _p]),
     'egn_colreduce_ws_bytes': (C.c_long, [_i]),
     'egn_colsum_f32': (_i, [_p, _i, _i, _i, _p, _p, _p]),
-    'egn_bn_stats_f32': (_i, [_p, _i, _i, _i, C.c_float, _p, _p, _p, _p, _p]),
-    'egn_bn_act_fwd_f32': (_i, [_p, _p, _p, _p, _p, _p, C.c_float, _i, _p, _i, _i, _i, _p]),
-    'egn_bn_bwd_sums_f32': (_i, [_p, _p, _p, C.c_float, _p, _p, _p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
-    'egn_bn_bwd_dz_f32': (_i, [_p, _p, _p, C.c_float, _p, _p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _p]),
+    'egn_bn_stats_f32': (_i, [_p, _i, _i, _i, C.c_float, _p, _p, _p, _p, _p, C.c_float, _p, _p]),
+    'egn_bn_act_fwd_f32': (_i, [_p, _p, _p, _p, _p, _p, C.c_float, _i, _p, _p, _i, _i, _i, _p]),
+    'egn_bn_bwd_sums_f32': (_i, [_p, _p, _p, C.c_float, _p, _p, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p]),
+    'egn_bn_bwd_dz_f32': (_i, [_p, _p, _p, C.c_float, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
     'egn_add_f32': (_i, [_p, _p, _p, C.c_long, _p]),
-    'egn_mse_f32': (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _p]),
+    'egn_mse_f32': (_i, [_p, _p, _i, _i, _i, _i, C.c_float, _i, _p, _p, _p]),
+    'egn_l1_f32': (_i, [_p, _p, C.c_long, C.c_float, _p, _p, _p]),
+    'egn_sigmoid_bwd_f32': (_i, [_p, _p, _p, C.c_long, _p]),
+    'egn_packed_weight_floats': (C.c_long, [_i] * 5),
+    'egn_pack_conv_weight_f32': (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    'egn_zero_insert2_f32': (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    'egn_fuse_bwd_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'egn_ema_f32': (_i, [_p, _p, C.c_float, _i, _p]),
     'egn_adam_step_f32': (_i, [_p, _p, _p, _p, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, _i, _p]),
     'egn_program_create': (_p, [_i]),

@@ -86,14 +86,17 @@ extern "C" int egn_transpose_f32(const float* src, int R, int C, int ld_src, flo
 }
 
 // ---------------------------------------------------------------------------
-// column reductions over the batch: block = 64 columns x 4 row groups... one
-// block owns 16 float4 column groups (64 columns) and strides over the rows
-// with 16 row lanes; LDS tree over the row lanes.  Sums in fp32 per lane
-// (rows/16 terms each), combined in double.
+// column reductions over the rows of a row-major [rows, ld] matrix (ld % 4 == 0;
+// NHWC activations are exactly this with rows = N*H*W, ld = cs).  A block covers
+// up to 64 float4 column groups and as many row lanes as fit in 256 threads, so
+// consecutive lanes read consecutive 16-byte pieces of consecutive rows; the
+// rows are split over gridDim.y blocks whose partials (double) are combined in
+// a fixed order by a second kernel (deterministic).
 //   mode 0: sum[c]              = sum_r a[r][c]
-//   mode 1: stats of z          : mean[c], invstd[c] (biased var + eps), var_unbiased[c]
+//   mode 1: stats of z          : mean[c], invstd[c] (biased var + eps), var_unbiased[c],
+//                                 optional running-stat update (torch momentum rule)
 //   mode 2: BN backward sums    : s1[c] = sum dpre, s2[c] = sum dpre * xhat
-//           dpre = dy * (mask? mask*keep_scale : 1) * (pre > 0 or no relu), pre = gamma*xhat + beta
+//           dpre = dy * (mask? mask*keep_scale : 1) * gate,  gate = (gamma*xhat + beta + res > 0) or 1
 // ---------------------------------------------------------------------------
 struct ColArgs {
   const float* a;      // z (mode 1, 2) or the matrix to sum (mode 0)
@@ -103,70 +106,109 @@ struct ColArgs {
   const float* invstd; // mode 2
   const float* gamma;  // mode 2
   const float* beta;   // mode 2
+  const float* res;    // mode 2, optional residual added before the ReLU gate
+  float* run_mean;     // mode 1, optional running statistics to update in place
+  float* run_var;
+  float momentum;
   float* out0;         // sum | mean | s1
   float* out1;         // - | invstd | s2
   float* out2;         // - | unbiased var | -
   int rows, cols, ld;
   int mode, relu;
   float eps, keep_scale;
+  int nsplit;
 };
 
-// stage 1: grid (cols/64, EGN_COL_SPLITS); block = 64 columns x 4 row lanes over its
-// slice of the rows; partial sums (double) go to ws[split][2][cols]
-constexpr int EGN_COL_SPLITS = 32;
+constexpr int EGN_COL_MAX_SPLITS = 256;
 
 __global__ __launch_bounds__(256) void colreduce_partial_kernel(ColArgs p, double* __restrict__ ws) {
-  __shared__ double red0[4][65];
-  __shared__ double red1[4][65];
-  const int cl = threadIdx.x & 63;   // column within the block's 64
-  const int rl = threadIdx.x >> 6;   // row lane 0..3
-  const int c = blockIdx.x * 64 + cl;
-  const int rows_per = (p.rows + EGN_COL_SPLITS - 1) / EGN_COL_SPLITS;
+  __shared__ double red[2][256][4];
+  const int cg_total = p.ld / 4;
+  const int g0 = blockIdx.x * 64;
+  const int cgb = min(64, cg_total - g0);  // float4 column groups of this block
+  const int RL = 256 / cgb;                // row lanes
+  const int t = threadIdx.x;
+  const int rl = t / cgb, g = t - rl * cgb;
+  const int rows_per = (p.rows + p.nsplit - 1) / p.nsplit;
   const int r_lo = blockIdx.y * rows_per;
   const int r_hi = min(p.rows, r_lo + rows_per);
-  double s0 = 0.0, s1 = 0.0;
-  if (c < p.cols) {
-    float mean = 0.f, istd = 0.f, g = 0.f, b = 0.f;
-    if (p.mode == 2) { mean = p.mean[c]; istd = p.invstd[c]; g = p.gamma[c]; b = p.beta[c]; }
-    float f0 = 0.f, f1 = 0.f;
+  const int c0 = (g0 + g) * 4;
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (rl < RL) {
+    float mean[4], istd[4], gm[4], bt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const bool ok = p.mode == 2 && c0 + k < p.cols;
+      mean[k] = ok ? p.mean[c0 + k] : 0.f;
+      istd[k] = ok ? p.invstd[c0 + k] : 0.f;
+      gm[k] = ok ? p.gamma[c0 + k] : 0.f;
+      bt[k] = ok ? p.beta[c0 + k] : 0.f;
+    }
+    float f0[4] = {0, 0, 0, 0}, f1[4] = {0, 0, 0, 0};
     int cnt = 0;
-    for (int r = r_lo + rl; r < r_hi; r += 4) {
-      const size_t i = (size_t)r * p.ld + c;
-      const float v = p.a[i];
+    for (int r = r_lo + rl; r < r_hi; r += RL) {
+      const size_t i = (size_t)r * p.ld + c0;
+      const float4 v4 = *reinterpret_cast<const float4*>(p.a + i);
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
       if (p.mode == 0) {
-        f0 += v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f0[k] += v[k];
       } else if (p.mode == 1) {
-        f0 += v;
-        f1 += v * v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { f0[k] += v[k]; f1[k] += v[k] * v[k]; }
       } else {
-        const float xhat = (v - mean) * istd;
-        float d = p.dy[i];
-        if (p.mask) d *= p.mask[i] * p.keep_scale;
-        if (p.relu && !(g * xhat + b > 0.f)) d = 0.f;
-        f0 += d;
-        f1 += d * xhat;
+        const float4 d4 = *reinterpret_cast<const float4*>(p.dy + i);
+        float d[4] = {d4.x, d4.y, d4.z, d4.w};
+        if (p.mask) {
+          const float4 m4 = *reinterpret_cast<const float4*>(p.mask + i);
+          d[0] *= m4.x * p.keep_scale; d[1] *= m4.y * p.keep_scale;
+          d[2] *= m4.z * p.keep_scale; d[3] *= m4.w * p.keep_scale;
+        }
+        float rs[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.res) {
+          const float4 r4 = *reinterpret_cast<const float4*>(p.res + i);
+          rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float xhat = (v[k] - mean[k]) * istd[k];
+          float dd = d[k];
+          if (p.relu && !(gm[k] * xhat + bt[k] + rs[k] > 0.f)) dd = 0.f;
+          f0[k] += dd;
+          f1[k] += dd * xhat;
+        }
       }
       if (++cnt == 64) {  // flush the fp32 partials to double every 64 terms
-        s0 += f0; s1 += f1; f0 = 0.f; f1 = 0.f; cnt = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s0[k] += f0[k]; s1[k] += f1[k]; f0[k] = 0.f; f1[k] = 0.f; }
+        cnt = 0;
       }
     }
-    s0 += f0; s1 += f1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s0[k] += f0[k]; s1[k] += f1[k]; }
   }
-  red0[rl][cl] = s0;
-  red1[rl][cl] = s1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[0][t][k] = s0[k]; red[1][t][k] = s1[k]; }
   __syncthreads();
-  if (rl == 0 && c < p.cols) {
-    ws[((size_t)blockIdx.y * 2 + 0) * p.cols + c] = red0[0][cl] + red0[1][cl] + red0[2][cl] + red0[3][cl];
-    ws[((size_t)blockIdx.y * 2 + 1) * p.cols + c] = red1[0][cl] + red1[1][cl] + red1[2][cl] + red1[3][cl];
+  // thread (which, g, k) sums its column over the row lanes in lane order
+  if (t < cgb * 4) {
+    const int gg = t >> 2, k = t & 3;
+    const int c = (g0 + gg) * 4 + k;
+    if (c < p.cols) {
+      double a0 = 0.0, a1 = 0.0;
+      for (int l = 0; l < RL; ++l) { a0 += red[0][l * cgb + gg][k]; a1 += red[1][l * cgb + gg][k]; }
+      ws[((size_t)blockIdx.y * 2 + 0) * p.cols + c] = a0;
+      ws[((size_t)blockIdx.y * 2 + 1) * p.cols + c] = a1;
+    }
   }
 }
 
-// stage 2: one thread per column combines the EGN_COL_SPLITS partials and finalises
+// stage 2: one thread per column combines the partials and finalises
 __global__ __launch_bounds__(256) void colreduce_final_kernel(ColArgs p, const double* __restrict__ ws) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c < p.cols) {
     double t0 = 0.0, t1 = 0.0;
-    for (int k = 0; k < EGN_COL_SPLITS; ++k) {
+    for (int k = 0; k < p.nsplit; ++k) {
       t0 += ws[((size_t)k * 2 + 0) * p.cols + c];
       t1 += ws[((size_t)k * 2 + 1) * p.cols + c];
     }
@@ -178,7 +220,10 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(ColArgs p, const d
       if (var < 0) var = 0;
       p.out0[c] = (float)m;
       p.out1[c] = (float)(1.0 / sqrt(var + (double)p.eps));
-      if (p.out2) p.out2[c] = (float)(p.rows > 1 ? var * p.rows / (p.rows - 1) : var);
+      const float vu = (float)(p.rows > 1 ? var * p.rows / (p.rows - 1) : var);
+      if (p.out2) p.out2[c] = vu;
+      if (p.run_mean) p.run_mean[c] = (1.f - p.momentum) * p.run_mean[c] + p.momentum * (float)m;
+      if (p.run_var) p.run_var[c] = (1.f - p.momentum) * p.run_var[c] + p.momentum * vu;
     } else {
       p.out0[c] = (float)t0;
       p.out1[c] = (float)t1;
@@ -187,12 +232,21 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(ColArgs p, const d
 }
 
 // ws: caller-provided scratch of egn_colreduce_ws_bytes(cols) bytes
-extern "C" long egn_colreduce_ws_bytes(int cols) { return (long)EGN_COL_SPLITS * 2 * cols * (long)sizeof(double); }
+extern "C" long egn_colreduce_ws_bytes(int cols) {
+  return (long)EGN_COL_MAX_SPLITS * 2 * cols * (long)sizeof(double);
+}
 
-static int launch_col(const ColArgs& p, double* ws, void* stream) {
-  if (p.rows <= 0 || p.cols <= 0 || p.ld < p.cols || !ws) return EGN_E_BADARG;
-  hipLaunchKernelGGL(colreduce_partial_kernel, dim3((p.cols + 63) / 64, EGN_COL_SPLITS), dim3(256), 0,
-                     (hipStream_t)stream, p, ws);
+static int launch_col(ColArgs& p, double* ws, void* stream) {
+  if (p.rows <= 0 || p.cols <= 0 || p.ld < p.cols || p.ld % 4 || !ws) return EGN_E_BADARG;
+  const int cg = p.ld / 4;
+  const int gx = (cg + 63) / 64;
+  const int rl = 256 / (cg < 64 ? cg : 64);
+  int want = (512 + gx - 1) / gx;
+  int cap = p.rows / (2 * rl);
+  p.nsplit = want < cap ? want : cap;
+  if (p.nsplit > EGN_COL_MAX_SPLITS) p.nsplit = EGN_COL_MAX_SPLITS;
+  if (p.nsplit < 1) p.nsplit = 1;
+  hipLaunchKernelGGL(colreduce_partial_kernel, dim3(gx, p.nsplit), dim3(256), 0, (hipStream_t)stream, p, ws);
   hipLaunchKernelGGL(colreduce_final_kernel, dim3((p.cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, ws);
   return (int)hipGetLastError();
 }
@@ -204,9 +258,11 @@ extern "C" int egn_colsum_f32(const float* a, int rows, int cols, int ld, float*
 }
 
 extern "C" int egn_bn_stats_f32(const float* z, int rows, int cols, int ld, float eps, float* mean, float* invstd,
-                                float* var_unbiased, void* ws, void* stream) {
+                                float* var_unbiased, float* running_mean, float* running_var, float momentum,
+                                void* ws, void* stream) {
   ColArgs p = {};
   p.a = z; p.out0 = mean; p.out1 = invstd; p.out2 = var_unbiased;
+  p.run_mean = running_mean; p.run_var = running_var; p.momentum = momentum;
   p.rows = rows; p.cols = cols; p.ld = ld; p.mode = 1; p.eps = eps;
   return launch_col(p, (double*)ws, stream);
 }
@@ -220,7 +276,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
                                                          const float* __restrict__ mask, float keep_scale, int relu,
-                                                         float* __restrict__ y, int rows, int cols, int ld) {
+                                                         const float* __restrict__ res, float* __restrict__ y,
+                                                         int rows, int cols, int ld) {
   const int ld4 = ld / 4;
   const size_t total = (size_t)rows * ld4;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
@@ -231,12 +288,15 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
     if (mask) mk = reinterpret_cast<const float4*>(mask)[e];
     const float mka[4] = {mk.x, mk.y, mk.z, mk.w};
+    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (res) rv = reinterpret_cast<const float4*>(res)[e];
+    const float ra[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = c4 * 4 + k;
       float o = 0.f;
       if (c < cols) {
-        o = gamma[c] * ((in[k] - mean[c]) * invstd[c]) + beta[c];
+        o = gamma[c] * ((in[k] - mean[c]) * invstd[c]) + beta[c] + ra[k];
         if (relu) o = fmaxf(o, 0.f);
         if (mask) o *= mka[k] * keep_scale;
       }
@@ -247,20 +307,21 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 }
 
 extern "C" int egn_bn_act_fwd_f32(const float* z, const float* mean, const float* invstd, const float* gamma,
-                                  const float* beta, const float* mask, float keep_scale, int relu, float* y,
-                                  int rows, int cols, int ld, void* stream) {
+                                  const float* beta, const float* mask, float keep_scale, int relu,
+                                  const float* res, float* y, int rows, int cols, int ld, void* stream) {
   if (rows <= 0 || cols <= 0 || ld % 4 || ld < cols) return EGN_E_BADARG;
   const size_t total = (size_t)rows * (ld / 4);
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean,
-                     invstd, gamma, beta, mask, keep_scale, relu, y, rows, cols, ld);
+                     invstd, gamma, beta, mask, keep_scale, relu, res, y, rows, cols, ld);
   return (int)hipGetLastError();
 }
 
 extern "C" int egn_bn_bwd_sums_f32(const float* dy, const float* z, const float* mask, float keep_scale,
                                    const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                   int relu, int rows, int cols, int ld, float* dbeta, float* dgamma, void* ws,
-                                   void* stream) {
+                                   int relu, const float* res, int rows, int cols, int ld, float* dbeta,
+                                   float* dgamma, void* ws, void* stream) {
   ColArgs p = {};
+  p.res = res;
   p.a = z; p.dy = dy; p.mask = mask; p.keep_scale = keep_scale; p.mean = mean; p.invstd = invstd;
   p.gamma = gamma; p.beta = beta; p.relu = relu; p.out0 = dbeta; p.out1 = dgamma;
   p.rows = rows; p.cols = cols; p.ld = ld; p.mode = 2;
@@ -274,9 +335,10 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict_
                                                         const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int relu,
+                                                        const float* __restrict__ res,
                                                         const float* __restrict__ dbeta,
                                                         const float* __restrict__ dgamma, float* __restrict__ dz,
-                                                        int rows, int cols, int ld) {
+                                                        float* __restrict__ dres, int rows, int cols, int ld) {
   const int ld4 = ld / 4;
   const size_t total = (size_t)rows * ld4;
   const float inv_rows = 1.0f / (float)rows;
@@ -289,32 +351,37 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict_
     const float zi[4] = {zv.x, zv.y, zv.z, zv.w};
     const float di[4] = {dv.x, dv.y, dv.z, dv.w};
     const float mi[4] = {mk.x, mk.y, mk.z, mk.w};
-    float out[4];
+    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (res) rv = reinterpret_cast<const float4*>(res)[e];
+    const float ri[4] = {rv.x, rv.y, rv.z, rv.w};
+    float out[4], gated[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int c = c4 * 4 + k;
-      float o = 0.f;
+      float o = 0.f, d = 0.f;
       if (c < cols) {
         const float xhat = (zi[k] - mean[c]) * invstd[c];
-        float d = di[k];
+        d = di[k];
         if (mask) d *= mi[k] * keep_scale;
-        if (relu && !(gamma[c] * xhat + beta[c] > 0.f)) d = 0.f;
+        if (relu && !(gamma[c] * xhat + beta[c] + ri[k] > 0.f)) d = 0.f;
         o = gamma[c] * invstd[c] * (d - dbeta[c] * inv_rows - xhat * dgamma[c] * inv_rows);
       }
       out[k] = o;
+      gated[k] = d;
     }
     reinterpret_cast<float4*>(dz)[e] = make_float4(out[0], out[1], out[2], out[3]);
+    if (dres) reinterpret_cast<float4*>(dres)[e] = make_float4(gated[0], gated[1], gated[2], gated[3]);
   }
 }
 
 extern "C" int egn_bn_bwd_dz_f32(const float* dy, const float* z, const float* mask, float keep_scale,
                                  const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                 int relu, const float* dbeta, const float* dgamma, float* dz, int rows, int cols,
-                                 int ld, void* stream) {
+                                 int relu, const float* res, const float* dbeta, const float* dgamma, float* dz,
+                                 float* dres, int rows, int cols, int ld, void* stream) {
   if (rows <= 0 || cols <= 0 || ld % 4 || ld < cols) return EGN_E_BADARG;
   const size_t total = (size_t)rows * (ld / 4);
   hipLaunchKernelGGL(bn_bwd_dz_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, z, mask,
-                     keep_scale, mean, invstd, gamma, beta, relu, dbeta, dgamma, dz, rows, cols, ld);
+                     keep_scale, mean, invstd, gamma, beta, relu, res, dbeta, dgamma, dz, dres, rows, cols, ld);
   return (int)hipGetLastError();
 }
 
@@ -336,29 +403,35 @@ extern "C" int egn_add_f32(const float* a, const float* b, float* y, long n, voi
   return (int)hipGetLastError();
 }
 
-// loss[0] += sum((pred - tgt)^2) / (rows*cols)  (loss must be zeroed by the caller);
-// dpred = 2 (pred - tgt) / (rows*cols)   (MSELoss reduction='mean', function.py:204-215)
+// loss[0] += weight * sum((pred - tgt)^2) / (rows*cols)  (the caller zeroes loss);
+// dpred (=, or += with accumulate) weight * 2 (pred - tgt) / (rows*cols)
+// (MSELoss reduction='mean', function.py:204-215; weight 0.5 = the heat-map term :95-111)
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
-                                                  int rows, int cols, int ldp, int ldt, float* __restrict__ dpred,
+                                                  int rows, int cols, int ldp, int ldt, float weight,
+                                                  int accumulate, float* __restrict__ dpred,
                                                   double* __restrict__ loss) {
   const size_t total = (size_t)rows * cols;
-  const double inv = 1.0 / (double)total;
+  const double inv = (double)weight / (double)total;
   double acc = 0.0;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(e / cols), c = (int)(e % cols);
     const float d = pred[(size_t)r * ldp + c] - tgt[(size_t)r * ldt + c];
     acc += (double)d * d;
-    if (dpred) dpred[(size_t)r * ldp + c] = (float)(2.0 * d * inv);
+    if (dpred) {
+      const float gd = (float)(2.0 * d * inv);
+      float* q = dpred + (size_t)r * ldp + c;
+      *q = accumulate ? *q + gd : gd;
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
   if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv);
 }
 extern "C" int egn_mse_f32(const float* pred, const float* tgt, int rows, int cols, int ld_pred, int ld_tgt,
-                           float* dpred, double* loss, void* stream) {
+                           float weight, int accumulate, float* dpred, double* loss, void* stream) {
   if (rows <= 0 || cols <= 0 || ld_pred < cols || ld_tgt < cols) return EGN_E_BADARG;
   hipLaunchKernelGGL(mse_kernel, dim3(grid_for((size_t)rows * cols, 256) > 256 ? 256 : grid_for((size_t)rows * cols, 256)),
-                     dim3(256), 0, (hipStream_t)stream, pred, tgt, rows, cols, ld_pred, ld_tgt, dpred, loss);
+                     dim3(256), 0, (hipStream_t)stream, pred, tgt, rows, cols, ld_pred, ld_tgt, weight, accumulate, dpred, loss);
   return (int)hipGetLastError();
 }
 
@@ -396,5 +469,168 @@ extern "C" int egn_adam_step_f32(float* p, const float* g, float* m, float* v, l
   const double bc2_sqrt = sqrt(1.0 - pow((double)beta2, (double)step));
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
                      (size_t)n, lr, beta1, beta2, eps, (float)bc1, (float)bc2_sqrt);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Convolution training support
+// ---------------------------------------------------------------------------
+// torch conv weight [Cout][Cin][KH][KW] -> the conv kernel's packed layout
+// [chunk][tap][quad][CoP][4] (input channel = chunk*16 + quad*4 + r), on the
+// device, every step (the weights change).
+//   dgrad == 0: the forward filter:   out channel = co, in channel = ci, tap
+//   dgrad == 1: the data-gradient filter (autograd's conv_transpose view):
+//               out channel = ci, in channel = co, tap rotated by 180 degrees,
+//               so  dx = conv(dy [zero-inserted for stride 2], packed, stride 1, pad K-1-p)
+__global__ __launch_bounds__(256) void pack_conv_weight_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                                               int taps, int dgrad, float4* __restrict__ dst,
+                                                               int CoP, int nchunk) {
+  const size_t total = (size_t)nchunk * taps * 4 * CoP;
+  const int n_out = dgrad ? Cin : Cout;
+  const int n_in = dgrad ? Cout : Cin;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int o = (int)(e % CoP);
+    size_t r_ = e / CoP;
+    const int quad = (int)(r_ % 4);
+    r_ /= 4;
+    const int tap = (int)(r_ % taps);
+    const int chunk = (int)(r_ / taps);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (o < n_out) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = chunk * EGN_CK + quad * 4 + r;
+        if (i < n_in)
+          v[r] = dgrad ? w[((size_t)i * Cin + o) * taps + (taps - 1 - tap)] : w[((size_t)o * Cin + i) * taps + tap];
+      }
+    }
+    dst[e] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+extern "C" long egn_packed_weight_floats(int Cout, int Cin, int KH, int KW, int dgrad) {
+  const int n_out = dgrad ? Cin : Cout, n_in = dgrad ? Cout : Cin;
+  if (n_out <= 0 || n_in <= 0 || KH <= 0 || KW <= 0) return -1;
+  return (long)((n_in + EGN_CK - 1) / EGN_CK) * KH * KW * 4 * ((n_out + 15) & ~15) * 4;
+}
+
+extern "C" int egn_pack_conv_weight_f32(const float* w, int Cout, int Cin, int KH, int KW, int dgrad, float* dst,
+                                        void* stream) {
+  if (!w || !dst || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return EGN_E_BADARG;
+  const int n_out = dgrad ? Cin : Cout, n_in = dgrad ? Cout : Cin;
+  const int CoP = (n_out + 15) & ~15;
+  const int nchunk = (n_in + EGN_CK - 1) / EGN_CK;
+  const size_t total = (size_t)nchunk * KH * KW * 4 * CoP;
+  hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, w, Cout,
+                     Cin, KH * KW, dgrad, reinterpret_cast<float4*>(dst), CoP, nchunk);
+  return (int)hipGetLastError();
+}
+
+// up[n][2y][2x][:] = dy[n][y][x][:], everything else zero (data gradient of a
+// stride-2 convolution = stride-1 convolution over the zero-inserted dy)
+__global__ __launch_bounds__(256) void zero_insert2_kernel(const float4* __restrict__ dy, float4* __restrict__ up,
+                                                           int N, int Ho, int Wo, int H, int W, int cs4) {
+  const size_t total = (size_t)N * H * W * cs4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % cs4);
+    size_t p = e / cs4;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const int n = (int)(p / H);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!(x & 1) && !(y & 1) && (y >> 1) < Ho && (x >> 1) < Wo)
+      v = dy[(((size_t)n * Ho + (y >> 1)) * Wo + (x >> 1)) * cs4 + c4];
+    up[e] = v;
+  }
+}
+extern "C" int egn_zero_insert2_f32(const float* dy, float* up, int N, int Ho, int Wo, int H, int W, int cs,
+                                    void* stream) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || H < 2 * Ho - 1 || W < 2 * Wo - 1 || cs % 4 || cs <= 0) return EGN_E_BADARG;
+  const size_t total = (size_t)N * H * W * (cs / 4);
+  hipLaunchKernelGGL(zero_insert2_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(dy), reinterpret_cast<float4*>(up), N, Ho, Wo, H, W, cs / 4);
+  return (int)hipGetLastError();
+}
+
+// backward of one term of the multi-resolution fuse y = relu(sum_j up_j(t_j))
+// (hrnet.py:282-300): g[n][h][w][:] = sum over the 2^s x 2^s block of dy * (y > 0)
+// (s = 0: the ReLU gate only; y == NULL: no gate)
+__global__ __launch_bounds__(256) void fuse_bwd_kernel(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                       float4* __restrict__ g, int N, int H, int W, int cs4, int s) {
+  const int hs = H >> s, ws = W >> s, k = 1 << s;
+  const size_t total = (size_t)N * hs * ws * cs4;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(e % cs4);
+    size_t p = e / cs4;
+    const int x = (int)(p % ws);
+    p /= ws;
+    const int yy = (int)(p % hs);
+    const int n = (int)(p / hs);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int dy_ = 0; dy_ < k; ++dy_)
+      for (int dx_ = 0; dx_ < k; ++dx_) {
+        const size_t i = (((size_t)n * H + (yy * k + dy_)) * W + (x * k + dx_)) * cs4 + c4;
+        float4 d = dy[i];
+        if (y) {
+          const float4 o = y[i];
+          if (!(o.x > 0.f)) d.x = 0.f;
+          if (!(o.y > 0.f)) d.y = 0.f;
+          if (!(o.z > 0.f)) d.z = 0.f;
+          if (!(o.w > 0.f)) d.w = 0.f;
+        }
+        acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+      }
+    g[e] = acc;
+  }
+}
+extern "C" int egn_fuse_bwd_f32(const float* dy, const float* y, float* g, int N, int H, int W, int cs, int shift,
+                                void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || cs % 4 || cs <= 0 || shift < 0 || shift > 5 || (H >> shift) << shift != H ||
+      (W >> shift) << shift != W)
+    return EGN_E_BADARG;
+  const size_t total = (size_t)N * (H >> shift) * (W >> shift) * (cs / 4);
+  hipLaunchKernelGGL(fuse_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(dy), reinterpret_cast<const float4*>(y),
+                     reinterpret_cast<float4*>(g), N, H, W, cs / 4, shift);
+  return (int)hipGetLastError();
+}
+
+// dz = dy * y * (1 - y)   (backward of the Sigmoid that ends the coordinate head, hrnet.py:461-466)
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          float* __restrict__ dz, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float o = y[e];
+    dz[e] = dy[e] * o * (1.f - o);
+  }
+}
+extern "C" int egn_sigmoid_bwd_f32(const float* dy, const float* y, float* dz, long n, void* stream) {
+  if (n <= 0) return EGN_E_BADARG;
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, dy, y, dz,
+                     (size_t)n);
+  return (int)hipGetLastError();
+}
+
+// loss[0] += weight * mean(|pred - tgt|);  dpred = weight * sign(pred - tgt) / n
+// (nn.L1Loss(reduction='mean'), the coordinate term of JointsCompositeLoss, function.py:155-168)
+__global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, size_t n,
+                                                 float weight, float* __restrict__ dpred, double* __restrict__ loss) {
+  const double inv = (double)weight / (double)n;
+  double acc = 0.0;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float d = pred[e] - tgt[e];
+    acc += fabs((double)d);
+    if (dpred) dpred[e] = (float)(d > 0.f ? inv : (d < 0.f ? -inv : 0.0));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv);
+}
+extern "C" int egn_l1_f32(const float* pred, const float* tgt, long n, float weight, float* dpred, double* loss,
+                          void* stream) {
+  if (n <= 0 || !loss) return EGN_E_BADARG;
+  int g = grid_for((size_t)n, 256);
+  if (g > 256) g = 256;
+  hipLaunchKernelGGL(l1_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, pred, tgt, (size_t)n, weight, dpred, loss);
   return (int)hipGetLastError();
 }

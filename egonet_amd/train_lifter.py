@@ -142,19 +142,17 @@ class LifterTrainStep(object):
                 mean = self._buf('mean%d' % ui, u.outf)
                 istd = self._buf('istd%d' % ui, u.outf)
                 varu = self._buf('varu%d' % ui, u.outf)
-                _lib.check(L.egn_bn_stats_f32(_lib.ptr(z), B, u.outf, u.outf, u.bn.eps, _lib.ptr(mean), _lib.ptr(istd),
-                                              _lib.ptr(varu), _lib.ptr(ws), st), 'bn_stats')
                 mom = u.bn.momentum if u.bn.momentum is not None else 0.1
-                _lib.check(L.egn_ema_f32(_lib.ptr(u.bn.running_mean), _lib.ptr(mean), mom, u.outf, st))
-                _lib.check(L.egn_ema_f32(_lib.ptr(u.bn.running_var), _lib.ptr(varu), mom, u.outf, st))
-                u.bn.num_batches_tracked += 1
+                _lib.check(L.egn_bn_stats_f32(_lib.ptr(z), B, u.outf, u.outf, u.bn.eps, _lib.ptr(mean), _lib.ptr(istd),
+                                              _lib.ptr(varu), _lib.ptr(u.bn.running_mean),
+                                              _lib.ptr(u.bn.running_var), mom, _lib.ptr(ws), st), 'bn_stats')
                 mask = None
                 if self.p > 0:
                     mask = self._buf('mask%d' % ui, B, u.outf)
                     mask.copy_((torch.rand(B, u.outf, device=dev) >= self.p).float())
                 y = self._buf('y%d' % ui, B, u.outf)
                 _lib.check(L.egn_bn_act_fwd_f32(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(u.bn.weight),
-                                                _lib.ptr(u.bn.bias), _lib.ptr(mask), keep, 1, _lib.ptr(y), B,
+                                                _lib.ptr(u.bn.bias), _lib.ptr(mask), keep, 1, None, _lib.ptr(y), B,
                                                 u.outf, u.outf, st), 'bn_act_fwd')
                 saved.append((a, ld_a, z, mean, istd, mask))
                 if ui == 0:
@@ -168,6 +166,7 @@ class LifterTrainStep(object):
                     block_in = out
                     a = out
                 ld_a = u.outf
+            torch._foreach_add_([u.bn.num_batches_tracked for u in self.units], 1)
             feat = a
             nf = self.final.in_features
             no = self.final.out_features
@@ -176,7 +175,7 @@ class LifterTrainStep(object):
             # loss + gradient of the prediction
             self.loss_dev.zero_()
             dpred = self._buf('dpred', B, no)
-            _lib.check(L.egn_mse_f32(_lib.ptr(pred), _lib.ptr(target), B, no, no, no, _lib.ptr(dpred),
+            _lib.check(L.egn_mse_f32(_lib.ptr(pred), _lib.ptr(target), B, no, no, no, 1.0, 0, _lib.ptr(dpred),
                                      _lib.ptr(self.loss_dev), st), 'mse')
 
             # ---- backward ----
@@ -194,14 +193,14 @@ class LifterTrainStep(object):
                     d_y = d_block_out     # unit 0 and the second unit of a block see the block-output gradient
                 dbeta, dgamma = g[id(u.bn.bias)], g[id(u.bn.weight)]
                 _lib.check(L.egn_bn_bwd_sums_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
-                                                 _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), 1, B,
-                                                 u.outf, u.outf, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(ws), st),
-                           'bn_bwd_sums')
+                                                 _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), 1, None,
+                                                 B, u.outf, u.outf, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(ws),
+                                                 st), 'bn_bwd_sums')
                 dz = self._buf('dz', B, u.outf)
                 _lib.check(L.egn_bn_bwd_dz_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
-                                               _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), 1,
-                                               _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(dz), B, u.outf, u.outf, st),
-                           'bn_bwd_dz')
+                                               _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), 1, None,
+                                               _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(dz), None, B, u.outf,
+                                               u.outf, st), 'bn_bwd_dz')
                 self._wgrad(a_in, ld_in, u.inf, dz, u.outf, u.outf, B, g[id(u.fc.weight)])
                 _lib.check(L.egn_colsum_f32(_lib.ptr(dz), B, u.outf, u.outf, _lib.ptr(g[id(u.fc.bias)]), _lib.ptr(ws), st))
                 if ui == 0:

@@ -178,32 +178,66 @@ int egn_transpose_f32(const float* src, int R, int C, int ld_src, float* dst,
 long egn_colreduce_ws_bytes(int cols);
 int egn_colsum_f32(const float* a, int rows, int cols, int ld, float* sum,
                    void* ws, void* stream);
-/* per-column batch statistics: mean, 1/sqrt(biased var + eps), unbiased var */
+/* per-column batch statistics of z [rows, ld] (NHWC conv output: rows = N*H*W,
+ * ld = cs): mean, 1/sqrt(biased var + eps), unbiased var; when running_mean /
+ * running_var are given they are updated in place with torch's rule
+ * running = (1-momentum)*running + momentum*batch (unbiased var) */
 int egn_bn_stats_f32(const float* z, int rows, int cols, int ld, float eps,
-                     float* mean, float* invstd, float* var_unbiased, void* ws,
-                     void* stream);
-/* y = relu?(gamma*(z-mean)*invstd + beta) * (mask ? mask*keep_scale : 1) */
+                     float* mean, float* invstd, float* var_unbiased,
+                     float* running_mean, float* running_var, float momentum,
+                     void* ws, void* stream);
+/* y = relu?(gamma*(z-mean)*invstd + beta + res?) * (mask ? mask*keep_scale : 1)
+ * (BatchNorm on batch statistics + residual + ReLU + inverted dropout) */
 int egn_bn_act_fwd_f32(const float* z, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, const float* mask,
-                       float keep_scale, int relu, float* y, int rows, int cols,
-                       int ld, void* stream);
+                       float keep_scale, int relu, const float* res, float* y,
+                       int rows, int cols, int ld, void* stream);
 /* BatchNorm backward, step 1: dbeta = sum dpre, dgamma = sum dpre*xhat with
- * dpre = dy * dropout-mask * relu-mask */
+ * dpre = dy * dropout-mask * relu-gate(gamma*xhat + beta + res > 0) */
 int egn_bn_bwd_sums_f32(const float* dy, const float* z, const float* mask,
                         float keep_scale, const float* mean, const float* invstd,
-                        const float* gamma, const float* beta, int relu, int rows,
-                        int cols, int ld, float* dbeta, float* dgamma, void* ws,
-                        void* stream);
-/* step 2: dz = gamma*invstd*(dpre - dbeta/rows - xhat*dgamma/rows) */
+                        const float* gamma, const float* beta, int relu,
+                        const float* res, int rows, int cols, int ld,
+                        float* dbeta, float* dgamma, void* ws, void* stream);
+/* step 2: dz = gamma*invstd*(dpre - dbeta/rows - xhat*dgamma/rows); dres
+ * (optional) = dpre, the gradient that flows into the residual branch */
 int egn_bn_bwd_dz_f32(const float* dy, const float* z, const float* mask,
                       float keep_scale, const float* mean, const float* invstd,
                       const float* gamma, const float* beta, int relu,
-                      const float* dbeta, const float* dgamma, float* dz, int rows,
-                      int cols, int ld, void* stream);
+                      const float* res, const float* dbeta, const float* dgamma,
+                      float* dz, float* dres, int rows, int cols, int ld,
+                      void* stream);
 int egn_add_f32(const float* a, const float* b, float* y, long n, void* stream);
-/* *loss += mean((pred-tgt)^2) (zero it first); dpred = 2(pred-tgt)/(rows*cols) */
+/* *loss += weight*mean((pred-tgt)^2) (zero it first);
+ * dpred (= or, with accumulate, +=) weight*2(pred-tgt)/(rows*cols).
+ * weight 0.5 over all joints = the heat-map term of JointsCompositeLoss
+ * (function.py:95-111), weight 1 = MSELoss1D (function.py:204-215) */
 int egn_mse_f32(const float* pred, const float* tgt, int rows, int cols,
-                int ld_pred, int ld_tgt, float* dpred, double* loss, void* stream);
+                int ld_pred, int ld_tgt, float weight, int accumulate,
+                float* dpred, double* loss, void* stream);
+/* *loss += weight*mean(|pred-tgt|); dpred = weight*sign(pred-tgt)/n
+ * (nn.L1Loss, the coordinate term, function.py:155-168) */
+int egn_l1_f32(const float* pred, const float* tgt, long n, float weight,
+               float* dpred, double* loss, void* stream);
+/* dz = dy*y*(1-y): backward of the coordinate head's Sigmoid (hrnet.py:461-466) */
+int egn_sigmoid_bwd_f32(const float* dy, const float* y, float* dz, long n,
+                        void* stream);
+/* torch conv weight [Cout][Cin][KH][KW] -> packed filter of egn_conv2d_f32, on
+ * the device.  dgrad 0: the forward filter.  dgrad 1: the data-gradient
+ * filter (in/out channels swapped, taps rotated by 180 degrees), so that
+ *   dx = egn_conv2d_f32(dy [zero-inserted when stride 2], packed, Cin' = Cout,
+ *                       Cout' = Cin, stride 1, pad K-1-pad)
+ * egn_packed_weight_floats = number of floats dst must hold. */
+long egn_packed_weight_floats(int Cout, int Cin, int KH, int KW, int dgrad);
+int egn_pack_conv_weight_f32(const float* w, int Cout, int Cin, int KH, int KW,
+                             int dgrad, float* dst, void* stream);
+/* up[n][2y][2x][:] = dy[n][y][x][:], zero elsewhere; up is [N,H,W,cs] */
+int egn_zero_insert2_f32(const float* dy, float* up, int N, int Ho, int Wo,
+                         int H, int W, int cs, void* stream);
+/* backward of one term of egn_fuse_sum_relu_f32: g [N,H>>shift,W>>shift,cs] =
+ * block sums of dy*(y>0) (y NULL: no gate) */
+int egn_fuse_bwd_f32(const float* dy, const float* y, float* g, int N, int H,
+                     int W, int cs, int shift, void* stream);
 /* running = (1-momentum)*running + momentum*batch */
 int egn_ema_f32(float* running, const float* batch, float momentum, int n,
                 void* stream);

@@ -65,57 +65,74 @@ def test_column_reductions(rows, cols):
     zd = z.cpu().double()
     np.testing.assert_allclose(s.cpu().numpy(), zd.sum(0).numpy(), rtol=1e-6, atol=1e-5)
     mean, istd, varu = (torch.zeros(cols, device='cuda') for _ in range(3))
+    rm, rv = torch.full((cols,), 0.3, device='cuda'), torch.full((cols,), 2.0, device='cuda')
     _lib.check(L.egn_bn_stats_f32(_lib.ptr(z), rows, cols, cols, 1e-5, _lib.ptr(mean), _lib.ptr(istd),
-                                  _lib.ptr(varu), _lib.ptr(ws), _st()))
+                                  _lib.ptr(varu), _lib.ptr(rm), _lib.ptr(rv), 0.1, _lib.ptr(ws), _st()))
+    np.testing.assert_allclose(rm.cpu().numpy(), 0.9 * 0.3 + 0.1 * zd.mean(0).numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(rv.cpu().numpy(), 0.9 * 2.0 + 0.1 * zd.var(0, unbiased=True).numpy(), rtol=2e-6)
     np.testing.assert_allclose(mean.cpu().numpy(), zd.mean(0).numpy(), rtol=0, atol=1e-6)
     np.testing.assert_allclose(istd.cpu().numpy(), (zd.var(0, unbiased=False) + 1e-5).rsqrt().numpy(), rtol=2e-6)
     np.testing.assert_allclose(varu.cpu().numpy(), zd.var(0, unbiased=True).numpy(), rtol=2e-6)
 
 
-@pytest.mark.parametrize('rows,cols,p', [(16, 128, 0.0), (64, 100, 0.5), (512, 1024, 0.5)])
-def test_bn_relu_dropout_forward_backward(rows, cols, p):
+@pytest.mark.parametrize('rows,cols,p,with_res,relu', [
+    (16, 128, 0.0, False, 1), (64, 100, 0.5, False, 1), (512, 1024, 0.5, False, 1),
+    (2 * 16 * 16, 48, 0.0, True, 1),      # BasicBlock tail: relu(bn2(conv2) + residual)
+    (2 * 8 * 8, 96, 0.0, False, 0),       # fuse-layer BatchNorm without ReLU
+    (9000, 36, 0.0, True, 1),             # many rows, few columns (NHWC maps)
+])
+def test_bn_relu_dropout_forward_backward(rows, cols, p, with_res, relu):
     """bn_act_fwd / bn_bwd_sums / bn_bwd_dz against autograd through
-    batch_norm(training) -> relu -> mask."""
+    batch_norm(training) (+ residual) -> relu -> mask."""
     L = _lib.lib()
     g = torch.Generator().manual_seed(cols)
     z = torch.randn(rows, cols, generator=g) * 1.5 + 0.2
     gamma = torch.rand(cols, generator=g) + 0.5
     beta = torch.randn(cols, generator=g) * 0.3
     dy = torch.randn(rows, cols, generator=g)
+    res = torch.randn(rows, cols, generator=g) if with_res else None
     mask = (torch.rand(rows, cols, generator=g) >= p).float() if p > 0 else None
     keep = 1.0 / (1.0 - p) if p > 0 else 1.0
     # torch (float64 autograd)
     zz, gg, bb = (t.double().requires_grad_(True) for t in (z, gamma, beta))
+    rr = res.double().requires_grad_(True) if with_res else None
     pre = torch.nn.functional.batch_norm(zz, None, None, gg, bb, True, 0.1, 1e-5)
-    y = torch.relu(pre)
+    if with_res:
+        pre = pre + rr
+    y = torch.relu(pre) if relu else pre
     if mask is not None:
         y = y * mask.double() * keep
     y.backward(dy.double())
     # native
     zd, gd, bd, dyd = z.cuda(), gamma.cuda(), beta.cuda(), dy.cuda()
     md = mask.cuda() if mask is not None else None
+    rd = res.cuda() if with_res else None
     ws = _ws(cols)
     mean, istd, varu, dbeta, dgamma = (torch.zeros(cols, device='cuda') for _ in range(5))
     _lib.check(L.egn_bn_stats_f32(_lib.ptr(zd), rows, cols, cols, 1e-5, _lib.ptr(mean), _lib.ptr(istd),
-                                  _lib.ptr(varu), _lib.ptr(ws), _st()))
+                                  _lib.ptr(varu), None, None, 0.0, _lib.ptr(ws), _st()))
     yd = torch.zeros(rows, cols, device='cuda')
     _lib.check(L.egn_bn_act_fwd_f32(_lib.ptr(zd), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(gd), _lib.ptr(bd),
-                                    _lib.ptr(md), keep, 1, _lib.ptr(yd), rows, cols, cols, _st()))
+                                    _lib.ptr(md), keep, relu, _lib.ptr(rd), _lib.ptr(yd), rows, cols, cols, _st()))
     np.testing.assert_allclose(yd.cpu().numpy(), y.detach().numpy(), rtol=0, atol=2e-5)
     _lib.check(L.egn_bn_bwd_sums_f32(_lib.ptr(dyd), _lib.ptr(zd), _lib.ptr(md), keep, _lib.ptr(mean), _lib.ptr(istd),
-                                     _lib.ptr(gd), _lib.ptr(bd), 1, rows, cols, cols, _lib.ptr(dbeta),
-                                     _lib.ptr(dgamma), _lib.ptr(ws), _st()))
+                                     _lib.ptr(gd), _lib.ptr(bd), relu, _lib.ptr(rd), rows, cols, cols,
+                                     _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(ws), _st()))
     dz = torch.zeros(rows, cols, device='cuda')
+    dres = torch.zeros(rows, cols, device='cuda') if with_res else None
     _lib.check(L.egn_bn_bwd_dz_f32(_lib.ptr(dyd), _lib.ptr(zd), _lib.ptr(md), keep, _lib.ptr(mean), _lib.ptr(istd),
-                                   _lib.ptr(gd), _lib.ptr(bd), 1, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(dz),
-                                   rows, cols, cols, _st()))
+                                   _lib.ptr(gd), _lib.ptr(bd), relu, _lib.ptr(rd), _lib.ptr(dbeta), _lib.ptr(dgamma),
+                                   _lib.ptr(dz), _lib.ptr(dres), rows, cols, cols, _st()))
     # an element whose pre-activation is within rounding of 0 may flip its ReLU
     # gate between fp32 and fp64; exclude columns that hold one
     safe = (pre.detach().abs() > 1e-5).all(0).numpy()
-    assert safe.mean() > 0.9
-    np.testing.assert_allclose(dbeta.cpu().numpy()[safe], bb.grad.numpy()[safe], rtol=1e-5, atol=1e-4)
-    np.testing.assert_allclose(dgamma.cpu().numpy()[safe], gg.grad.numpy()[safe], rtol=1e-5, atol=1e-4)
+    assert safe.mean() > 0.8
+    tol = 1e-4 * max(1.0, (rows / 512.0) ** 0.5)
+    np.testing.assert_allclose(dbeta.cpu().numpy()[safe], bb.grad.numpy()[safe], rtol=1e-5, atol=tol)
+    np.testing.assert_allclose(dgamma.cpu().numpy()[safe], gg.grad.numpy()[safe], rtol=1e-5, atol=tol)
     np.testing.assert_allclose(dz.cpu().numpy()[:, safe], zz.grad.numpy()[:, safe], rtol=0, atol=1e-4)
+    if with_res:
+        np.testing.assert_allclose(dres.cpu().numpy()[:, safe], rr.grad.numpy()[:, safe], rtol=0, atol=1e-6)
 
 
 def test_mse_loss_and_gradient():
@@ -125,10 +142,16 @@ def test_mse_loss_and_gradient():
     pd, td = pred.cuda(), tgt.cuda()
     dp = torch.zeros_like(pd)
     loss = torch.zeros(1, dtype=torch.float64, device='cuda')
-    _lib.check(L.egn_mse_f32(_lib.ptr(pd), _lib.ptr(td), 300, 96, 96, 96, _lib.ptr(dp), _lib.ptr(loss), _st()))
+    _lib.check(L.egn_mse_f32(_lib.ptr(pd), _lib.ptr(td), 300, 96, 96, 96, 1.0, 0, _lib.ptr(dp), _lib.ptr(loss), _st()))
     pp = pred.double().requires_grad_(True)
     want = torch.nn.functional.mse_loss(pp, tgt.double())
     want.backward()
+    # weight 0.5 + accumulate on top of an existing gradient (heat-map term)
+    acc = torch.ones_like(pd)
+    loss2 = torch.zeros(1, dtype=torch.float64, device='cuda')
+    _lib.check(L.egn_mse_f32(_lib.ptr(pd), _lib.ptr(td), 300, 96, 96, 96, 0.5, 1, _lib.ptr(acc), _lib.ptr(loss2), _st()))
+    np.testing.assert_allclose(acc.cpu().numpy(), 1.0 + 0.5 * pp.grad.numpy(), rtol=1e-6, atol=1e-7)
+    assert abs(float(loss2.item()) - 0.5 * float(want.detach())) < 1e-9
     assert abs(float(loss.item()) - float(want)) < 1e-9
     np.testing.assert_allclose(dp.cpu().numpy(), pp.grad.numpy(), rtol=1e-6, atol=1e-10)
 
@@ -207,6 +230,97 @@ def test_conv_wgrad(n, cin, cout, h, w, k, stride, pad):
     _lib.check(L.egn_conv2d_wgrad_f32(_lib.ptr(xd), _lib.ptr(dyd), _lib.ptr(dw2), n, h, w, cin, cs_in, cout, cs_out,
                                       k, k, stride, pad, _lib.ptr(ws), need, _st()))
     assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,k,stride,pad', [
+    (2, 48, 48, 12, 20, 3, 1, 1),
+    (2, 96, 200, 16, 16, 3, 1, 1),
+    (2, 48, 96, 16, 16, 3, 2, 1),        # strided: zero-insert + stride-1 conv
+    (3, 96, 48, 8, 8, 1, 1, 0),
+    (2, 35, 66, 8, 8, 1, 2, 0),          # 1x1 stride 2
+    (6, 66, 66, 4, 4, 4, 1, 0),          # 4x4 valid -> "full" correlation, pad 3
+    (64, 1024, 96, 1, 1, 1, 1, 0),       # Linear
+])
+def test_conv_forward_and_dgrad_with_device_packed_weights(n, cin, cout, h, w, k, stride, pad):
+    """egn_pack_conv_weight_f32 (forward and data-gradient filters) + egn_conv2d_f32
+    (+ egn_zero_insert2_f32) against F.conv2d and its autograd input gradient."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) * 0.1
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    dy = torch.randn(n, cout, ho, wo, generator=g)
+    xx = x.double().requires_grad_(True)
+    yy = torch.nn.functional.conv2d(xx, wt.double(), None, stride, pad)
+    yy.backward(dy.double())
+    cs_in, cs_out = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
+    wd = wt.cuda()
+    one = torch.ones(max(cin, cout) + 16, device='cuda')
+    zero = torch.zeros(max(cin, cout) + 16, device='cuda')
+    # forward
+    wp = torch.zeros(L.egn_packed_weight_floats(cout, cin, k, k, 0), device='cuda')
+    _lib.check(L.egn_pack_conv_weight_f32(_lib.ptr(wd), cout, cin, k, k, 0, _lib.ptr(wp), _st()))
+    xd = _nhwc(x, cs_in).cuda()
+    yd = torch.full((n, ho, wo, cs_out), 5.0, device='cuda')
+    _lib.check(L.egn_conv2d_f32(_lib.ptr(xd), _lib.ptr(wp), _lib.ptr(one), _lib.ptr(zero), None, _lib.ptr(yd),
+                                n, h, w, cin, cs_in, cout, cs_out, k, k, stride, pad, 0, 0, 0, _st()))
+    got = yd.cpu()[..., :cout].permute(0, 3, 1, 2)
+    np.testing.assert_allclose(got.numpy(), yy.detach().numpy(), rtol=0, atol=2e-5 * float(yy.abs().max()))
+    assert float(yd.cpu()[..., cout:].abs().max() if cs_out > cout else 0.0) == 0.0
+    # data gradient
+    wq = torch.zeros(L.egn_packed_weight_floats(cout, cin, k, k, 1), device='cuda')
+    _lib.check(L.egn_pack_conv_weight_f32(_lib.ptr(wd), cout, cin, k, k, 1, _lib.ptr(wq), _st()))
+    dyd = _nhwc(dy, cs_out).cuda()
+    if stride == 2:
+        up = torch.full((n, h, w, cs_out), 9.0, device='cuda')
+        _lib.check(L.egn_zero_insert2_f32(_lib.ptr(dyd), _lib.ptr(up), n, ho, wo, h, w, cs_out, _st()))
+        src, sh, sw = up, h, w
+    else:
+        src, sh, sw = dyd, ho, wo
+    dxd = torch.full((n, h, w, cs_in), 5.0, device='cuda')
+    _lib.check(L.egn_conv2d_f32(_lib.ptr(src), _lib.ptr(wq), _lib.ptr(one), _lib.ptr(zero), None, _lib.ptr(dxd),
+                                n, sh, sw, cout, cs_out, cin, cs_in, k, k, 1, k - 1 - pad, 0, 0, 0, _st()))
+    got = dxd.cpu()[..., :cin].permute(0, 3, 1, 2)
+    np.testing.assert_allclose(got.numpy(), xx.grad.numpy(), rtol=0, atol=2e-5 * float(xx.grad.abs().max()))
+
+
+def test_fuse_backward_terms():
+    """y = relu(t0 + up2(t1) + up4(t2)): per-term gradients = gated block sums."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(8)
+    n, hh, ww, c = 2, 16, 8, 48
+    ts = [torch.randn(n, c, hh >> s, ww >> s, generator=g, dtype=torch.float64, requires_grad=True) for s in (0, 1, 2)]
+    y = torch.relu(ts[0] + torch.nn.functional.interpolate(ts[1], scale_factor=2, mode='nearest')
+                   + torch.nn.functional.interpolate(ts[2], scale_factor=4, mode='nearest'))
+    dy = torch.randn(n, c, hh, ww, generator=g)
+    y.backward(dy.double())
+    yd, dyd = _nhwc(y.detach().float(), c).cuda(), _nhwc(dy, c).cuda()
+    for s in (0, 1, 2):
+        out = torch.full((n, hh >> s, ww >> s, c), 4.0, device='cuda')
+        _lib.check(L.egn_fuse_bwd_f32(_lib.ptr(dyd), _lib.ptr(yd), _lib.ptr(out), n, hh, ww, c, s, _st()))
+        np.testing.assert_allclose(out.cpu().permute(0, 3, 1, 2).numpy(), ts[s].grad.numpy(), rtol=0, atol=1e-5)
+    out = torch.zeros(n, hh >> 1, ww >> 1, c, device='cuda')
+    _lib.check(L.egn_fuse_bwd_f32(_lib.ptr(dyd), None, _lib.ptr(out), n, hh, ww, c, 1, _st()))      # no gate
+    want = torch.nn.functional.avg_pool2d(dy, 2) * 4
+    np.testing.assert_allclose(out.cpu().permute(0, 3, 1, 2).numpy(), want.numpy(), rtol=0, atol=1e-5)
+
+
+def test_sigmoid_backward_and_l1_loss():
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(40, 66, generator=g, dtype=torch.float64, requires_grad=True)
+    tgt = torch.rand(40, 66, generator=g)
+    y = torch.sigmoid(z)
+    loss = 0.1 * torch.nn.functional.l1_loss(y, tgt.double())
+    loss.backward()
+    yd, td = y.detach().float().cuda(), tgt.cuda()
+    dyd = torch.zeros_like(yd)
+    ld = torch.zeros(1, dtype=torch.float64, device='cuda')
+    _lib.check(L.egn_l1_f32(_lib.ptr(yd), _lib.ptr(td), yd.numel(), 0.1, _lib.ptr(dyd), _lib.ptr(ld), _st()))
+    assert abs(float(ld.item()) - float(loss.detach())) < 1e-7
+    dz = torch.zeros_like(yd)
+    _lib.check(L.egn_sigmoid_bwd_f32(_lib.ptr(dyd), _lib.ptr(yd), _lib.ptr(dz), yd.numel(), _st()))
+    np.testing.assert_allclose(dz.cpu().numpy(), z.grad.numpy(), rtol=1e-5, atol=1e-9)
 
 
 def test_conv_wgrad_refuses_unsupported():
