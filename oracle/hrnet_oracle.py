@@ -30,7 +30,16 @@ def _conv(sd, key, x, stride=1, pad=0):
     return F.conv2d(x, sd[key + '.weight'], sd.get(key + '.bias'), stride, pad)
 
 
+BN_MOMENTUM = 0.1        # hrnet.py:20
+_TRAIN = [False]         # train-mode BatchNorm (batch statistics + running-stat update)
+
+
 def _bn(sd, key, x):
+    if _TRAIN[0]:
+        sd[key + '.num_batches_tracked'] += 1
+        return F.batch_norm(x, sd[key + '.running_mean'], sd[key + '.running_var'],
+                            sd[key + '.weight'], sd[key + '.bias'],
+                            True, BN_MOMENTUM, BN_EPS)
     return F.batch_norm(x, sd[key + '.running_mean'], sd[key + '.running_var'],
                         sd[key + '.weight'], sd[key + '.bias'],
                         False, 0.0, BN_EPS)
@@ -128,8 +137,23 @@ def coordinate_ramps(map_w, map_h):
     return torch.from_numpy(np.stack([xs, ys])[None].astype(np.float32))
 
 
+def hrnet_forward_train(sd, cfgs, x):
+    """Train-mode forward (model.train(): BatchNorm on batch statistics, running
+    statistics updated in ``sd``), differentiable w.r.t. the tensors of ``sd``
+    that require grad.  trainer.py:191 ``prediction = model(data)``."""
+    _TRAIN[0] = True
+    try:
+        return _hrnet_forward(sd, cfgs, x)
+    finally:
+        _TRAIN[0] = False
+
+
 @torch.no_grad()
 def hrnet_forward(sd, cfgs, x, return_trunk=False):
+    return _hrnet_forward(sd, cfgs, x, return_trunk)
+
+
+def _hrnet_forward(sd, cfgs, x, return_trunk=False):
     """Forward of PoseHighResolutionNet in eval mode.
 
     sd    flat state_dict (HC.pth layout), fp32 CPU tensors

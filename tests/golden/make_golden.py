@@ -82,6 +82,64 @@ def main():
             c = zlib.crc32(np.ascontiguousarray(v.numpy()).tobytes(), c)
         return c
 
+    # ---- 0: two training iterations of the reference HRNet (train mode) with the
+    #         reference's JointsCompositeLoss ('mse', 'l1', weights 1.0 / 0.1) and
+    #         Adam 1e-3: trainer.py:183-209.  The loss calls .cuda() on the
+    #         coordinate ground truth (function.py:188-189): aliased to identity.
+    import libs.loss.function as ref_loss
+    cfg = configs.tiny_config('coordinates')
+    net = ref_hrnet.get_pose_net(cfg, is_train=False).train()
+    sd = synth.synth_state_dict(net.state_dict(), seed=21)
+    net.load_state_dict(sd)
+    crit = ref_loss.JointsCompositeLoss(spec_list=['mse', 'l1', 'sl1'], img_size=cfg['heatmapModel']['input_size'],
+                                        hm_size=cfg['heatmapModel']['heatmap_size'],
+                                        loss_weights=[1.0, 0.1, 'None'])
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=1e-3)
+    gt = torch.Generator().manual_seed(77)
+    nb, nj = 4, cfg['heatmapModel']['num_joints']
+    hw, hh = cfg['heatmapModel']['heatmap_size']
+    xs = [synth.synth_crops(nb, 3, 64, 64, seed=30 + it) for it in range(2)]
+    tg = torch.rand(2, nb, nj, hh, hw, generator=gt)
+    jt = torch.rand(2, nb, nj, 3, generator=gt) * 64.0
+    keys = ['conv1.weight', 'bn1.weight', 'layer1.0.conv1.weight', 'layer1.0.downsample.1.weight',
+            'transition1.1.0.0.weight', 'stage2.0.branches.1.0.conv1.weight', 'stage2.0.fuse_layers.0.1.0.weight',
+            'stage2.0.fuse_layers.1.0.0.0.weight', 'stage3.0.fuse_layers.2.0.0.0.weight',
+            'stage4.0.branches.3.0.bn2.bias', 'stage4.0.fuse_layers.0.3.1.weight', 'head1.0.weight', 'head1.0.bias',
+            'head2.0.conv1.weight', 'head2.0.downsample.0.weight', 'head2.3.bn2.weight', 'head2.4.weight',
+            'head2.4.bias']
+    named = dict(net.named_parameters())
+    arrs = dict(cfg=np.array(json.dumps(cfg)), sd_crc=np.array(sd_crc(sd)), target=tg.numpy(), joints=jt.numpy(),
+                keys=np.array(json.dumps(keys)), param_order=np.array(json.dumps(list(named))))
+    losses = []
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for it in range(2):
+            opt.zero_grad()
+            out = net(xs[it])
+            loss = crit(out, tg[it], None, {'transformed_joints': jt[it].numpy().copy()})
+            loss.backward()
+            if it == 0:
+                arrs['grad_norms'] = np.array([float(p.grad.double().norm()) for p in named.values()])
+                for k in keys:
+                    arrs['g1/' + k] = named[k].grad.numpy().copy()
+                arrs['maps1'] = out[0].detach().numpy().copy()
+                arrs['coords1'] = out[1].detach().numpy().copy()
+            opt.step()
+            losses.append(float(loss))
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    fin = net.state_dict()
+    for k in keys:
+        arrs['p2/' + k] = fin[k].numpy().copy()
+    for k in ('bn1.running_mean', 'bn1.running_var', 'stage3.0.branches.2.0.bn1.running_var',
+              'head2.1.bn2.running_mean', 'bn1.num_batches_tracked'):
+        arrs['p2/' + k] = fin[k].numpy().copy()
+    arrs['losses'] = np.array(losses)
+    save('hrnet_train.npz', **arrs)
+    if '--train-only' in sys.argv:
+        return
+
     # ---- 1/2/3: tiny HRNets stored in full --------------------------------
     for tag, cfg, n in (
             ('tiny_coords', configs.tiny_config('coordinates'), 2),

@@ -149,6 +149,57 @@ def test_pose_oracle_cuboids():
                                g['alpha_trans'], atol=1e-9)
 
 
+def test_hrnet_train_oracle_vs_reference():
+    """Two train-mode iterations of the reference HRNet (tiny topology) with the
+    reference's JointsCompositeLoss and Adam: losses, first-step outputs and
+    gradients, parameters and running statistics after the second step."""
+    import json
+    from oracle.hrnet_train_oracle import HRNetTrainOracle
+    g = golden('hrnet_train.npz')
+    cfg = fixture_cfg(g)
+    sd = _synth_hc(cfg, seed=21)
+    require_same_rng(sd_crc(sd), g['sd_crc'], 'weights')
+    keys = json.loads(str(g['keys']))
+    orc = HRNetTrainOracle(sd, cfg, lr=1e-3)
+    assert orc.param_keys == json.loads(str(g['param_order']))
+    losses = []
+    for it in range(2):
+        x = synth.synth_crops(4, 3, 64, 64, seed=30 + it)
+        loss, maps, coords = orc.step(x, torch.from_numpy(g['target'][it]), torch.from_numpy(g['joints'][it][..., :2]))
+        losses.append(loss)
+        if it == 0:
+            np.testing.assert_allclose(maps.numpy(), g['maps1'], rtol=0, atol=1e-5)
+            np.testing.assert_allclose(coords.numpy(), g['coords1'], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(losses, g['losses'], rtol=1e-6)
+    fin = orc.sd
+    for k in keys:
+        # Adam's first steps move every entry by ~lr * sign(grad): an entry whose
+        # gradient is rounding noise may step the other way
+        d = np.abs(fin[k].detach().numpy() - g['p2/' + k])
+        assert np.mean(d > 1e-5) < 0.01, k
+    for k in ('bn1.running_mean', 'bn1.running_var', 'stage3.0.branches.2.0.bn1.running_var',
+              'head2.1.bn2.running_mean'):
+        np.testing.assert_allclose(fin[k].numpy(), g['p2/' + k], rtol=1e-4, atol=1e-5, err_msg=k)
+    assert int(fin['bn1.num_batches_tracked']) == int(g['p2/bn1.num_batches_tracked']) == 2
+
+
+def test_hrnet_train_oracle_first_step_gradients():
+    import json
+    from oracle.hrnet_train_oracle import HRNetTrainOracle
+    g = golden('hrnet_train.npz')
+    cfg = fixture_cfg(g)
+    orc = HRNetTrainOracle(_synth_hc(cfg, seed=21), cfg, lr=1e-3)
+    x = synth.synth_crops(4, 3, 64, 64, seed=30)
+    orc.step(x, torch.from_numpy(g['target'][0]), torch.from_numpy(g['joints'][0][..., :2]), update=False)
+    grads = orc.grads()
+    norms = np.array([float(grads[k].double().norm()) for k in orc.param_keys])
+    np.testing.assert_allclose(norms, g['grad_norms'], rtol=1e-4, atol=1e-9)
+    for k in json.loads(str(g['keys'])):
+        ref = g['g1/' + k]
+        np.testing.assert_allclose(grads[k].numpy(), ref, rtol=0, atol=1e-5 * max(1e-6, float(np.abs(ref).max())),
+                                   err_msg=k)
+
+
 def test_lifter_train_oracle_vs_reference():
     """Three train-mode iterations (batch-stat BN, MSE(mean), Adam) of the
     reference's FCModel on CPU."""
