@@ -196,9 +196,9 @@ static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
         : (a.Cout > 64)             ? WgradVariant{1, 1, 2, 1}
         : (a.Cin > 64)              ? WgradVariant{1, 1, 1, 2}
                                     : WgradVariant{1, 1, 1, 1};
-  } else if (a.taps == 9) {
-    v = WgradVariant{9, 1, 1, 1};
-  } else if (a.taps == 16) {
+  } else if (a.taps <= 9) {
+    v = WgradVariant{9, 1, 1, 1};  // waves whose tap does not exist idle
+  } else if (a.taps <= 16) {
     v = WgradVariant{8, 2, 1, 1};
   } else {
     return EGN_E_BADARG;

@@ -465,9 +465,12 @@ class HRNetEngine(object):
             r.join()
         return outs
 
-    def _record(self, n, cin, h, w, decode_mode):
+    def _record(self, n, cin, h, w, decode_mode, r=None):
+        """Walk the module tree once, issuing every layer to the recorder ``r``.
+        The default recorder builds an inference program; egonet_amd.train_hrnet
+        passes a tape that executes train-mode layers and records their backward."""
         m = self.model
-        r = _Recorder()
+        r = _Recorder() if r is None else r
         x = r.nchw_to_nhwc(Ref(SLOT_USER0, 0), n, cin, h, w, tag='input')
         t = r.conv(x, m.conv1.weight, None, m.bn1, ACT_RELU, None, 2, 1, tag='conv1')
         t = r.conv(t, m.conv2.weight, None, m.bn2, ACT_RELU, None, 2, 1, tag='conv2')

@@ -1,0 +1,415 @@
+"""Native training step of the HRNet heat-map / coordinate model on MI355X
+(BASELINE config 4).
+
+Reference hot loop, ``libs/trainer/trainer.py:183-209``::
+
+    optim.zero_grad(); prediction = model(data); loss = loss_func(prediction, target, weights, meta)
+    loss.backward(); optim.step()
+
+with ``model`` = PoseHighResolutionNet in train mode (BatchNorm on batch
+statistics), ``loss_func`` = JointsCompositeLoss(['mse','l1',None], weights
+1.0 / 0.1) (libs/loss/function.py:61-202, KITTI_train_IGRs.yml:86-89) and
+Adam(lr 1e-3) (libs/optimizer/optimizer.py:8-40).
+
+``HRNetTrainStep.step`` runs all of that as HIP launches through the C ABI;
+torch autograd / MIOpen are not involved:
+
+* forward: the SAME module walk the inference engine records
+  (``engine.HRNetEngine._record``) is issued to a tape that executes each layer
+  in train mode -- raw conv on the fp32-MFMA kernel (weights packed on the
+  device every step), batch statistics + running-stat update, fused
+  BatchNorm(+residual)+ReLU -- and remembers what its backward needs;
+* backward: the tape is replayed in reverse: fused BatchNorm/ReLU backward
+  (two-pass column reductions), weight gradients on the split-K MFMA kernel
+  (csrc/conv_wgrad.hip), data gradients on the forward conv kernel with the
+  180-degree-rotated, channel-swapped filter (stride 2: over the zero-inserted
+  gradient), multi-resolution fuse backward (gated block sums);
+* loss: 0.5 * MSE over the maps + 0.1 * L1 over the coordinates, gradients
+  written by the loss kernels;
+* Adam: ONE launch over the flat parameter buffer (``FlatParams``): parameters,
+  gradients and both moments each live in one contiguous allocation, the
+  module's ``nn.Parameter``s are views of it (state_dict / HC.pth unchanged).
+  The flat gradient is also what a data-parallel job all-reduces (one RCCL
+  call per bucket, ``egonet_amd.parallel``).
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib, tuner
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID
+from .engine import Buf, HRNetEngine, SLOT_USER0, _round_up
+
+
+class FlatParams(object):
+    """Trainable parameters as views of one flat fp32 buffer (+ flat grad, m, v)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError('no trainable parameters')
+        dev = self.params[0].device
+        self.offsets = []
+        total = 0
+        for p in self.params:
+            self.offsets.append(total)
+            total += _round_up(p.numel(), 4)          # every view stays 16-byte aligned
+        self.numel = total
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                view = self.flat[off:off + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.grad[off:off + p.numel()].view_as(p)
+        self.t = 0
+
+    def adam_step(self, lr, betas, eps, stream):
+        self.t += 1
+        _lib.check(_lib.lib().egn_adam_step_f32(_lib.ptr(self.flat), _lib.ptr(self.grad), _lib.ptr(self.m),
+                                                _lib.ptr(self.v), self.numel, lr, betas[0], betas[1], eps,
+                                                self.t, stream), 'adam')
+
+
+class _Tape(object):
+    """Recorder interface of ``engine._Recorder`` that EXECUTES train-mode layers."""
+
+    def __init__(self, owner, images):
+        self.o = owner
+        self.L = owner.L
+        self.dev = images.device
+        self.images = images
+        self.st = _lib.current_stream(self.dev)
+        self.data = {}            # id(Buf) -> 1-D fp32 tensor
+        self.grad = {}            # id(Buf) -> [tensor, owned]
+        self.keep = []            # Bufs (ids stay unique while the tape lives)
+        self.back = []            # backward closures, forward order
+        self.named = {}           # tag -> Buf
+        self.user = {}            # tag -> NCHW copy for the caller
+        self.no_grad = set()      # ids of Bufs that need no gradient (the input)
+        self.bns = []
+        self.maps_user = None
+
+    # -- recorder plumbing (concurrency hints are ignored: one stream) ------
+    def fork(self):
+        pass
+
+    def join(self):
+        pass
+
+    def lane(self, k):
+        pass
+
+    def decode(self, *a, **k):
+        raise NotImplementedError('decode is not part of the training step')
+
+    def _empty(self, numel):
+        return torch.empty(numel, dtype=torch.float32, device=self.dev)
+
+    def new(self, n, h, w, c, cs=None, name=''):
+        b = Buf(n, h, w, c, cs=cs, name=name)
+        self.keep.append(b)
+        self.data[id(b)] = self._empty(n * h * w * b.cs)
+        return b
+
+    def _accum(self, buf, g, owned=True):
+        if id(buf) in self.no_grad:
+            return
+        cur = self.grad.get(id(buf))
+        if cur is None:
+            self.grad[id(buf)] = [g, owned]
+            return
+        if not cur[1]:                              # shared tensor: do not add in place
+            out = self._empty(g.numel())
+            _lib.check(self.L.egn_add_f32(_lib.ptr(cur[0]), _lib.ptr(g), _lib.ptr(out), g.numel(), self.st), 'add')
+            self.grad[id(buf)] = [out, True]
+        else:
+            _lib.check(self.L.egn_add_f32(_lib.ptr(cur[0]), _lib.ptr(g), _lib.ptr(cur[0]), g.numel(), self.st), 'add')
+
+    def _take_grad(self, buf):
+        cur = self.grad.pop(id(buf), None)
+        return None if cur is None else cur[0]
+
+    # -- launches -----------------------------------------------------------
+    def _pack(self, weight, dgrad):
+        cout, cin, kh, kw = weight.shape
+        wp = self._empty(self.L.egn_packed_weight_floats(cout, cin, kh, kw, dgrad))
+        _lib.check(self.L.egn_pack_conv_weight_f32(_lib.ptr(weight), cout, cin, kh, kw, dgrad, _lib.ptr(wp), self.st),
+                   'pack')
+        return wp
+
+    def _conv_launch(self, x, wp, shift, y, n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, act):
+        key = (n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, False, False)
+        cfg = tuner.choose(self.dev, key)
+        _lib.check(self.L.egn_conv2d_f32(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(self.o.ones), _lib.ptr(shift), None,
+                                         _lib.ptr(y), n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, act,
+                                         0, cfg, self.st), 'conv')
+
+    def _wgrad(self, x, xd, dy, cs_out, weight, stride, pad):
+        cout, cin, kh, kw = weight.shape
+        L = self.L
+        need = L.egn_conv2d_wgrad_ws_bytes(x.n, x.h, x.w, cin, x.cs, cout, cs_out, kh, kw, stride, pad)
+        if need < 0:
+            raise NotImplementedError('weight gradient of a %dx%d convolution' % (kh, kw))
+        ws = self.o.wgrad_ws(need)
+        _lib.check(L.egn_conv2d_wgrad_f32(_lib.ptr(xd), _lib.ptr(dy), _lib.ptr(weight.grad), x.n, x.h, x.w, cin, x.cs,
+                                          cout, cs_out, kh, kw, stride, pad, _lib.ptr(ws), ws.numel() * 4, self.st),
+                   'wgrad')
+
+    def _dgrad(self, dy, ho, wo, cs_out, weight, stride, pad, x):
+        cout, cin, kh, kw = weight.shape
+        if kh != kw:
+            raise NotImplementedError('data gradient of a non-square %dx%d convolution' % (kh, kw))
+        L = self.L
+        wq = self._pack(weight, 1)
+        if stride == 2:
+            up = self._empty(x.n * x.h * x.w * cs_out)
+            _lib.check(L.egn_zero_insert2_f32(_lib.ptr(dy), _lib.ptr(up), x.n, ho, wo, x.h, x.w, cs_out, self.st),
+                       'zero_insert')
+            src, sh, sw = up, x.h, x.w
+        elif stride == 1:
+            src, sh, sw = dy, ho, wo
+        else:
+            raise NotImplementedError('stride %d' % stride)
+        dx = self._empty(x.n * x.h * x.w * x.cs)
+        self._conv_launch(src, wq, self.o.zeros, dx, x.n, sh, sw, cout, cs_out, cin, x.cs, kh, kw, 1, kh - 1 - pad,
+                          ACT_NONE)
+        return dx
+
+    # -- ops (engine._Recorder interface) -----------------------------------
+    def nchw_to_nhwc(self, x_ext, n, c, h, w, tag=''):
+        y = self.new(n, h, w, c, name=tag)
+        _lib.check(self.L.egn_nchw_to_nhwc_f32(_lib.ptr(self.images), _lib.ptr(self.data[id(y)]), n, c, h, w, y.cs,
+                                               self.st), 'to_nhwc')
+        self.no_grad.add(id(y))
+        return y
+
+    def nhwc_to_nchw(self, x, c, dst_ext, tag=''):
+        self.maps_user = torch.empty(x.n, c, x.h, x.w, dtype=torch.float32, device=self.dev)
+        _lib.check(self.L.egn_nhwc_to_nchw_f32(_lib.ptr(self.data[id(x)]), _lib.ptr(self.maps_user), x.n, c, x.h, x.w,
+                                               x.cs, self.st), 'to_nchw')
+
+    def ramps(self, y, c0, tag=''):
+        _lib.check(self.L.egn_fill_coord_ramps_f32(_lib.ptr(self.data[id(y)]), y.n, y.h, y.w, y.cs, c0, self.st),
+                   'ramps')
+
+    def conv(self, x, weight, bias=None, bn=None, act=ACT_NONE, res=None, stride=1, pad=0,
+             dst=None, out_nchw=False, cout_cs=None, tag=''):
+        L = self.L
+        cout, cin, kh, kw = weight.shape
+        assert cin == x.c, (cin, x.c, tag)
+        ho = (x.h + 2 * pad - kh) // stride + 1
+        wo = (x.w + 2 * pad - kw) // stride + 1
+        # user-facing outputs (dst / out_nchw of the inference recording) are computed
+        # into an internal NHWC tensor like every other layer -- the backward needs the
+        # padded layout -- and copied out in the caller's NCHW format afterwards
+        z = self.new(x.n, ho, wo, cout, cs=cout_cs, name=tag)
+        xd, zd = self.data[id(x)], self.data[id(z)]
+        wp = self._pack(weight, 0)
+        rows = x.n * ho * wo
+        if bn is None:
+            shift = self.o.zeros
+            if bias is not None:
+                shift = torch.zeros(_round_up(cout, 16), dtype=torch.float32, device=self.dev)
+                shift[:cout].copy_(bias.detach())
+            self._conv_launch(xd, wp, shift, zd, x.n, x.h, x.w, cin, x.cs, cout, z.cs, kh, kw, stride, pad, act)
+            if dst is not None or out_nchw:
+                u = torch.empty(x.n, cout, ho, wo, dtype=torch.float32, device=self.dev)
+                _lib.check(L.egn_nhwc_to_nchw_f32(_lib.ptr(zd), _lib.ptr(u), x.n, cout, ho, wo, z.cs, self.st), 'to_nchw')
+                self.user[tag] = u
+            self.named[tag] = z
+
+            def backward():
+                dy = self._take_grad(z)
+                if dy is None:
+                    return
+                if act == ACT_SIGMOID:
+                    dz = self._empty(dy.numel())
+                    _lib.check(L.egn_sigmoid_bwd_f32(_lib.ptr(dy), _lib.ptr(zd), _lib.ptr(dz), dy.numel(), self.st),
+                               'sigmoid_bwd')
+                    dy = dz
+                elif act != ACT_NONE:
+                    raise NotImplementedError('activation %d without BatchNorm' % act)
+                if bias is not None and bias.requires_grad:
+                    _lib.check(L.egn_colsum_f32(_lib.ptr(dy), rows, cout, z.cs, _lib.ptr(bias.grad),
+                                                _lib.ptr(self.o.col_ws), self.st), 'bias grad')
+                if weight.requires_grad:
+                    self._wgrad(x, xd, dy, z.cs, weight, stride, pad)
+                if id(x) not in self.no_grad:
+                    self._accum(x, self._dgrad(dy, ho, wo, z.cs, weight, stride, pad, x))
+            self.back.append(backward)
+            return z
+
+        if bias is not None:
+            raise NotImplementedError('conv bias followed by BatchNorm')
+        self._conv_launch(xd, wp, self.o.zeros, zd, x.n, x.h, x.w, cin, x.cs, cout, z.cs, kh, kw, stride, pad, ACT_NONE)
+        mean, istd = self._empty(cout), self._empty(cout)
+        mom = 0.1 if bn.momentum is None else bn.momentum
+        _lib.check(L.egn_bn_stats_f32(_lib.ptr(zd), rows, cout, z.cs, bn.eps, _lib.ptr(mean), _lib.ptr(istd), None,
+                                      _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), mom,
+                                      _lib.ptr(self.o.col_ws), self.st), 'bn_stats')
+        self.bns.append(bn)
+        y = self.new(x.n, ho, wo, cout, cs=z.cs, name=tag)
+        yd = self.data[id(y)]
+        relu = 1 if act == ACT_RELU else 0
+        if act not in (ACT_NONE, ACT_RELU):
+            raise NotImplementedError('activation %d after BatchNorm' % act)
+        rd = None if res is None else self.data[id(res)]
+        _lib.check(L.egn_bn_act_fwd_f32(_lib.ptr(zd), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(bn.weight),
+                                        _lib.ptr(bn.bias), None, 1.0, relu, _lib.ptr(rd), _lib.ptr(yd), rows, cout,
+                                        z.cs, self.st), 'bn_act_fwd')
+        self.named[tag] = y
+
+        def backward():
+            dy = self._take_grad(y)
+            if dy is None:
+                return
+            dbeta = bn.bias.grad if bn.bias.requires_grad else self._empty(cout)
+            dgamma = bn.weight.grad if bn.weight.requires_grad else self._empty(cout)
+            _lib.check(L.egn_bn_bwd_sums_f32(_lib.ptr(dy), _lib.ptr(zd), None, 1.0, _lib.ptr(mean), _lib.ptr(istd),
+                                             _lib.ptr(bn.weight), _lib.ptr(bn.bias), relu, _lib.ptr(rd), rows, cout,
+                                             z.cs, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(self.o.col_ws),
+                                             self.st), 'bn_bwd_sums')
+            dz = self._empty(dy.numel())
+            dres = self._empty(dy.numel()) if (res is not None and id(res) not in self.no_grad) else None
+            _lib.check(L.egn_bn_bwd_dz_f32(_lib.ptr(dy), _lib.ptr(zd), None, 1.0, _lib.ptr(mean), _lib.ptr(istd),
+                                           _lib.ptr(bn.weight), _lib.ptr(bn.bias), relu, _lib.ptr(rd), _lib.ptr(dbeta),
+                                           _lib.ptr(dgamma), _lib.ptr(dz), _lib.ptr(dres), rows, cout, z.cs, self.st),
+                       'bn_bwd_dz')
+            if dres is not None:
+                self._accum(res, dres)
+            if weight.requires_grad:
+                self._wgrad(x, xd, dz, z.cs, weight, stride, pad)
+            if id(x) not in self.no_grad:
+                self._accum(x, self._dgrad(dz, ho, wo, z.cs, weight, stride, pad, x))
+        self.back.append(backward)
+        return y
+
+    def fuse(self, terms, relu, tag=''):
+        L = self.L
+        base = [t for t, s in terms if s == 0][0]
+        y = self.new(base.n, base.h, base.w, base.c, cs=base.cs, name=tag)
+        yd = self.data[id(y)]
+        nt = len(terms)
+        ptrs = (C.c_void_p * nt)(*[self.data[id(t)].data_ptr() for t, _ in terms])
+        shifts = (C.c_int * nt)(*[s for _, s in terms])
+        _lib.check(L.egn_fuse_sum_relu_f32(_lib.ptr(yd), y.n, y.h, y.w, y.c, y.cs, nt, ptrs, shifts, int(relu), self.st),
+                   'fuse')
+        self.named[tag] = y
+
+        def backward():
+            dy = self._take_grad(y)
+            if dy is None:
+                return
+            gate = _lib.ptr(yd) if relu else None
+            shared = {}
+            for t, s in terms:
+                if id(t) in self.no_grad:
+                    continue
+                g = shared.get(s)
+                if g is None:
+                    g = self._empty(t.n * t.h * t.w * t.cs)
+                    _lib.check(L.egn_fuse_bwd_f32(_lib.ptr(dy), gate, _lib.ptr(g), y.n, y.h, y.w, y.cs, s, self.st),
+                               'fuse_bwd')
+                    shared[s] = g
+                self._accum(t, g, owned=False)       # same-shift terms share one tensor
+        self.back.append(backward)
+        return y
+
+
+class HRNetTrainStep(object):
+    """``step(images, target, joints_xy)`` = one iteration of trainer.py:183-209."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, w_hm=1.0, w_coor=0.1, grad_sync=None):
+        p0 = next(model.parameters())
+        if not p0.is_cuda:
+            raise ValueError('HRNetTrainStep needs the model on a GPU')
+        if model.head_type not in ('coordinates', 'heatmap') or model.pixel_shuffle:
+            raise NotImplementedError('native training: head_type %r pixel_shuffle %r'
+                                      % (model.head_type, model.pixel_shuffle))
+        if model.head_type == 'heatmap' and w_coor:
+            raise NotImplementedError("the 'heatmap' head trains with the heat-map term only (w_coor=0)")
+        self.model = model
+        self.dev = p0.device
+        self.L = _lib.lib()
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.w_hm, self.w_coor = float(w_hm), float(w_coor or 0.0)
+        self.grad_sync = grad_sync
+        self.flat = FlatParams(model.parameters())
+        widest = max(p.shape[0] for p in model.parameters()) + 32
+        self.ones = torch.ones(_round_up(widest, 16), dtype=torch.float32, device=self.dev)
+        self.zeros = torch.zeros(_round_up(widest, 16), dtype=torch.float32, device=self.dev)
+        self.col_ws = torch.zeros(self.L.egn_colreduce_ws_bytes(widest) // 4, dtype=torch.float32, device=self.dev)
+        self._wgrad_ws = None
+        self.loss_dev = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self.walker = HRNetEngine(model)
+        self.last_maps = self.last_coords = None
+
+    def wgrad_ws(self, nbytes):
+        if self._wgrad_ws is None or self._wgrad_ws.numel() * 4 < nbytes:
+            self._wgrad_ws = torch.empty(nbytes // 4 + 1024, dtype=torch.float32, device=self.dev)
+        return self._wgrad_ws
+
+    @torch.no_grad()
+    def step(self, images, target, joints_xy=None, update=True):
+        """images [N,3,H,W], target [N,K,h,w] heat-maps, joints_xy [N,K,2] in input
+        pixels (``meta['transformed_joints'][:, :, :2]``).  Returns the loss as a
+        1-element float64 device tensor (no host sync)."""
+        m, L = self.model, self.L
+        if not m.training:
+            raise RuntimeError('HRNetTrainStep.step needs model.train()')
+        images = images.contiguous().float()
+        target = target.contiguous().float()
+        n, cin, h, w = images.shape
+        if h % 32 or w % 32:
+            raise ValueError('HRNet input height/width must be multiples of 32, got %dx%d' % (h, w))
+        with torch.cuda.device(self.dev):
+            st = _lib.current_stream(self.dev)
+            self.flat.grad.zero_()
+            tape = _Tape(self, images)
+            self.walker._record(n, cin, h, w, None, r=tape)
+            torch._foreach_add_([bn.num_batches_tracked for bn in tape.bns], 1)
+            J = m.num_joints
+            self.loss_dev.zero_()
+            if m.head_type == 'coordinates':
+                aug, coords = tape.named['head1'], tape.named['head2.4']
+                cd = tape.user['head2.4'].view(n, 2 * J)          # compact [N, 2K] = coords [N,K,2]
+                self.last_coords = cd.view(n, J, 2)
+                self.last_maps = tape.maps_user
+                if self.w_coor:
+                    if joints_xy is None:
+                        raise ValueError('the coordinate term needs joints_xy')
+                    gt = torch.as_tensor(joints_xy, dtype=torch.float32).to(self.dev)[..., :2].clone()
+                    gt[..., 0] /= w            # function.py:160-161 (img_size = (width, height))
+                    gt[..., 1] /= h
+                    gt = gt.contiguous()
+                    dc = tape._empty(cd.numel())
+                    _lib.check(L.egn_l1_f32(_lib.ptr(cd), _lib.ptr(gt), cd.numel(), self.w_coor, _lib.ptr(dc),
+                                            _lib.ptr(self.loss_dev), st), 'l1')
+                    dpad = tape._empty(n * coords.cs)             # back to the padded NHWC row layout
+                    _lib.check(L.egn_nchw_to_nhwc_f32(_lib.ptr(dc), _lib.ptr(dpad), n, 2 * J, 1, 1, coords.cs, st))
+                    tape.grad[id(coords)] = [dpad, True]
+            else:
+                aug = tape.named['final_layer']
+                self.last_maps = tape.user['final_layer']
+            if tuple(target.shape) != (n, J, aug.h, aug.w):
+                raise ValueError('target must be %s, got %s' % ((n, J, aug.h, aug.w), tuple(target.shape)))
+            tg = tape._empty(n * aug.h * aug.w * aug.cs)
+            _lib.check(L.egn_nchw_to_nhwc_f32(_lib.ptr(target), _lib.ptr(tg), n, J, aug.h, aug.w, aug.cs, st))
+            da = torch.zeros(n * aug.h * aug.w * aug.cs, dtype=torch.float32, device=self.dev)
+            # (1/K) sum_k 0.5*MSE_k = 0.5 * MSE over all joints (equal element counts)
+            _lib.check(L.egn_mse_f32(_lib.ptr(tape.data[id(aug)]), _lib.ptr(tg), n * aug.h * aug.w, J, aug.cs, aug.cs,
+                                     0.5 * self.w_hm, 0, _lib.ptr(da), _lib.ptr(self.loss_dev), st), 'mse')
+            tape._accum(aug, da)
+            for fn in reversed(tape.back):
+                fn()
+            if self.grad_sync is not None:
+                self.grad_sync(self.flat.grad)
+            if update:
+                self.flat.adam_step(self.lr, self.betas, self.eps, st)
+            m._engine = None          # the inference engine caches folded weights
+        return self.loss_dev

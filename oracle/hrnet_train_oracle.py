@@ -20,7 +20,7 @@ from . import hrnet_oracle
 def composite_loss(out, target, joints_xy, img_size, w_hm=1.0, w_coor=0.1):
     """out = (maps [N,K,H,W], coords [N,K,2]); target [N,K,H,W]; joints_xy [N,K,2] in
     input-image pixels."""
-    maps, coords = out
+    maps, coords = out if isinstance(out, tuple) else (out, None)
     n, k = maps.shape[:2]
     pred = maps.reshape(n, k, -1)
     gt = target.reshape(n, k, -1)
@@ -28,6 +28,8 @@ def composite_loss(out, target, joints_xy, img_size, w_hm=1.0, w_coor=0.1):
     for j in range(k):                      # function.py:103-111, joint by joint
         loss = loss + 0.5 * F.mse_loss(pred[:, j], gt[:, j], reduction='mean')
     total = (loss / k) * w_hm
+    if coords is None or not w_coor:
+        return total
     cgt = joints_xy.clone().float()
     cgt[:, :, 0] /= img_size[0]
     cgt[:, :, 1] /= img_size[1]
@@ -55,6 +57,8 @@ class HRNetTrainOracle(object):
         loss.backward()
         if update:
             self.opt.step()
+        if not isinstance(out, tuple):
+            return float(loss.detach()), out.detach(), None
         return float(loss.detach()), out[0].detach(), out[1].detach()
 
     def grads(self):

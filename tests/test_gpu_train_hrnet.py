@@ -1,0 +1,169 @@
+"""Native HRNet training step (egonet_amd.train_hrnet, BASELINE config 4 per GPU)
+on MI355X against (a) two iterations of the REFERENCE (tests/golden/hrnet_train.npz:
+reference model, reference JointsCompositeLoss, torch Adam) and (b) the CPU
+training oracle at the full W48 / 256x256 size.
+
+Tolerances: fp32 throughout; gradients are compared relative to each tensor's
+largest entry.  Adam's first steps move every entry by ~lr*sign(grad), so an
+entry whose gradient is rounding noise can step the other way -- parameters
+after the update are compared with an outlier budget, as in the CPU oracle test.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, fixture_cfg, sd_crc, require_same_rng
+from egonet_amd import configs, synth
+from egonet_amd.model.heatmapModel import hrnet as hip_hrnet
+from egonet_amd.train_hrnet import HRNetTrainStep
+from oracle.hrnet_train_oracle import HRNetTrainOracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _no_autotune(monkeypatch):
+    monkeypatch.setenv('EGONET_AMD_AUTOTUNE', '0')      # cost-model tile choice: keeps the tests short
+
+
+def _tiny_model(cfg, seed=21):
+    net = hip_hrnet.get_pose_net(cfg, is_train=False)
+    sd = synth.synth_state_dict(net.state_dict(), seed=seed)
+    net.load_state_dict(sd)
+    return net.cuda().train(), sd
+
+
+def _rel_err(got, want):
+    scale = float(np.abs(want).max())
+    return float(np.abs(got - want).max()) / max(scale, 1e-12)
+
+
+def test_first_step_gradients_vs_reference():
+    g = golden('hrnet_train.npz')
+    cfg = fixture_cfg(g)
+    net, sd = _tiny_model(cfg)
+    require_same_rng(sd_crc(sd), g['sd_crc'], 'weights')
+    tr = HRNetTrainStep(net, lr=1e-3)
+    x = synth.synth_crops(4, 3, 64, 64, seed=30).cuda()
+    loss = tr.step(x, torch.from_numpy(g['target'][0]).cuda(), torch.from_numpy(g['joints'][0]), update=False)
+    assert abs(float(loss.item()) - float(g['losses'][0])) < 2e-5 * abs(float(g['losses'][0]))
+    np.testing.assert_allclose(tr.last_maps.cpu().numpy(), g['maps1'], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(tr.last_coords.cpu().numpy(), g['coords1'], rtol=0, atol=1e-5)
+    named = dict(net.named_parameters())
+    order = json.loads(str(g['param_order']))
+    assert list(named) == order
+    norms = np.array([float(named[k].grad.double().norm()) for k in order])
+    np.testing.assert_allclose(norms, g['grad_norms'], rtol=2e-3, atol=1e-8)
+    for k in json.loads(str(g['keys'])):
+        assert _rel_err(named[k].grad.cpu().numpy(), g['g1/' + k]) < 2e-3, k
+
+
+def test_two_steps_vs_reference():
+    g = golden('hrnet_train.npz')
+    cfg = fixture_cfg(g)
+    net, _ = _tiny_model(cfg)
+    tr = HRNetTrainStep(net, lr=1e-3)
+    losses = []
+    for it in range(2):
+        x = synth.synth_crops(4, 3, 64, 64, seed=30 + it).cuda()
+        loss = tr.step(x, torch.from_numpy(g['target'][it]).cuda(), torch.from_numpy(g['joints'][it]))
+        losses.append(float(loss.item()))
+    np.testing.assert_allclose(losses, g['losses'], rtol=2e-4)
+    fin = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    for k in json.loads(str(g['keys'])):
+        d = np.abs(fin[k] - g['p2/' + k])
+        assert np.mean(d > 2e-5) < 0.03, (k, float(np.mean(d > 2e-5)))
+    for k in ('bn1.running_mean', 'bn1.running_var', 'stage3.0.branches.2.0.bn1.running_var',
+              'head2.1.bn2.running_mean'):
+        np.testing.assert_allclose(fin[k], g['p2/' + k], rtol=1e-3, atol=1e-5, err_msg=k)
+    assert int(fin['bn1.num_batches_tracked']) == 2
+
+
+def test_heatmap_head_vs_oracle():
+    cfg = configs.tiny_config('heatmap')
+    net, sd = _tiny_model(cfg, seed=5)
+    gen = torch.Generator().manual_seed(1)
+    x = synth.synth_crops(3, 3, 64, 64, seed=2)
+    tgt = torch.rand(3, 5, 16, 16, generator=gen)
+    orc = HRNetTrainOracle(sd, cfg, lr=1e-3, w_coor=0.0)
+    want_loss, want_maps, _ = orc.step(x, tgt, None, update=False)
+    tr = HRNetTrainStep(net, lr=1e-3, w_coor=0.0)
+    loss = tr.step(x.cuda(), tgt.cuda(), None, update=False)
+    assert abs(float(loss.item()) - want_loss) < 2e-5 * abs(want_loss)
+    np.testing.assert_allclose(tr.last_maps.cpu().numpy(), want_maps.numpy(), rtol=0, atol=2e-4)
+    # the fp32 noise floor of this net (ReLU gates next to 0 flip, 3-sample batch
+    # statistics): the fp32 oracle against the same oracle in float64
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    orc64 = HRNetTrainOracle(sd64, cfg, lr=1e-3, w_coor=0.0)
+    orc64.step(x.double(), tgt.double(), None, update=False)
+    g64 = orc64.grads()
+    named = dict(net.named_parameters())
+    for k, gw in orc.grads().items():
+        ref = g64[k].numpy()
+        floor = _rel_err(gw.numpy().astype(np.float64), ref)
+        assert _rel_err(named[k].grad.cpu().numpy().astype(np.float64), ref) < max(2e-3, 4 * floor), (k, floor)
+
+
+def test_frozen_prefix_gets_no_gradient_and_no_update():
+    cfg = configs.tiny_config('coordinates')
+    net, sd = _tiny_model(cfg, seed=9)
+    for name, p in net.named_parameters():
+        if name.startswith(('conv1', 'bn1', 'layer1')):
+            p.requires_grad = False
+    before = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    tr = HRNetTrainStep(net, lr=1e-3)
+    gen = torch.Generator().manual_seed(3)
+    x = synth.synth_crops(2, 3, 64, 64, seed=4).cuda()
+    tr.step(x, torch.rand(2, 5, 16, 16, generator=gen).cuda(), torch.rand(2, 5, 2, generator=gen) * 64)
+    after = net.state_dict()
+    assert torch.equal(after['conv1.weight'], before['conv1.weight'])
+    assert torch.equal(after['layer1.2.bn3.bias'], before['layer1.2.bn3.bias'])
+    assert not torch.equal(after['stage2.0.branches.0.0.conv1.weight'], before['stage2.0.branches.0.0.conv1.weight'])
+    assert not torch.equal(after['bn1.running_mean'], before['bn1.running_mean'])   # train-mode BN still tracks
+
+
+def test_inference_after_training_uses_the_updated_weights():
+    cfg = configs.tiny_config('coordinates')
+    net, _ = _tiny_model(cfg, seed=9)
+    x = synth.synth_crops(2, 3, 64, 64, seed=4).cuda()
+    net.eval()
+    with torch.no_grad():
+        m0, _ = net(x)
+    net.train()
+    tr = HRNetTrainStep(net, lr=1e-2)
+    gen = torch.Generator().manual_seed(3)
+    tr.step(x, torch.rand(2, 5, 16, 16, generator=gen).cuda(), torch.rand(2, 5, 2, generator=gen) * 64)
+    net.eval()
+    with torch.no_grad():
+        m1, _ = net(x)
+    assert float((m1 - m0).abs().max()) > 1e-4
+
+
+def test_w48_gradients_vs_oracle_full_size():
+    """Full HRNet-W48 at 256x256, 2 crops: every parameter gradient against the CPU
+    oracle (torch autograd on the functional restatement)."""
+    cfg = configs.w48_config('coordinates')
+    net = hip_hrnet.get_pose_net(cfg, is_train=False)
+    sd = synth.synth_state_dict(net.state_dict(), seed=1)
+    net.load_state_dict(sd)
+    gen = torch.Generator().manual_seed(12)
+    x = synth.synth_crops(2, 3, 256, 256, seed=13)
+    tgt = torch.rand(2, 33, 64, 64, generator=gen)
+    jt = torch.rand(2, 33, 2, generator=gen) * 256
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    orc = HRNetTrainOracle(sd, cfg, lr=1e-3)
+    want_loss, want_maps, want_coords = orc.step(x, tgt, jt, update=False)
+    net = net.cuda().train()
+    tr = HRNetTrainStep(net, lr=1e-3)
+    loss = tr.step(x.cuda(), tgt.cuda(), jt, update=False)
+    assert abs(float(loss.item()) - want_loss) < 5e-5 * abs(want_loss)
+    np.testing.assert_allclose(tr.last_coords.cpu().numpy(), want_coords.numpy(), rtol=0, atol=2e-5)
+    named = dict(net.named_parameters())
+    worst = 0.0
+    for k, gw in orc.grads().items():
+        e = _rel_err(named[k].grad.cpu().numpy(), gw.numpy())
+        worst = max(worst, e)
+        assert e < 5e-3, (k, e)
+    print('worst relative gradient error over %d tensors: %.2e' % (len(named), worst))

@@ -205,30 +205,32 @@ def _nhwc(t, cs):
     (2, 96, 48, 8, 8, 1, 1, 0),          # 1x1 fuse conv
     (2, 35, 66, 8, 8, 1, 2, 0),          # 1x1 stride-2 projection (head2)
     (6, 66, 66, 4, 4, 4, 1, 0),          # 4x4 valid conv of the coordinate head
+    (3, 10, 10, 4, 3, (4, 3), 1, 0),     # 4x3 valid conv (Pedestrian 64x48 maps)
 ])
 def test_conv_wgrad(n, cin, cout, h, w, k, stride, pad):
     L = _lib.lib()
     g = torch.Generator().manual_seed(n * 131 + cin)
     x = torch.randn(n, cin, h, w, generator=g)
-    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    kh, kw = k if isinstance(k, tuple) else (k, k)
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
     dy = torch.randn(n, cout, ho, wo, generator=g)
-    wt = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    wt = torch.zeros(cout, cin, kh, kw, dtype=torch.float64, requires_grad=True)
     torch.nn.functional.conv2d(x.double(), wt, None, stride, pad).backward(dy.double())
     cs_in, cs_out = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
     xd, dyd = _nhwc(x, cs_in).cuda(), _nhwc(dy, cs_out).cuda()
-    need = L.egn_conv2d_wgrad_ws_bytes(n, h, w, cin, cs_in, cout, cs_out, k, k, stride, pad)
+    need = L.egn_conv2d_wgrad_ws_bytes(n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad)
     assert need > 0
     ws = torch.zeros(need // 4, device='cuda')
-    dw = torch.full((cout, cin, k, k), 3.0, device='cuda')
+    dw = torch.full((cout, cin, kh, kw), 3.0, device='cuda')
     _lib.check(L.egn_conv2d_wgrad_f32(_lib.ptr(xd), _lib.ptr(dyd), _lib.ptr(dw), n, h, w, cin, cs_in, cout, cs_out,
-                                      k, k, stride, pad, _lib.ptr(ws), need, _st()))
+                                      kh, kw, stride, pad, _lib.ptr(ws), need, _st()))
     want = wt.grad
     tol = 2e-6 * float(want.abs().max()) * max(1.0, (n * ho * wo) ** 0.5 / 8)
     np.testing.assert_allclose(dw.cpu().numpy(), want.numpy(), rtol=0, atol=tol)
     # deterministic: a second launch gives the same bits
     dw2 = torch.zeros_like(dw)
     _lib.check(L.egn_conv2d_wgrad_f32(_lib.ptr(xd), _lib.ptr(dyd), _lib.ptr(dw2), n, h, w, cin, cs_in, cout, cs_out,
-                                      k, k, stride, pad, _lib.ptr(ws), need, _st()))
+                                      kh, kw, stride, pad, _lib.ptr(ws), need, _st()))
     assert torch.equal(dw, dw2)
 
 
@@ -326,7 +328,7 @@ def test_sigmoid_backward_and_l1_loss():
 def test_conv_wgrad_refuses_unsupported():
     L = _lib.lib()
     a = torch.zeros(64, device='cuda')
-    assert L.egn_conv2d_wgrad_ws_bytes(1, 8, 8, 4, 4, 4, 4, 2, 2, 1, 0) < 0           # 2x2 taps
+    assert L.egn_conv2d_wgrad_ws_bytes(1, 8, 8, 4, 4, 4, 4, 5, 5, 1, 0) < 0           # 25 taps
     assert L.egn_conv2d_wgrad_f32(_lib.ptr(a), _lib.ptr(a), _lib.ptr(a), 1, 8, 8, 4, 6, 4, 4, 3, 3, 1, 1,
                                   _lib.ptr(a), 256, _st()) != 0                       # cs_in % 4
 
