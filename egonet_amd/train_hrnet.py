@@ -280,6 +280,9 @@ class _Tape(object):
                                            _lib.ptr(bn.weight), _lib.ptr(bn.bias), relu, _lib.ptr(rd), _lib.ptr(dbeta),
                                            _lib.ptr(dgamma), _lib.ptr(dz), _lib.ptr(dres), rows, cout, z.cs, self.st),
                        'bn_bwd_dz')
+            if self.o.debug_hook is not None:
+                self.o.debug_hook(dict(tag=tag, dy=dy, z=zd, mean=mean, istd=istd, bn=bn, res=rd, dbeta=dbeta,
+                                       dgamma=dgamma, dz=dz, dres=dres, relu=relu, rows=rows, cols=cout, ld=z.cs))
             if dres is not None:
                 self._accum(res, dres)
             if weight.requires_grad:
@@ -348,6 +351,7 @@ class HRNetTrainStep(object):
         self.loss_dev = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.walker = HRNetEngine(model)
         self.last_maps = self.last_coords = None
+        self.debug_hook = None        # tools/train_debug.py: per-layer checks of the BatchNorm backward
 
     def wgrad_ws(self, nbytes):
         if self._wgrad_ws is None or self._wgrad_ws.numel() * 4 < nbytes:
@@ -412,4 +416,6 @@ class HRNetTrainStep(object):
             if update:
                 self.flat.adam_step(self.lr, self.betas, self.eps, st)
             m._engine = None          # the inference engine caches folded weights
+            if self.debug_hook is not None:
+                self.last_tape = tape
         return self.loss_dev

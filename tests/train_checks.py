@@ -1,0 +1,113 @@
+"""Launch-local checks of the native training tape (egonet_amd.train_hrnet).
+
+End-to-end gradient comparisons of a deep ReLU network in fp32 are limited by
+ReLU ties: an element whose pre-activation is within rounding of 0 gets gate 1
+in one implementation and 0 in another, and everything below it changes by a
+finite amount (measured on MI355X, tools/train_debug.py: HRNet-W48, 2 crops:
+99 of 30.8 M block-output gates differ from torch's own GPU autograd ->
+gradient cosine 0.99985; tiny net without a flipped gate: relative L2 1e-5).
+
+So the full-size parity test checks every backward launch IN PLACE: each
+weight-gradient, data-gradient and BatchNorm-backward launch of the step is
+recomputed in float64 on the CPU (torch conv autograd / the BatchNorm backward
+formulas) from the very tensors the launch consumed.  The composition of the
+launches (the tape wiring) is pinned by the small, flip-free cases against the
+reference's own iterations (tests/golden/hrnet_train.npz).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def rel(got, want):
+    return float(np.abs(got - want).max()) / max(float(np.abs(want).max()), 1e-30)
+
+
+def _nchw(t, n, h, w, cs, c):
+    return t.view(n, h, w, cs)[..., :c].permute(0, 3, 1, 2).double().cpu()
+
+
+class LayerChecks(object):
+    """Context manager: wraps the tape's wgrad / dgrad launches and the BatchNorm
+    backward hook of an ``HRNetTrainStep``; collects relative errors."""
+
+    def __init__(self, trainer):
+        self.tr = trainer
+        self.wgrad, self.dgrad, self.bn = [], [], []
+
+    def __enter__(self):
+        from egonet_amd import train_hrnet as T
+        self._T = T
+        self._orig = (T._Tape._wgrad, T._Tape._dgrad)
+        orig_w, orig_d = self._orig
+        me = self
+
+        def wgrad(tape, x, xd, dy, cs_out, weight, stride, pad):
+            orig_w(tape, x, xd, dy, cs_out, weight, stride, pad)
+            cout, cin, kh, kw = weight.shape
+            ho, wo = (x.h + 2 * pad - kh) // stride + 1, (x.w + 2 * pad - kw) // stride + 1
+            wt = torch.zeros(cout, cin, kh, kw, dtype=torch.float64, requires_grad=True)
+            with torch.enable_grad():
+                F.conv2d(_nchw(xd, x.n, x.h, x.w, x.cs, cin), wt, None, stride, pad).backward(
+                    _nchw(dy, x.n, ho, wo, cs_out, cout))
+            me.wgrad.append((rel(weight.grad.double().cpu().numpy(), wt.grad.numpy()),
+                             (x.n, x.h, x.w, cin, cout, kh, stride)))
+
+        def dgrad(tape, dy, ho, wo, cs_out, weight, stride, pad, x):
+            dx = orig_d(tape, dy, ho, wo, cs_out, weight, stride, pad, x)
+            cout, cin, kh, kw = weight.shape
+            xs = torch.zeros(x.n, cin, x.h, x.w, dtype=torch.float64, requires_grad=True)
+            with torch.enable_grad():
+                F.conv2d(xs, weight.detach().double().cpu(), None, stride, pad).backward(
+                    _nchw(dy, x.n, ho, wo, cs_out, cout))
+            e = rel(_nchw(dx, x.n, x.h, x.w, x.cs, cin).numpy(), xs.grad.numpy())
+            padmax = float(dx.view(x.n, x.h, x.w, x.cs)[..., cin:].abs().max()) if x.cs > cin else 0.0
+            me.dgrad.append((max(e, padmax), (x.n, x.h, x.w, cin, cout, kh, stride)))
+            return dx
+
+        T._Tape._wgrad, T._Tape._dgrad = wgrad, dgrad
+        self._prev_hook = self.tr.debug_hook
+        self.tr.debug_hook = self._bn_hook
+        return self
+
+    def __exit__(self, *exc):
+        self._T._Tape._wgrad, self._T._Tape._dgrad = self._orig
+        self.tr.debug_hook = self._prev_hook
+        return False
+
+    def _bn_hook(self, d):
+        rows, cols, ld = d['rows'], d['cols'], d['ld']
+
+        def v(t):
+            return t.view(rows, ld)[:, :cols].double().cpu()
+        z, dy = v(d['z']), v(d['dy'])
+        mean, istd = d['mean'].double().cpu(), d['istd'].double().cpu()
+        gm, bt = d['bn'].weight.detach().double().cpu(), d['bn'].bias.detach().double().cpu()
+        xhat = (z - mean) * istd
+        pre = gm * xhat + bt + (v(d['res']) if d['res'] is not None else 0)
+        dpre = dy * (pre > 0) if d['relu'] else dy
+        dbeta, dgamma = dpre.sum(0), (dpre * xhat).sum(0)
+        dz = gm * istd * (dpre - dbeta / rows - xhat * dgamma / rows)
+        errs = [rel(v(d['dz']).numpy(), dz.numpy()),
+                rel(d['dbeta'].double().cpu().numpy(), dbeta.numpy()),
+                rel(d['dgamma'].double().cpu().numpy(), dgamma.numpy()),
+                rel(v(d['dres']).numpy(), dpre.numpy()) if d['dres'] is not None else 0.0,
+                rel(mean.numpy(), z.mean(0).numpy()),
+                rel(istd.numpy(), (z.var(0, unbiased=False) + d['bn'].eps).rsqrt().numpy())]
+        self.bn.append((max(errs), d['tag'], (rows, cols, ld), errs))
+        if self._prev_hook is not None:
+            self._prev_hook(d)
+
+    def worst(self):
+        return {k: max([r[0] for r in getattr(self, k)] or [0.0]) for k in ('wgrad', 'dgrad', 'bn')}
+
+
+def gradient_agreement(named_params, oracle_grads):
+    """(global relative L2, cosine, median per-tensor relative L2) of the module's
+    .grad tensors against a dict of oracle gradients."""
+    a = np.concatenate([named_params[k].grad.cpu().numpy().ravel().astype(np.float64) for k in oracle_grads])
+    b = np.concatenate([oracle_grads[k].numpy().ravel().astype(np.float64) for k in oracle_grads])
+    per = [np.linalg.norm(named_params[k].grad.cpu().numpy().astype(np.float64) - oracle_grads[k].numpy())
+           / max(np.linalg.norm(oracle_grads[k].numpy().astype(np.float64)), 1e-30) for k in oracle_grads]
+    return (float(np.linalg.norm(a - b) / np.linalg.norm(b)),
+            float(a @ b / np.linalg.norm(a) / np.linalg.norm(b)), float(np.median(per)))
