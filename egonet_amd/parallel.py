@@ -108,6 +108,47 @@ class GradBuckets(object):
                 off += n
 
 
+class FlatGradSync(object):
+    """Gradient all-reduce (mean) over ONE flat gradient buffer, in place, in
+    slices of ``bucket_mb`` -- the ``grad_sync`` hook of the native training steps
+    (egonet_amd.train_hrnet.FlatParams keeps every gradient in one allocation,
+    so nothing is packed or copied).
+
+    The slices are issued back to front: the native backward fills the flat
+    buffer from its END (last layers first), so with ``async_op`` the early
+    collectives overlap what is still being reduced.  Replaces the per-step
+    parameter broadcast + output gather of ``torch.nn.DataParallel``
+    (tools/train_IGRs.py:59) by the one exchange step data parallelism needs.
+    xGMI is point to point: 32 MB slices keep every ring step well above the
+    latency floor without serialising the whole 256 MB HRNet gradient.
+    """
+
+    def __init__(self, bucket_mb=32.0, group=None):
+        self.group = group
+        self.bucket = max(1, int(bucket_mb * 2 ** 20) // 4)
+
+    def slices(self, numel):
+        out, hi = [], numel
+        while hi > 0:
+            lo = max(0, hi - self.bucket)
+            out.append((lo, hi))
+            hi = lo
+        return out
+
+    def __call__(self, flat):
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(self.group)
+        if world == 1:
+            return
+        pending = []
+        for lo, hi in self.slices(flat.numel()):
+            pending.append(dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for work in pending:
+            work.wait()
+        flat.div_(world)
+
+
 def broadcast_module(module, src=0, group=None):
     """Make every rank start from rank ``src``'s parameters and buffers."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:

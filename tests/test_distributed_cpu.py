@@ -77,3 +77,40 @@ def test_gloo_world2_gradient_allreduce_and_gather():
     # both ranks hold identical reduced gradients by construction; check they are
     # finite and that the reduction is the mean of two different local gradients
     assert np.isfinite(grads).all() and np.abs(grads).sum() > 0
+
+
+def _flat_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    n = 1000 + 37                                    # ragged against the slice size
+    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    sync = parallel.FlatGradSync(bucket_mb=4 * 100 / 2 ** 20)     # 100-float slices
+    sl = sync.slices(n)
+    assert sl[0] == (n - 100, n) and sl[-1][0] == 0 and len(sl) == 11            # back to front, covers all
+    sync(flat)
+    if rank == 0:
+        q.put(flat.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_flat_gradient_sync():
+    """The grad_sync hook of the native training steps: in-place mean all-reduce of
+    the flat gradient buffer in back-to-front slices."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flat_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    flat = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_allclose(flat, np.arange(1037, dtype=np.float32) * 1.5)
+
+
+def test_flat_gradient_sync_is_a_noop_without_a_process_group():
+    flat = torch.ones(10)
+    parallel.FlatGradSync()(flat)
+    assert torch.equal(flat, torch.ones(10))
