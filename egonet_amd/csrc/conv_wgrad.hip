@@ -22,6 +22,7 @@
 // spread over the waves of a block (3x3: nine waves share one staged dy tile
 // and one x halo tile), so the tap shift is only an LDS address offset.
 #include <algorithm>
+#include <cstdlib>
 
 #include "egn_internal.h"
 #include "conv_common.h"
@@ -155,17 +156,26 @@ __global__ __launch_bounds__(64 * NTAPW * WM * WN) void conv_wgrad_kernel(WgradA
 }
 
 // dw[co][ci][tap] = sum_s part[s][tap][co][ci]   (fixed order: deterministic)
+// block = 64 elements x 4 split lanes: lane l sums splits l, l+4, ...; the four
+// lane sums are combined in lane order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                            int nsplit, int taps, int Cout, int Cin, int CoP, int CiP) {
+  __shared__ float red[4][64];
   const size_t total = (size_t)taps * Cout * Cin;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const int ci = (int)(e % Cin);
-    const int co = (int)((e / Cin) % Cout);
-    const int tap = (int)(e / ((size_t)Cin * Cout));
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += part[((size_t)(k * taps + tap) * CoP + co) * CiP + ci];
-    dw[((size_t)co * Cin + ci) * taps + tap] = s;
+  const int el = threadIdx.x & 63, lane = threadIdx.x >> 6;
+  const size_t e = (size_t)blockIdx.x * 64 + el;
+  float s = 0.f;
+  int ci = 0, co = 0, tap = 0;
+  if (e < total) {
+    ci = (int)(e % Cin);
+    co = (int)((e / Cin) % Cout);
+    tap = (int)(e / ((size_t)Cin * Cout));
+    for (int k = lane; k < nsplit; k += 4) s += part[((size_t)(k * taps + tap) * CoP + co) * CiP + ci];
   }
+  red[lane][el] = s;
+  __syncthreads();
+  if (lane == 0 && e < total)
+    dw[((size_t)co * Cin + ci) * taps + tap] = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
 }
 
 static int ilog2_exact(int v) {
@@ -178,6 +188,8 @@ static int pow2_ceil(int v) {
   while (p < v) p <<= 1;
   return p;
 }
+
+constexpr int EGN_WGRAD_MAX_SPLITS = 512;
 
 struct WgradVariant {
   int ntapw, tpw, wm, wn;
@@ -233,8 +245,15 @@ static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
   const int tiles_b = (a.N + a.TNB - 1) / a.TNB;
   a.ntiles = a.tiles_x * a.tiles_y * tiles_b;
   const int base = a.co_tiles * a.ci_tiles;
-  int want = (768 + base - 1) / base;  // ~3 blocks per CU
-  want = std::max(1, std::min(std::min(want, a.ntiles), 64));
+  // blocks the launch should have: ~2 per CU; more splits = more partial traffic
+  // (each split writes taps*CoP*CiP floats), fewer = idle CUs
+  static const int target = [] {
+    const char* e = getenv("EGN_WGRAD_BLOCKS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 512;
+  }();
+  int want = (target + base - 1) / base;
+  want = std::max(1, std::min(std::min(want, a.ntiles), EGN_WGRAD_MAX_SPLITS));
   a.tiles_per_split = (a.ntiles + want - 1) / want;
   a.nsplit = (a.ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
   return 0;
@@ -281,9 +300,7 @@ extern "C" int egn_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
   else rc = wgrad_launch<1, 1, 1, 1>(a, lds, st);
   if (rc != 0) return rc;
   const size_t total = (size_t)a.taps * Cout * Cin;
-  size_t g = (total + 255) / 256;
-  if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, a.part, dw, a.nsplit, a.taps, Cout, Cin,
-                     a.CoP, a.CiP);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, a.part, dw, a.nsplit,
+                     a.taps, Cout, Cin, a.CoP, a.CiP);
   return (int)hipGetLastError();
 }

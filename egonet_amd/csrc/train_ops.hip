@@ -203,14 +203,28 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(ColArgs p, doubl
   }
 }
 
-// stage 2: one thread per column combines the partials and finalises
+// stage 2: a block combines the partials of 8 columns with 32 split lanes each
+// (fixed association order: lane-strided sums, then the lanes in order) and finalises
 __global__ __launch_bounds__(256) void colreduce_final_kernel(ColArgs p, const double* __restrict__ ws) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ double r0[32][9];
+  __shared__ double r1[32][9];
+  const int cl = threadIdx.x & 7, sl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  double a0 = 0.0, a1 = 0.0;
   if (c < p.cols) {
+    for (int k = sl; k < p.nsplit; k += 32) {
+      a0 += ws[((size_t)k * 2 + 0) * p.cols + c];
+      a1 += ws[((size_t)k * 2 + 1) * p.cols + c];
+    }
+  }
+  r0[sl][cl] = a0;
+  r1[sl][cl] = a1;
+  __syncthreads();
+  if (sl == 0 && c < p.cols) {
     double t0 = 0.0, t1 = 0.0;
-    for (int k = 0; k < p.nsplit; ++k) {
-      t0 += ws[((size_t)k * 2 + 0) * p.cols + c];
-      t1 += ws[((size_t)k * 2 + 1) * p.cols + c];
+    for (int k = 0; k < 32; ++k) {
+      t0 += r0[k][cl];
+      t1 += r1[k][cl];
     }
     if (p.mode == 0) {
       p.out0[c] = (float)t0;
@@ -247,7 +261,7 @@ static int launch_col(ColArgs& p, double* ws, void* stream) {
   if (p.nsplit > EGN_COL_MAX_SPLITS) p.nsplit = EGN_COL_MAX_SPLITS;
   if (p.nsplit < 1) p.nsplit = 1;
   hipLaunchKernelGGL(colreduce_partial_kernel, dim3(gx, p.nsplit), dim3(256), 0, (hipStream_t)stream, p, ws);
-  hipLaunchKernelGGL(colreduce_final_kernel, dim3((p.cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, p, ws);
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3((p.cols + 7) / 8), dim3(256), 0, (hipStream_t)stream, p, ws);
   return (int)hipGetLastError();
 }
 
