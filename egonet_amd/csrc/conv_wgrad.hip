@@ -41,10 +41,16 @@ struct WgradArgs {
   int co_tiles, ci_tiles, CoP, CiP;
 };
 
-template <int NTAPW, int TPW, int WM, int WN>
+// J = channels per lane and operand (4: 64-wide tiles, ds_read_b128; 3: 48-wide
+// tiles for the 48 / 96 channel branches, 9 instead of 16 MFMAs per K step).
+// PF = software pipeline: the next pixel tile's global loads are issued into
+// registers before the MFMA loop of the current one (A_IT / B_IT float4 per lane).
+template <int NTAPW, int TPW, int WM, int WN, int J, int A_IT, int B_IT>
 __global__ __launch_bounds__(64 * NTAPW * WM * WN) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int NT = 64 * NTAPW * WM * WN;
-  constexpr int CW = 64 * WM, IW = 64 * WN;
+  constexpr int WT = 16 * J;                 // channels per wave tile
+  constexpr int CW = WT * WM, IW = WT * WN;  // channels per block tile
+  constexpr int CW4 = CW / 4, IW4 = IW / 4;
   constexpr int LDA = CW + 4, LDB = IW + 4;  // +4 floats: rows stay 16 B aligned, banks rotate
   extern __shared__ float wsm[];
   float* sA = wsm;                // [TP][LDA]   dy tile
@@ -63,13 +69,13 @@ __global__ __launch_bounds__(64 * NTAPW * WM * WN) void conv_wgrad_kernel(WgradA
   const int cit = blockIdx.x / a.co_tiles;
   const int co0 = cot * CW, ci0 = cit * IW;
 
-  f32x4 acc[TPW][4][4];
+  f32x4 acc[TPW][J][J];
 #pragma unroll
   for (int t = 0; t < TPW; ++t)
 #pragma unroll
-    for (int ja = 0; ja < 4; ++ja)
+    for (int ja = 0; ja < J; ++ja)
 #pragma unroll
-      for (int jb = 0; jb < 4; ++jb) acc[t][ja][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int jb = 0; jb < J; ++jb) acc[t][ja][jb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   int tap_off[TPW];  // LDS pixel offset of this wave's taps inside the halo tile (-1: no such tap)
 #pragma unroll
@@ -83,73 +89,108 @@ __global__ __launch_bounds__(64 * NTAPW * WM * WN) void conv_wgrad_kernel(WgradA
   const int thw_mask = (1 << a.lg_thw) - 1;
   const int tw_mask = a.TW - 1;
   const int hpi = a.HH * a.HWd;  // halo pixels per image
+  const int a_elems = a.TP * CW4, b_elems = a.NHP * IW4;
 
+  float4 ra[A_IT], rb[B_IT];
+
+// global -> registers for pixel tile TILE (zeros outside the image / batch / channels)
+#define EGN_WG_LOAD(TILE)                                                                               \
+  {                                                                                                     \
+    const int tx_ = (TILE) % a.tiles_x;                                                                 \
+    const int ty_ = ((TILE) / a.tiles_x) % a.tiles_y;                                                   \
+    const int tb_ = (TILE) / (a.tiles_x * a.tiles_y);                                                   \
+    const int nb_ = tb_ * a.TNB, oy0_ = ty_ * a.TH, ox0_ = tx_ * a.TW;                                  \
+    _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                               \
+      const int e = tid + it * NT;                                                                      \
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+      if (e < a_elems) {                                                                                \
+        const int p = e / CW4, c4 = e - p * CW4;                                                        \
+        const int b = p >> a.lg_thw, rem = p & thw_mask;                                                \
+        const int n = nb_ + b, oy = oy0_ + (rem >> a.lg_tw), ox = ox0_ + (rem & tw_mask);               \
+        const int c = co0 + 4 * c4;                                                                     \
+        if (n < a.N && oy < a.Ho && ox < a.Wo && c < a.cs_out)                                          \
+          v = *reinterpret_cast<const float4*>(a.dy + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.cs_out + c); \
+      }                                                                                                 \
+      ra[it] = v;                                                                                       \
+    }                                                                                                   \
+    _Pragma("unroll") for (int it = 0; it < B_IT; ++it) {                                               \
+      const int e = tid + it * NT;                                                                      \
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                       \
+      if (e < b_elems) {                                                                                \
+        const int hp = e / IW4, c4 = e - hp * IW4;                                                      \
+        const int b = hp / hpi, r = hp - b * hpi;                                                       \
+        const int hy = r / a.HWd, hx = r - hy * a.HWd;                                                  \
+        const int n = nb_ + b;                                                                          \
+        const int iy = oy0_ * a.stride - a.pad + hy, ix = ox0_ * a.stride - a.pad + hx;                 \
+        const int c = ci0 + 4 * c4;                                                                     \
+        if (n < a.N && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.cs_in)                       \
+          v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.cs_in + c); \
+      }                                                                                                 \
+      rb[it] = v;                                                                                       \
+    }                                                                                                   \
+  }
+
+  if (t_begin < t_end) EGN_WG_LOAD(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {
-    const int tx = tile % a.tiles_x;
-    const int ty = (tile / a.tiles_x) % a.tiles_y;
-    const int tb = tile / (a.tiles_x * a.tiles_y);
-    const int n_base = tb * a.TNB, oy0 = ty * a.TH, ox0 = tx * a.TW;
     __syncthreads();  // the previous tile's fragments are consumed
-    // dy tile: rows of pixels outside the image / batch are zero
-    for (int e = tid; e < a.TP * (CW / 4); e += NT) {
-      const int p = e / (CW / 4), c4 = e - p * (CW / 4);
-      const int b = p >> a.lg_thw, rem = p & thw_mask;
-      const int n = n_base + b, oy = oy0 + (rem >> a.lg_tw), ox = ox0 + (rem & tw_mask);
-      const int c = co0 + 4 * c4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b < a.TNB && n < a.N && oy < a.Ho && ox < a.Wo && c < a.cs_out)
-        v = *reinterpret_cast<const float4*>(a.dy + ((size_t)(n * a.Ho + oy) * a.Wo + ox) * a.cs_out + c);
-      *reinterpret_cast<float4*>(sA + p * LDA + 4 * c4) = v;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int e = tid + it * NT;
+      if (e < a_elems) {
+        const int p = e / CW4, c4 = e - p * CW4;
+        *reinterpret_cast<float4*>(sA + p * LDA + 4 * c4) = ra[it];
+      }
     }
-    // x halo tile: padding and everything outside the image is zero
-    for (int e = tid; e < a.NHP * (IW / 4); e += NT) {
-      const int hp = e / (IW / 4), c4 = e - hp * (IW / 4);
-      const int b = hp / hpi, r = hp - b * hpi;
-      const int hy = r / a.HWd, hx = r - hy * a.HWd;
-      const int n = n_base + b;
-      const int iy = oy0 * a.stride - a.pad + hy, ix = ox0 * a.stride - a.pad + hx;
-      const int c = ci0 + 4 * c4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n < a.N && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.cs_in)
-        v = *reinterpret_cast<const float4*>(a.x + ((size_t)(n * a.H + iy) * a.W + ix) * a.cs_in + c);
-      *reinterpret_cast<float4*>(sB + hp * LDB + 4 * c4) = v;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int e = tid + it * NT;
+      if (e < b_elems) {
+        const int hp = e / IW4, c4 = e - hp * IW4;
+        *reinterpret_cast<float4*>(sB + hp * LDB + 4 * c4) = rb[it];
+      }
     }
     __syncthreads();
-    const float* pa = sA + wm * 64 + 4 * li;
-    const float* pb = sB + wn * 64 + 4 * li;
+    if (tile + 1 < t_end) EGN_WG_LOAD(tile + 1);  // in flight during the MFMA loop below
+    const float* pa = sA + wm * WT + J * li;
+    const float* pb = sB + wn * WT + J * li;
 #pragma unroll 2
     for (int s = 0; s < a.TP / 4; ++s) {
       const int p = 4 * s + kq;
       const int b = p >> a.lg_thw, rem = p & thw_mask;
       const int hbase = (b * a.HH + (rem >> a.lg_tw) * a.stride) * a.HWd + (rem & tw_mask) * a.stride;
-      const f32x4 av = *reinterpret_cast<const f32x4*>(pa + p * LDA);
+      float av[J];
+#pragma unroll
+      for (int j = 0; j < J; ++j) av[j] = pa[p * LDA + j];
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
         if (tap_off[t] >= 0) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(pb + (hbase + tap_off[t]) * LDB);
+          float bv[J];
 #pragma unroll
-          for (int ja = 0; ja < 4; ++ja)
+          for (int j = 0; j < J; ++j) bv[j] = pb[(hbase + tap_off[t]) * LDB + j];
 #pragma unroll
-            for (int jb = 0; jb < 4; ++jb)
+          for (int ja = 0; ja < J; ++ja)
+#pragma unroll
+            for (int jb = 0; jb < J; ++jb)
               acc[t][ja][jb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ja], bv[jb], acc[t][ja][jb], 0, 0, 0);
         }
       }
     }
   }
+#undef EGN_WG_LOAD
 
-  // partial [split][tap][CoP][CiP]: lane owns rows 4*(4kq+r)+ja, columns 4li..4li+3
+  // partial [split][tap][CoP][CiP]: lane owns rows J*(4kq+r)+ja, columns J*li .. J*li+J-1
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int tap = tapw + t * NTAPW;
     if (tap < a.taps) {
-      float* dst = a.part + ((size_t)(blockIdx.y * a.taps + tap) * a.CoP + co0 + wm * 64) * a.CiP + ci0 + wn * 64 + 4 * li;
+      float* dst = a.part + ((size_t)(blockIdx.y * a.taps + tap) * a.CoP + co0 + wm * WT) * a.CiP + ci0 + wn * WT + J * li;
 #pragma unroll
-      for (int ja = 0; ja < 4; ++ja)
+      for (int ja = 0; ja < J; ++ja)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = 4 * (4 * kq + r) + ja;
-          *reinterpret_cast<float4*>(dst + (size_t)row * a.CiP) =
-              make_float4(acc[t][ja][0][r], acc[t][ja][1][r], acc[t][ja][2][r], acc[t][ja][3][r]);
+          float* q = dst + (size_t)(J * (4 * kq + r) + ja) * a.CiP;
+#pragma unroll
+          for (int jb = 0; jb < J; ++jb) q[jb] = acc[t][ja][jb][r];
         }
     }
   }
@@ -193,7 +234,16 @@ constexpr int EGN_WGRAD_MAX_SPLITS = 512;
 
 struct WgradVariant {
   int ntapw, tpw, wm, wn;
+  int j, a_it, b_it;  // channels per lane, register-staging depth (float4 per lane) of the dy / x tiles
 };
+
+static int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+// 48-wide (J = 3) or 64-wide (J = 4) wave tiles: whichever pads Cout x Cin less
+static int pick_j(int cout, int cin, int wm, int wn) {
+  const long c3 = (long)pad_to(cout, 48 * wm) * pad_to(cin, 48 * wn);
+  const long c4 = (long)pad_to(cout, 64 * wm) * pad_to(cin, 64 * wn);
+  return c3 < c4 ? 3 : 4;
+}
 
 static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
   if (a.N <= 0 || a.H <= 0 || a.W <= 0 || a.Cin <= 0 || a.Cout <= 0 || a.KH <= 0 || a.KW <= 0 || a.stride <= 0 ||
@@ -204,18 +254,19 @@ static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
   if (a.Ho <= 0 || a.Wo <= 0) return EGN_E_BADARG;
   a.taps = a.KH * a.KW;
   if (a.taps == 1) {
-    v = (a.Cout > 64 && a.Cin > 64) ? WgradVariant{1, 1, 2, 2}
-        : (a.Cout > 64)             ? WgradVariant{1, 1, 2, 1}
-        : (a.Cin > 64)              ? WgradVariant{1, 1, 1, 2}
-                                    : WgradVariant{1, 1, 1, 1};
+    v = (a.Cout > 64 && a.Cin > 64) ? WgradVariant{1, 1, 2, 2, 4, 4, 4}
+        : (a.Cout > 64)             ? WgradVariant{1, 1, 2, 1, 4, 8, 4}
+        : (a.Cin > 64)              ? WgradVariant{1, 1, 1, 2, 4, 4, 8}
+                                    : WgradVariant{1, 1, 1, 1, pick_j(a.Cout, a.Cin, 1, 1), 8, 8};
   } else if (a.taps <= 9) {
-    v = WgradVariant{9, 1, 1, 1};  // waves whose tap does not exist idle
+    v = WgradVariant{9, 1, 1, 1, pick_j(a.Cout, a.Cin, 1, 1), 2, 5};  // waves whose tap does not exist idle
   } else if (a.taps <= 16) {
-    v = WgradVariant{8, 2, 1, 1};
+    v = WgradVariant{8, 2, 1, 1, pick_j(a.Cout, a.Cin, 1, 1), 2, 5};
   } else {
     return EGN_E_BADARG;
   }
-  const int CW = 64 * v.wm, IW = 64 * v.wn;
+  const int NT = 64 * v.ntapw * v.wm * v.wn;
+  const int CW = 16 * v.j * v.wm, IW = 16 * v.j * v.wn;
   a.co_tiles = (a.Cout + CW - 1) / CW;
   a.ci_tiles = (a.Cin + IW - 1) / IW;
   a.CoP = a.co_tiles * CW;
@@ -231,11 +282,12 @@ static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
     a.TP = a.TNB * a.TH * a.TW;
     a.NHP = a.TNB * a.HH * a.HWd;
     lds = ((size_t)a.TP * (CW + 4) + (size_t)a.NHP * (IW + 4)) * sizeof(float);
-    if (lds <= budget) break;
+    const bool regs_ok = a.TP * (CW / 4) <= v.a_it * NT && a.NHP * (IW / 4) <= v.b_it * NT;
+    if (lds <= budget && regs_ok) break;
     if (a.TNB > 1 && a.TNB * a.TH * a.TW > 4) a.TNB /= 2;
     else if (a.TH > 1 && a.TH >= a.TW) a.TH /= 2;
     else if (a.TW > 1) a.TW /= 2;
-    else if (lds <= 150 * 1024) break;
+    else if (lds <= 150 * 1024 && regs_ok) break;
     else return EGN_E_BADARG;
   }
   a.lg_tw = ilog2_exact(a.TW);
@@ -250,7 +302,7 @@ static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
   static const int target = [] {
     const char* e = getenv("EGN_WGRAD_BLOCKS");
     const int v = e ? atoi(e) : 0;
-    return v > 0 ? v : 512;
+    return v > 0 ? v : 256;
   }();
   int want = (target + base - 1) / base;
   want = std::max(1, std::min(std::min(want, a.ntiles), EGN_WGRAD_MAX_SPLITS));
@@ -259,9 +311,9 @@ static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
   return 0;
 }
 
-template <int NTAPW, int TPW, int WM, int WN>
+template <int NTAPW, int TPW, int WM, int WN, int J, int A_IT, int B_IT>
 static int wgrad_launch(const WgradArgs& a, size_t lds, hipStream_t stream) {
-  auto k = conv_wgrad_kernel<NTAPW, TPW, WM, WN>;
+  auto k = conv_wgrad_kernel<NTAPW, TPW, WM, WN, J, A_IT, B_IT>;
   if (lds > 64 * 1024) EGN_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k, dim3(a.co_tiles * a.ci_tiles, a.nsplit), dim3(64 * NTAPW * WM * WN), lds, stream, a);
   return (int)hipGetLastError();
@@ -292,12 +344,12 @@ extern "C" int egn_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
   if (rc != 0) return rc;
   if ((size_t)ws_bytes < (size_t)a.nsplit * a.taps * a.CoP * a.CiP * sizeof(float)) return EGN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (v.ntapw == 9) rc = wgrad_launch<9, 1, 1, 1>(a, lds, st);
-  else if (v.ntapw == 8) rc = wgrad_launch<8, 2, 1, 1>(a, lds, st);
-  else if (v.wm == 2 && v.wn == 2) rc = wgrad_launch<1, 1, 2, 2>(a, lds, st);
-  else if (v.wm == 2) rc = wgrad_launch<1, 1, 2, 1>(a, lds, st);
-  else if (v.wn == 2) rc = wgrad_launch<1, 1, 1, 2>(a, lds, st);
-  else rc = wgrad_launch<1, 1, 1, 1>(a, lds, st);
+  if (v.ntapw == 9) rc = v.j == 3 ? wgrad_launch<9, 1, 1, 1, 3, 2, 5>(a, lds, st) : wgrad_launch<9, 1, 1, 1, 4, 2, 5>(a, lds, st);
+  else if (v.ntapw == 8) rc = v.j == 3 ? wgrad_launch<8, 2, 1, 1, 3, 2, 5>(a, lds, st) : wgrad_launch<8, 2, 1, 1, 4, 2, 5>(a, lds, st);
+  else if (v.wm == 2 && v.wn == 2) rc = wgrad_launch<1, 1, 2, 2, 4, 4, 4>(a, lds, st);
+  else if (v.wm == 2) rc = wgrad_launch<1, 1, 2, 1, 4, 8, 4>(a, lds, st);
+  else if (v.wn == 2) rc = wgrad_launch<1, 1, 1, 2, 4, 4, 8>(a, lds, st);
+  else rc = v.j == 3 ? wgrad_launch<1, 1, 1, 1, 3, 8, 8>(a, lds, st) : wgrad_launch<1, 1, 1, 1, 4, 8, 8>(a, lds, st);
   if (rc != 0) return rc;
   const size_t total = (size_t)a.taps * Cout * Cin;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, a.part, dw, a.nsplit,
