@@ -84,5 +84,42 @@ def modify_bbox(bbox, target_ar, enlarge=1.1):
     return resize_bbox(box[0], box[1], box[2], box[3], target_ar=target_ar)
 
 
+def generate_target_batch(joints, joints_vis, parameters, device=None, stream=None):
+    """Heat-map targets of a whole batch on the GPU (csrc/targets.hip): the
+    reference's per-sample ``generate_target`` (img_proc.py:347-409) for
+    ``joints`` [N,K,>=2] (input-image pixels) and ``joints_vis`` [N,K].
+    Returns CUDA tensors ``(target [N,K,hs[0],hs[1]], target_weight [N,K,1])``."""
+    if parameters.get('target_type', 'gaussian') != 'gaussian':
+        raise AssertionError('Only support gaussian map now!')
+    if parameters.get('use_different_joints_weight'):
+        raise NotImplementedError('use_different_joints_weight')
+    L = _lib.lib()
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+    j = torch.as_tensor(np.asarray(joints) if not torch.is_tensor(joints) else joints)
+    n, k = j.shape[:2]
+    j3 = torch.zeros(n, k, 3, dtype=torch.float64, device=device)
+    j3[..., :2] = j[..., :2].to(device=device, dtype=torch.float64)
+    vis = torch.as_tensor(np.asarray(joints_vis) if not torch.is_tensor(joints_vis) else joints_vis)
+    vis = vis.reshape(n, k).to(device=device, dtype=torch.float32).contiguous()
+    inp, hs = parameters['input_size'], parameters['heatmap_size']
+    rows, cols = int(hs[0]), int(hs[1])
+    target = torch.empty(n, k, rows, cols, dtype=torch.float32, device=device)
+    weight = torch.empty(n, k, 1, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        st = _lib.current_stream(device) if stream is None else stream
+        _lib.check(L.egn_gaussian_targets_f32(_lib.ptr(j3), _lib.ptr(vis), n, k, rows, cols,
+                                              float(inp[0]) / float(hs[0]), float(inp[1]) / float(hs[1]),
+                                              float(parameters['sigma']), _lib.ptr(target), _lib.ptr(weight), st),
+                   'gaussian targets')
+    return target, weight
+
+
+def generate_target(joints, joints_vis, parameters):
+    """One sample, numpy in / numpy out like the reference (img_proc.py:347-409);
+    computed on the GPU."""
+    t, w = generate_target_batch(np.asarray(joints)[None], np.asarray(joints_vis)[None], parameters)
+    return t[0].cpu().numpy(), w[0].cpu().numpy()
+
+
 def to_npy(tensor):
     return tensor if isinstance(tensor, np.ndarray) else tensor.data.cpu().numpy()

@@ -327,7 +327,8 @@ class _Tape(object):
 class HRNetTrainStep(object):
     """``step(images, target, joints_xy)`` = one iteration of trainer.py:183-209."""
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, w_hm=1.0, w_coor=0.1, grad_sync=None):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, w_hm=1.0, w_coor=0.1, grad_sync=None,
+                 sigma=1):
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise ValueError('HRNetTrainStep needs the model on a GPU')
@@ -342,6 +343,8 @@ class HRNetTrainStep(object):
         self.lr, self.betas, self.eps = lr, betas, eps
         self.w_hm, self.w_coor = float(w_hm), float(w_coor or 0.0)
         self.grad_sync = grad_sync
+        self.sigma = sigma            # heatmapModel.sigma: targets drawn on the device when step(target=None)
+        self.last_target_weight = None
         self.flat = FlatParams(model.parameters())
         widest = max(p.shape[0] for p in model.parameters()) + 32
         self.ones = torch.ones(_round_up(widest, 16), dtype=torch.float32, device=self.dev)
@@ -359,15 +362,17 @@ class HRNetTrainStep(object):
         return self._wgrad_ws
 
     @torch.no_grad()
-    def step(self, images, target, joints_xy=None, update=True):
-        """images [N,3,H,W], target [N,K,h,w] heat-maps, joints_xy [N,K,2] in input
-        pixels (``meta['transformed_joints'][:, :, :2]``).  Returns the loss as a
-        1-element float64 device tensor (no host sync)."""
+    def step(self, images, target, joints_xy=None, update=True, joints_vis=None):
+        """images [N,3,H,W], target [N,K,h,w] heat-maps (None: drawn on the device from
+        joints_xy / joints_vis with ``self.sigma``), joints_xy [N,K,2] in input pixels
+        (``meta['transformed_joints'][:, :, :2]``).  Returns the loss as a 1-element
+        float64 device tensor (no host sync)."""
         m, L = self.model, self.L
         if not m.training:
             raise RuntimeError('HRNetTrainStep.step needs model.train()')
         images = images.contiguous().float()
-        target = target.contiguous().float()
+        if target is not None:
+            target = target.contiguous().float()
         n, cin, h, w = images.shape
         if h % 32 or w % 32:
             raise ValueError('HRNet input height/width must be multiples of 32, got %dx%d' % (h, w))
@@ -400,6 +405,19 @@ class HRNetTrainStep(object):
             else:
                 aug = tape.named['final_layer']
                 self.last_maps = tape.user['final_layer']
+            if target is None:
+                # heat-map targets drawn on the device from the joints (img_proc.py:347-409):
+                # the [N,K,h,w] target never crosses PCIe
+                if joints_xy is None:
+                    raise ValueError('step() needs target heat-maps or joints_xy to draw them from')
+                if aug.h != aug.w or h != w:
+                    raise NotImplementedError('device-side targets: square maps only (the reference mixes the '
+                                              'width/height indices of input_size / heatmap_size, img_proc.py:376-383)')
+                from .common import img_proc
+                target, self.last_target_weight = img_proc.generate_target_batch(
+                    joints_xy, torch.ones(n, J) if joints_vis is None else joints_vis,
+                    dict(target_type='gaussian', input_size=(w, h), heatmap_size=(aug.h, aug.w), sigma=self.sigma),
+                    device=self.dev)
             if tuple(target.shape) != (n, J, aug.h, aug.w):
                 raise ValueError('target must be %s, got %s' % ((n, J, aug.h, aug.w), tuple(target.shape)))
             tg = tape._empty(n * aug.h * aug.w * aug.cs)

@@ -238,6 +238,17 @@ int egn_zero_insert2_f32(const float* dy, float* up, int N, int Ho, int Wo,
  * block sums of dy*(y>0) (y NULL: no gate) */
 int egn_fuse_bwd_f32(const float* dy, const float* y, float* g, int N, int H,
                      int W, int cs, int shift, void* stream);
+/* Heat-map training targets for a whole batch (img_proc.py:347-409
+ * generate_target): an un-normalised Gaussian dot of half-width 3*sigma centred
+ * on cell int(joint/stride + 0.5) of every visible joint, clipped to the map.
+ *   joints [N,K,3] f64 (x, y, unused) in input pixels; vis [N,K] f32 or NULL
+ *   target [N,K,H,W] f32 out; weight [N,K] f32 out (vis, zeroed where the dot
+ *   is completely out of bounds), may be NULL
+ *   stride_x = input_size[0]/heatmap_size[0], stride_y = input_size[1]/heatmap_size[1] */
+int egn_gaussian_targets_f32(const double* joints, const float* vis, int N, int K,
+                             int H, int W, double stride_x, double stride_y,
+                             double sigma, float* target, float* weight,
+                             void* stream);
 /* running = (1-momentum)*running + momentum*batch */
 int egn_ema_f32(float* running, const float* batch, float momentum, int n,
                 void* stream);

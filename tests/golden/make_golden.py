@@ -137,6 +137,32 @@ def main():
         arrs['p2/' + k] = fin[k].numpy().copy()
     arrs['losses'] = np.array(losses)
     save('hrnet_train.npz', **arrs)
+    # ---- 0b: Gaussian heat-map targets by the reference's generate_target
+    #          (img_proc.py:347-409): joints inside, on the border, outside, negative,
+    #          invisible; sigma 1 (shipped configs) and 2; square and 64x48-style maps
+    gj = torch.Generator().manual_seed(5)
+    tcases = {}
+    for tag, inp, hm_, sig in (('s1', (256, 256), (64, 64), 1), ('s2', (256, 256), (64, 64), 2),
+                               ('rect', (256, 192), (64, 48), 1)):
+        jts = (torch.rand(3, 12, 3, generator=gj, dtype=torch.float64) * 1.3 - 0.15).numpy() * np.array([inp[0], inp[1], 1.0])
+        jts[0, 0, :2] = [0.0, 0.0]
+        jts[0, 1, :2] = [inp[0] - 1.0, inp[1] - 1.0]
+        jts[0, 2, :2] = [-30.0, 40.0]          # dot completely left of the map -> weight 0
+        jts[0, 3, :2] = [-7.9, 40.0]           # partially inside
+        jts[0, 4, :2] = [inp[0] + 11.9, 5.0]
+        vis = (torch.rand(3, 12, generator=gj) > 0.2).float().numpy()
+        vis[0, :5] = 1.0
+        prm = dict(num_joints=12, target_type='gaussian', input_size=np.array(inp), heatmap_size=np.array(hm_),
+                   sigma=sig, use_different_joints_weight=False)
+        outs = [ref_ip.generate_target(jts[i], vis[i], prm) for i in range(3)]
+        tcases[tag + '/joints'] = jts
+        tcases[tag + '/vis'] = vis
+        tcases[tag + '/input_size'] = np.array(inp)
+        tcases[tag + '/heatmap_size'] = np.array(hm_)
+        tcases[tag + '/sigma'] = np.array(sig)
+        tcases[tag + '/target'] = np.stack([o[0] for o in outs])
+        tcases[tag + '/weight'] = np.stack([o[1] for o in outs])
+    save('targets.npz', **tcases)
     if '--train-only' in sys.argv:
         return
 

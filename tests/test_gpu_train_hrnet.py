@@ -124,6 +124,26 @@ def test_frozen_prefix_gets_no_gradient_and_no_update():
     assert not torch.equal(after['bn1.running_mean'], before['bn1.running_mean'])   # train-mode BN still tracks
 
 
+def test_targets_drawn_on_the_device_give_the_same_step():
+    """step(target=None) draws the Gaussian maps from the joints on the GPU
+    (img_proc.py:347-409); same loss as with the oracle's host-side maps."""
+    from oracle import targets_oracle
+    cfg = configs.tiny_config('coordinates')
+    gen = torch.Generator().manual_seed(6)
+    x = synth.synth_crops(3, 3, 64, 64, seed=4).cuda()
+    jt = torch.rand(3, 5, 2, generator=gen, dtype=torch.float64) * 80 - 8          # some joints off the crop
+    vis = (torch.rand(3, 5, generator=gen) > 0.2).float()
+    maps, w = targets_oracle.generate_target_batch(jt.numpy(), vis.numpy(), (64, 64), (16, 16), 1)
+    losses = []
+    for target in (torch.from_numpy(maps).cuda(), None):
+        net, _ = _tiny_model(cfg, seed=9)
+        tr = HRNetTrainStep(net, lr=1e-3, sigma=1)
+        losses.append(float(tr.step(x, target, jt, joints_vis=vis).item()))
+        if target is None:
+            np.testing.assert_array_equal(tr.last_target_weight.cpu().numpy(), w)
+    assert abs(losses[0] - losses[1]) < 1e-6 * abs(losses[0])
+
+
 def test_inference_after_training_uses_the_updated_weights():
     cfg = configs.tiny_config('coordinates')
     net, _ = _tiny_model(cfg, seed=9)

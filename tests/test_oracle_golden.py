@@ -149,6 +149,20 @@ def test_pose_oracle_cuboids():
                                g['alpha_trans'], atol=1e-9)
 
 
+@pytest.mark.parametrize('tag', ['s1', 's2', 'rect'])
+def test_target_oracle_vs_reference_generate_target(tag):
+    from oracle import targets_oracle
+    g = golden('targets.npz')
+    tgt, w = targets_oracle.generate_target_batch(g[tag + '/joints'], g[tag + '/vis'], g[tag + '/input_size'],
+                                                  g[tag + '/heatmap_size'], int(g[tag + '/sigma']))
+    assert tgt.dtype == np.float32 and tgt.shape == g[tag + '/target'].shape
+    np.testing.assert_array_equal(tgt, g[tag + '/target'])          # same float32 arithmetic: bit exact
+    np.testing.assert_array_equal(w, g[tag + '/weight'])
+    if tag == 's1':                              # the fixture holds the edge cases
+        assert g[tag + '/weight'][0, 2, 0] == 0 and g[tag + '/vis'][0, 2] == 1      # dot entirely outside
+        assert 0 < g[tag + '/target'][0, 3].max() < 1                                # clipped dot, centre outside
+
+
 def test_hrnet_train_oracle_vs_reference():
     """Two train-mode iterations of the reference HRNet (tiny topology) with the
     reference's JointsCompositeLoss and Adam: losses, first-step outputs and
