@@ -30,6 +30,7 @@ from .. import _lib
 from . import FCmodel
 from . import heatmapModel  # noqa: F401  (plugin namespace)
 from ..common.img_proc import modify_bbox, to_npy
+from ..common.format import get_pred_str, save_txt_file
 import egonet_amd.model as models  # noqa: F401  (eval() lookup below, like the reference)
 
 
@@ -229,8 +230,8 @@ class EgoNet(nn.Module):
         return np.array([self._wrap(e[1] - math.atan2(-f, k[0, 0] - cx) - 0.5 * math.pi)
                          for e, k in zip(euler_angles, kpts)])
 
-    def gather_lifting_results(self, record, alpha_mode='trans'):
-        """egonet.py:297-339 without plotting / string formatting."""
+    def gather_lifting_results(self, record, alpha_mode='trans', get_str=False):
+        """egonet.py:297-339 without plotting."""
         record['euler_angles'], record['translation'] = self.get_6d_rep(record['kpts_3d_pred'])
         if alpha_mode == 'trans':
             record['alphas'] = self.get_observation_angle_trans(record['euler_angles'],
@@ -240,16 +241,22 @@ class EgoNet(nn.Module):
                                                                record['kpts_2d_pred'], record['K'])
         else:
             raise NotImplementedError
+        if get_str:
+            record['pred_str'] = get_pred_str(record)
         return record
 
     def post_process(self, records, visualize=False, color_dict=None, save_dict=None,
                      alpha_mode='trans'):
-        """egonet.py:385-408: pose angles per image.  Plotting and KITTI text
-        output are outside the hot path."""
-        if visualize or (save_dict and save_dict.get('flag')):
-            raise NotImplementedError('visualisation / result files are outside the hot path')
+        """egonet.py:385-408 (+ plot_one_image :341-383 minus the plotting): pose angles
+        per image and, with ``save_dict = {'flag': True, 'save_dir': ...}``, one KITTI
+        result file per image (needs ``raw_txt_format`` in the record)."""
+        if visualize:
+            raise NotImplementedError('visualisation is outside the hot path')
+        save = bool(save_dict and save_dict.get('flag'))
         for path in records:
-            records[path] = self.gather_lifting_results(records[path], alpha_mode=alpha_mode)
+            records[path] = self.gather_lifting_results(records[path], alpha_mode=alpha_mode, get_str=save)
+            if save:
+                save_txt_file(path, records[path], save_dict)
         return records
 
     # ------------------------------------------------------------------

@@ -163,6 +163,28 @@ def main():
         tcases[tag + '/target'] = np.stack([o[0] for o in outs])
         tcases[tag + '/weight'] = np.stack([o[1] for o in outs])
     save('targets.npz', **tcases)
+    # ---- 0c: KITTI result lines by the reference's get_pred_str (format.py:24-60)
+    import libs.common.format as ref_fmt
+    rng = np.random.RandomState(3)
+    recs = []
+    for n_inst in (1, 3, 4):
+        raw = []
+        for i in range(n_inst):
+            d = {'class': ['Car', 'Van', 'Pedestrian'][i % 3], 'truncation': float(rng.randint(0, 3)) / 2,
+                 'occlusion': float(rng.randint(0, 4)), 'alpha': float(rng.uniform(-3.2, 3.2)),
+                 'bbox': [float(v) for v in rng.uniform(0, 1242, 4)],
+                 'dimensions': [float(v) for v in rng.uniform(1, 5, 3)],
+                 'locations': [float(v) for v in rng.uniform(-30, 60, 3)], 'rot_y': float(rng.uniform(-3.2, 3.2))}
+            if i % 2 == 0:
+                d['score'] = float(rng.uniform(0, 1))
+            raw.append(d)
+        rec = {'raw_txt_format': raw, 'euler_angles': rng.uniform(-3.2, 3.2, (n_inst, 3)),
+               'alphas': rng.uniform(-3.2, 3.2, n_inst)}
+        recs.append({'raw_txt_format': raw, 'euler_angles': rec['euler_angles'].tolist(),
+                     'alphas': rec['alphas'].tolist(), 'pred_str': ref_fmt.get_pred_str(rec)})
+    with open(os.path.join(HERE, 'format.json'), 'w') as f:
+        json.dump(recs, f, indent=1)
+    print('format.json')
     if '--train-only' in sys.argv:
         return
 
