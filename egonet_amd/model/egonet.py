@@ -44,6 +44,7 @@ class EgoNet(nn.Module):
     def __init__(self, cfgs, pre_trained=False):
         super().__init__()
         hm = cfgs['heatmapModel']
+        self.cfgs = cfgs
         # plugin lookup by name, as in the reference (egonet.py:43-44)
         self.HC = eval('models.heatmapModel.' + hm['name'] + '.get_pose_net')(cfgs, is_train=False)
         self.resolution = hm['input_size']
@@ -280,14 +281,18 @@ class EgoNet(nn.Module):
                                 'score': scores[j]})
         return records
 
-    def forward(self, annot_dict):
-        try:
-            import cv2  # noqa: F401
-        except ImportError as e:
-            raise ImportError('EgoNet.forward crops instances with cv2 like the reference '
-                              '(egonet.py:68-155); use infer_crops() with pre-cropped patches') from e
-        from ..common import crop_cv2
-        instances, records = crop_cv2.crop_instances(self, annot_dict)
+    def forward(self, annot_dict, images=None):
+        """egonet.py:488-504.  Instances are cropped on the GPU (common/crop_gpu.py: one
+        launch per image for warp + ToTensor + Normalize); ``images`` optionally maps a
+        path to an [H,W,3] uint8 RGB array, otherwise the files are read with PIL.
+        When the caller has set ``pth_trans`` (tools/inference.py:147) and cv2 is
+        importable, the reference's host-side cv2 route is used instead."""
+        if self.pth_trans is not None:
+            from ..common import crop_cv2
+            instances, records = crop_cv2.crop_instances(self, annot_dict)
+        else:
+            from ..common import crop_gpu
+            instances, records = crop_gpu.crop_instances(self, annot_dict, images)
         recs = self.get_keypoints(instances, records)
         recs = self.lift_2d_to_3d(recs)
         for idx, path in enumerate(annot_dict['path']):

@@ -147,6 +147,19 @@ int egn_pose_solve_f64(const double* pred3d, int n, const double* kpt_x,
                        double* euler, double* alpha, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Crop front end: all boxes of one image in one launch (egonet.py:68-96:
+ * get_affine_transform + cv2.warpAffine(INTER_LINEAR, border 0) + ToTensor +
+ * Normalize).  img [H,W,3] uint8 RGB (row pitch in bytes); M [n,6] f64 forward
+ * 2x3 affines image -> crop; out [n,3,out_h,out_w] f32 = (bilinear/255 - mean)/std.
+ * Restates cv::warpAffine's 8-bit fixed-point scheme (1/32 pixel); OpenCV is
+ * absent from the build image: parity with cv2 is unpinned.
+ * ---------------------------------------------------------------------- */
+int egn_crop_warp_normalize_u8(const uint8_t* img, int H, int W, int pitch,
+                               const double* M, int n, int out_h, int out_w,
+                               const float* mean, const float* stdv, float* out,
+                               void* stream);
+
+/* ------------------------------------------------------------------------
  * Training step building blocks (reference: libs/trainer/trainer.py:183-209
  * zero_grad / forward / loss / backward / optim.step; FCmodel.py Linear +
  * BatchNorm1d (batch statistics) + ReLU + Dropout; function.py:204-215
