@@ -486,6 +486,42 @@ extern "C" int egn_adam_step_f32(float* p, const float* g, float* m, float* v, l
   return (int)hipGetLastError();
 }
 
+// The same update with the step counter and the learning rate in DEVICE memory:
+// state[0] = step count (incremented here, by one thread, before the update),
+// hyper[0] = lr.  Nothing of the iteration is baked into kernel arguments, so a
+// captured hipGraph of a whole training step replays correctly step after step.
+__global__ void adam_tick_kernel(int* __restrict__ state) { state[0] += 1; }
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                       const float* __restrict__ hyper, float b1, float b2, float eps,
+                                                       const int* __restrict__ state) {
+  __shared__ float s_step, s_bc2;
+  if (threadIdx.x == 0) {
+    const double t = (double)state[0];
+    s_step = (float)((double)hyper[0] / (1.0 - pow((double)b1, t)));
+    s_bc2 = (float)sqrt(1.0 - pow((double)b2, t));
+  }
+  __syncthreads();
+  const float step_size = s_step, bc2_sqrt = s_bc2;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[e];
+    const float mi = b1 * m[e] + (1.f - b1) * gi;
+    const float vi = b2 * v[e] + (1.f - b2) * gi * gi;
+    m[e] = mi;
+    v[e] = vi;
+    p[e] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+extern "C" int egn_adam_step_dev_f32(float* p, const float* g, float* m, float* v, long n, const float* lr_dev,
+                                     float beta1, float beta2, float eps, int* step_dev, void* stream) {
+  if (n <= 0 || !lr_dev || !step_dev) return EGN_E_BADARG;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (size_t)n, lr_dev, beta1, beta2, eps, step_dev);
+  return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // Convolution training support
 // ---------------------------------------------------------------------------

@@ -66,13 +66,22 @@ class FlatParams(object):
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.grad[off:off + p.numel()].view_as(p)
-        self.t = 0
+        # step counter and learning rate live in device memory (hipGraph-safe)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._lr_host = None
+
+    @property
+    def t(self):
+        return int(self.step_dev.item())
 
     def adam_step(self, lr, betas, eps, stream):
-        self.t += 1
-        _lib.check(_lib.lib().egn_adam_step_f32(_lib.ptr(self.flat), _lib.ptr(self.grad), _lib.ptr(self.m),
-                                                _lib.ptr(self.v), self.numel, lr, betas[0], betas[1], eps,
-                                                self.t, stream), 'adam')
+        if lr != self._lr_host:                 # only when the scheduler changed it (never inside a graph)
+            self.lr_dev.fill_(lr)
+            self._lr_host = lr
+        _lib.check(_lib.lib().egn_adam_step_dev_f32(_lib.ptr(self.flat), _lib.ptr(self.grad), _lib.ptr(self.m),
+                                                    _lib.ptr(self.v), self.numel, _lib.ptr(self.lr_dev), betas[0],
+                                                    betas[1], eps, _lib.ptr(self.step_dev), stream), 'adam')
 
 
 class _Tape(object):

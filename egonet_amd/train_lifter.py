@@ -24,6 +24,7 @@ import torch
 
 from . import _lib, tuner
 from .engine import _round_up
+from .train_hrnet import FlatParams
 
 
 class _Unit(object):
@@ -35,7 +36,7 @@ class _Unit(object):
 
 
 class LifterTrainStep(object):
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, dropout=None):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, dropout=None, grad_sync=None):
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise ValueError('LifterTrainStep needs the model on a GPU')
@@ -44,18 +45,17 @@ class LifterTrainStep(object):
         self.model = model
         self.dev = p0.device
         self.lr, self.betas, self.eps = lr, betas, eps
+        self.grad_sync = grad_sync
         self.p = float(model.p_dropout if dropout is None else dropout)
         self.units = [_Unit(model.w1, model.batch_norm1)]
         for blk in model.res_blocks:
             self.units += [_Unit(blk.w1, blk.batch_norm1), _Unit(blk.w2, blk.batch_norm2)]
         self.final = model.w2
-        self.t = 0
-        self.params = [p for p in model.parameters() if p.requires_grad]
-        self.grads = {id(p): torch.zeros_like(p) for p in self.params}
-        self.m = {id(p): torch.zeros_like(p) for p in self.params}
-        self.v = {id(p): torch.zeros_like(p) for p in self.params}
-        for p in self.params:
-            p.grad = self.grads[id(p)]
+        # parameters / gradients / Adam moments as views of flat buffers: one Adam launch,
+        # one all-reduce buffer, step counter and lr on the device (hipGraph-safe)
+        self.flat = FlatParams(model.parameters())
+        self.params = self.flat.params
+        self.grads = {id(p): p.grad for p in self.params}
         self._ws = {}
         self._wgrad_floats = 0
         widest = _round_up(max([u.outf for u in self.units] + [u.inf for u in self.units]
@@ -214,10 +214,8 @@ class LifterTrainStep(object):
                     _lib.check(L.egn_add_f32(_lib.ptr(d_block_out), _lib.ptr(da), _lib.ptr(nxt), B * u.inf, st))
                     d_block_out = nxt
 
+            if self.grad_sync is not None:
+                self.grad_sync(self.flat.grad)
             if update:
-                self.t += 1
-                for p in self.params:
-                    _lib.check(L.egn_adam_step_f32(_lib.ptr(p), _lib.ptr(g[id(p)]), _lib.ptr(self.m[id(p)]),
-                                                   _lib.ptr(self.v[id(p)]), p.numel(), self.lr, self.betas[0],
-                                                   self.betas[1], self.eps, self.t, st), 'adam')
+                self.flat.adam_step(self.lr, self.betas, self.eps, st)
         return self.loss_dev

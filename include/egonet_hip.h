@@ -270,6 +270,14 @@ int egn_adam_step_f32(float* p, const float* g, float* m, float* v, long n,
                       float lr, float beta1, float beta2, float eps, int step,
                       void* stream);
 
+/* the same update with the step counter (step_dev[0], incremented by the call)
+ * and the learning rate (lr_dev[0]) in device memory: nothing of the iteration
+ * is baked into kernel arguments, so a hipGraph captured around a whole
+ * training step replays correctly */
+int egn_adam_step_dev_f32(float* p, const float* g, float* m, float* v, long n,
+                          const float* lr_dev, float beta1, float beta2,
+                          float eps, int* step_dev, void* stream);
+
 /* ------------------------------------------------------------------------
  * Programs: a recorded sequence of the launches above with every pointer
  * expressed as (slot, byte offset).  Slots are bound to base addresses before

@@ -81,6 +81,35 @@ def test_lifter_gradients_full_size_vs_oracle():
                                orc.sd['batch_norm1.running_mean'].numpy(), atol=1e-5)
 
 
+def test_graphed_lifter_step_equals_eager_steps():
+    """The whole iteration captured as one hipGraph (egonet_amd/graph.py): replays give
+    bit-identical parameters to eager steps -- the Adam step counter lives on the device."""
+    from egonet_amd.graph import GraphedStep
+    cfg = configs.tiny_config()
+    cfg['FCModel']['dropout'] = 0.0
+    gen = torch.Generator().manual_seed(1)
+    xs = torch.randn(6, 32, 10, generator=gen).cuda()
+    ys = torch.randn(6, 32, 12, generator=gen).cuda()
+    nets = []
+    for graphed in (False, True):
+        net = FCmodel.get_fc_model(1, cfg, 10, 12)
+        net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=4))
+        net = net.cuda().train()
+        tr = LifterTrainStep(net, lr=1e-3)
+        if graphed:
+            g = GraphedStep(tr, xs[0], ys[0], warmup=2)          # 2 real iterations on batch 0
+            losses = [float(g(xs[i], ys[i]).item()) for i in range(1, 6)]
+        else:
+            for _ in range(2):
+                tr.step(xs[0], ys[0])
+            losses = [float(tr.step(xs[i], ys[i]).item()) for i in range(1, 6)]
+        nets.append((net, losses, tr.flat.t))
+    assert nets[0][2] == nets[1][2] == 7
+    np.testing.assert_allclose(nets[0][1], nets[1][1], rtol=1e-12)     # the loss sum uses atomics: order varies
+    for (k, a), (_, b) in zip(nets[0][0].state_dict().items(), nets[1][0].state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 def test_lifter_training_reduces_loss_with_dropout():
     cfg = configs.tiny_config()
     net = FCmodel.get_fc_model(1, cfg, 10, 12).cuda().train()      # dropout 0.5 active

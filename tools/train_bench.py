@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dropout', type=float, default=0.5)
     ap.add_argument('--cpu', action='store_true')
+    ap.add_argument('--graph', action='store_true', help='replay the step as one hipGraph')
     a = ap.parse_args()
     cfg = configs.w48_config()
     cfg['FCModel']['dropout'] = a.dropout
@@ -53,11 +54,26 @@ def main():
     for _ in range(a.warmup):
         tr.step(xd, yd)
     torch.cuda.synchronize()
+    step = lambda: tr.step(xd, yd)                      # noqa: E731
+    if a.graph:
+        # the whole iteration (~130 launches, static shapes) as ONE hipGraph launch
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            tr.step(xd, yd)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            captured_loss = tr.step(xd, yd)
+        step = lambda: (graph.replay(), captured_loss)[1]      # noqa: E731
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
     for _ in range(a.steps):
-        loss = tr.step(xd, yd)
+        loss = step()
     e1.record()
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / a.steps
@@ -69,7 +85,7 @@ def main():
         'gemm_tflops': round(fl / (dev_ms * 1e-3) / 1e12, 2), 'gemm_gflop_per_step': round(fl / 1e9, 2),
         'dtype': 'f32', 'loss': float(loss.item()),
         'config': {'workload': 'train_lifting FCModel(66->96, 1024x2 blocks) fwd+bwd+Adam', 'batch': a.batch,
-                   'dropout': a.dropout, 'steps': a.steps, 'warmup': a.warmup},
+                   'dropout': a.dropout, 'steps': a.steps, 'warmup': a.warmup, 'hipgraph': bool(a.graph)},
     }
     if a.cpu:
         from oracle.lifter_train_oracle import LifterTrainOracle

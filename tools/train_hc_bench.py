@@ -33,6 +33,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='crops per GPU')
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--graph', action='store_true', help='replay the iteration as one hipGraph (single GPU)')
     a = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -52,6 +53,12 @@ def main():
     jt = (torch.rand(a.batch, 33, 2, generator=g) * 256).cuda()
     for _ in range(a.warmup):
         tr.step(x, tgt, jt)
+    step = lambda: tr.step(x, tgt, jt)                     # noqa: E731
+    if a.graph:
+        from egonet_amd.graph import GraphedStep
+        graphed = GraphedStep(tr, x, tgt, jt, warmup=1)
+        step = lambda: graphed(x, tgt, jt)                 # noqa: E731
+        step()
 
     def fence():
         torch.cuda.synchronize()
@@ -61,7 +68,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        loss = tr.step(x, tgt, jt)
+        loss = step()
     fence()
     dt = torch.tensor([time.perf_counter() - t0], device='cuda')
     if world > 1:
@@ -76,7 +83,7 @@ def main():
             'algorithmic_tflops_per_gpu': round(3 * GFLOP_FWD_PER_CROP * a.batch / sec / 1e3, 2),
             'loss': float(loss.item()),
             'config': {'workload': 'train_IGRs HRNet-W48 256x256 fwd+bwd+Adam, JointsCompositeLoss(mse,l1)',
-                       'batch_per_gpu': a.batch, 'global_batch': crops, 'parallelism': 'dp%d' % world},
+                       'batch_per_gpu': a.batch, 'hipgraph': bool(a.graph), 'global_batch': crops, 'parallelism': 'dp%d' % world},
         }))
     if world > 1:
         dist.destroy_process_group()
