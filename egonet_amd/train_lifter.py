@@ -90,8 +90,11 @@ class LifterTrainStep(object):
         if shift is None:
             sh = self.zeros
         else:
-            sh = self._buf('shift' + tagk, coutp)
-            sh[:cout].copy_(shift.detach())
+            if coutp == cout:                    # the bias vector already has the padded length
+                sh = shift.detach()
+            else:
+                sh = self._buf('shift' + tagk, coutp)
+                sh[:cout].copy_(shift.detach())
         # a contiguous [rows, cout] result is NHWC with cs = cout when cout % 4 == 0
         # (float4 row stores); otherwise the NCHW store path writes the same layout
         nchw = 1 if cout % 4 else 0
@@ -149,7 +152,7 @@ class LifterTrainStep(object):
                 mask = None
                 if self.p > 0:
                     mask = self._buf('mask%d' % ui, B, u.outf)
-                    mask.copy_((torch.rand(B, u.outf, device=dev) >= self.p).float())
+                    mask.bernoulli_(1.0 - self.p)          # keep mask (0/1), one launch, capture-aware RNG
                 y = self._buf('y%d' % ui, B, u.outf)
                 _lib.check(L.egn_bn_act_fwd_f32(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(u.bn.weight),
                                                 _lib.ptr(u.bn.bias), _lib.ptr(mask), keep, 1, None, _lib.ptr(y), B,
