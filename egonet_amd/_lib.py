@@ -44,6 +44,8 @@ SIGNATURES = {
     'egn_keypoints_to_screen_f64': (_i, [_p, _i, _i, _d, _d, _p, _p, _i, _i, _p, _p, _p, _p, _i, _p]),
     'egn_unnormalize_f64': (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
     'egn_pose_solve_f64': (_i, [_p, _i, _p, _d, _d, _i, _p, _p, _p]),
+    'egn_kitti_eval_image': (_i, [C.c_char_p, C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
+                                  C.POINTER(_d), C.POINTER(_d)]),
     'egn_crop_warp_normalize_u8': (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p]),
     'egn_conv2d_wgrad_ws_bytes': (C.c_long, [_i] * 11),
     'egn_conv2d_wgrad_f32': (_i, [_p, _p, _p] + [_i] * 11 + [_p, C.c_long, _p]),

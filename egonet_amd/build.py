@@ -21,7 +21,8 @@ ARCH = 'gfx950'
 
 
 def sources():
-    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+    """HIP kernels + host-only C++ (the KITTI evaluator) of the one shared library."""
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')) + glob.glob(os.path.join(CSRC, '*.cpp')))
 
 
 def needs_build():

@@ -153,7 +153,6 @@ __global__ __launch_bounds__(64 * NTAPW * WM * WN) void conv_wgrad_kernel(WgradA
     if (tile + 1 < t_end) EGN_WG_LOAD(tile + 1);  // in flight during the MFMA loop below
     const float* pa = sA + wm * WT + J * li;
     const float* pb = sB + wn * WT + J * li;
-#pragma unroll 2
     for (int s = 0; s < a.TP / 4; ++s) {
       const int p = 4 * s + kq;
       const int b = p >> a.lg_thw, rem = p & thw_mask;

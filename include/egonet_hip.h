@@ -147,6 +147,20 @@ int egn_pose_solve_f64(const double* pred3d, int n, const double* kpt_x,
                        double* euler, double* alpha, void* stream);
 
 /* ------------------------------------------------------------------------
+ * KITTI 2D-detection AP + Average Orientation Similarity, the IMAGE-metric path
+ * of tools/kitti-eval/evaluate_object_3d_offline.cpp (:131-265, :346-706,
+ * :791-850) without Boost.  Host code, no GPU.  Reads gt_dir/%06d.txt and
+ * result_dir/data/%06d.txt (KITTI label / result lines).
+ *   evaluated [3]       1 if class (car, pedestrian, cyclist) has detections
+ *   aos_valid           0 if any detection carries alpha == -10
+ *   precision, aos      [3 classes][3 levels easy/moderate/hard][41 recall samples]
+ * Returns 0; -1 bad argument; -2 missing ground-truth file; -3 no result files.
+ * ---------------------------------------------------------------------- */
+int egn_kitti_eval_image(const char* gt_dir, const char* result_dir, int* n_frames,
+                         int* evaluated, int* aos_valid, double* precision,
+                         double* aos);
+
+/* ------------------------------------------------------------------------
  * Crop front end: all boxes of one image in one launch (egonet.py:68-96:
  * get_affine_transform + cv2.warpAffine(INTER_LINEAR, border 0) + ToTensor +
  * Normalize).  img [H,W,3] uint8 RGB (row pitch in bytes); M [n,6] f64 forward
