@@ -235,6 +235,55 @@ def test_conv_wgrad(n, cin, cout, h, w, k, stride, pad):
 
 
 @pytest.mark.parametrize('n,cin,cout,h,w,k,stride,pad', [
+    (32, 48, 48, 64, 64, 3, 1, 1),       # BASELINE config 4 per-GPU sizes: the full-resolution branch,
+    (32, 96, 192, 32, 32, 3, 2, 1),      # a strided fuse conv,
+    (32, 384, 384, 8, 8, 3, 1, 1),       # the coarsest branch,
+    (32, 384, 48, 8, 8, 1, 1, 0),        # a 1x1 fuse conv,
+    (4096, 1024, 1024, 1, 1, 1, 1, 0),   # and the lifter's Linear at config 3's batch
+])
+def test_forward_dgrad_wgrad_are_adjoint_at_full_size(n, cin, cout, h, w, k, stride, pad):
+    """Size-independent property at the BASELINE sizes (no CPU oracle needed): the three
+    convolution kernels are adjoints of one another,
+        <conv(x, w), dy> = <w, wgrad(x, dy)> = <x, dgrad(dy, w)>,
+    inner products accumulated in float64."""
+    L = _lib.lib()
+    g = torch.Generator(device='cuda').manual_seed(n + cin)
+    cs_in, cs_out = (cin + 3) // 4 * 4, (cout + 3) // 4 * 4
+    ho, wo = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    x = torch.zeros(n, h, w, cs_in, device='cuda')
+    x[..., :cin] = torch.randn(n, h, w, cin, device='cuda', generator=g)
+    dy = torch.zeros(n, ho, wo, cs_out, device='cuda')
+    dy[..., :cout] = torch.randn(n, ho, wo, cout, device='cuda', generator=g)
+    wt = torch.randn(cout, cin, k, k, device='cuda', generator=g) * 0.05
+    one = torch.ones(max(cin, cout) + 16, device='cuda')
+    zero = torch.zeros(max(cin, cout) + 16, device='cuda')
+    wp = torch.zeros(L.egn_packed_weight_floats(cout, cin, k, k, 0), device='cuda')
+    _lib.check(L.egn_pack_conv_weight_f32(_lib.ptr(wt), cout, cin, k, k, 0, _lib.ptr(wp), _st()))
+    y = torch.empty(n, ho, wo, cs_out, device='cuda')
+    _lib.check(L.egn_conv2d_f32(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(one), _lib.ptr(zero), None, _lib.ptr(y),
+                                n, h, w, cin, cs_in, cout, cs_out, k, k, stride, pad, 0, 0, 0, _st()))
+    need = L.egn_conv2d_wgrad_ws_bytes(n, h, w, cin, cs_in, cout, cs_out, k, k, stride, pad)
+    ws = torch.empty(need // 4, device='cuda')
+    dw = torch.empty_like(wt)
+    _lib.check(L.egn_conv2d_wgrad_f32(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), n, h, w, cin, cs_in, cout, cs_out,
+                                      k, k, stride, pad, _lib.ptr(ws), need, _st()))
+    wq = torch.zeros(L.egn_packed_weight_floats(cout, cin, k, k, 1), device='cuda')
+    _lib.check(L.egn_pack_conv_weight_f32(_lib.ptr(wt), cout, cin, k, k, 1, _lib.ptr(wq), _st()))
+    src, sh, sw = dy, ho, wo
+    if stride == 2:
+        src, sh, sw = torch.empty(n, h, w, cs_out, device='cuda'), h, w
+        _lib.check(L.egn_zero_insert2_f32(_lib.ptr(dy), _lib.ptr(src), n, ho, wo, h, w, cs_out, _st()))
+    dx = torch.empty(n, h, w, cs_in, device='cuda')
+    _lib.check(L.egn_conv2d_f32(_lib.ptr(src), _lib.ptr(wq), _lib.ptr(one), _lib.ptr(zero), None, _lib.ptr(dx),
+                                n, sh, sw, cout, cs_out, cin, cs_in, k, k, 1, k - 1 - pad, 0, 0, 0, _st()))
+    a = float((y.double() * dy.double()).sum())
+    b = float((wt.double() * dw.double()).sum())
+    c = float((x.double() * dx.double()).sum())
+    scale = float((y.double() ** 2).sum().sqrt() * (dy.double() ** 2).sum().sqrt())
+    assert abs(a - b) < 2e-6 * scale and abs(a - c) < 2e-6 * scale, (a, b, c, scale)
+
+
+@pytest.mark.parametrize('n,cin,cout,h,w,k,stride,pad', [
     (2, 48, 48, 12, 20, 3, 1, 1),
     (2, 96, 200, 16, 16, 3, 1, 1),
     (2, 48, 96, 16, 16, 3, 2, 1),        # strided: zero-insert + stride-1 conv
