@@ -1,0 +1,278 @@
+// conv_c48.hip -- the 48 -> 48 channel 3x3 convolution (stride 1, pad 1, NHWC) of
+// HRNet's full-resolution branch with the WHOLE FILTER RESIDENT IN LDS.
+//
+// Why a dedicated kernel: these layers (hrnet.py:76-92 BasicBlock convs of branch 0,
+// 89 of the 306 conv launches of a W48 forward, 36 % of its time) have the shortest
+// K loop of the network (48 x 9 = 432), so what the general kernels pay per tile --
+// a weight slab DMA and a barrier per K stage, a prologue that cannot overlap
+// anything, a store burst at the end of every block -- is the largest fraction
+// there (62 % of the fp32-MFMA peak vs 70+ % on the wider branches).  The filter is
+// only 48*48*9*4 B = 82.9 KB in the packed layout, i.e. it FITS in the 160 KB LDS
+// next to a double-buffered 48-channel halo tile (2 x 36.9 KB).  So:
+//
+//   * one persistent block per CU loads the filter once and then walks over pixel
+//     tiles (8 x 16 outputs) with a stride of gridDim.x;
+//   * per tile: ONE barrier; the next tile's halo (all three 16-channel chunks)
+//     is LDS-DMA'd into the other buffer while the 27 (chunk, tap) steps of the
+//     current one run straight through -- no barrier, no DMA issue, no waitcnt on
+//     global memory inside the K loop;
+//   * the epilogue is wave-private and straight from the accumulators: a lane of a
+//     16x16 MFMA tile owns one channel of 4 consecutive pixels, 16 lanes cover 64
+//     contiguous bytes of a pixel's 192-byte row, so scale/shift, residual, ReLU
+//     and the dword buffer stores need no LDS pass and no barrier; the stores are
+//     not waited for (s_waitcnt vmcnt(24) before the next barrier leaves them in
+//     flight), they overlap the next tile's MFMAs.
+//
+// Fragment mapping, weight packing and numerics are those of conv_dma.hip /
+// conv_mfma.hip (v_mfma_f32_16x16x4_f32, exact fp32); 4 waves, wave w owns tile
+// rows 2w and 2w+1 (MT = 2) x all 48 output channels (NT = 3).
+#include "conv_common.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_c48_t;
+
+__device__ __forceinline__ void c48_dma16(__amdgpu_buffer_rsrc_t r, float4* dst, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_c48_t)dst, 16, voff, 0, 0, 0);
+}
+// The per-tile halo DMA as raw ISA.  Through the builtin the compiler knows that the
+// instruction writes LDS and puts an s_waitcnt vmcnt(0) in front of the next ds_read --
+// of the OTHER buffer -- which would expose the latency of the very prefetch this kernel
+// exists for.  The asm is invisible to the waitcnt insertion pass; completion is
+// enforced by hand (s_waitcnt vmcnt(24) + s_barrier at the top of the tile loop).
+// lds_addr: wave-uniform LDS byte address of the wave's 64 x 16 B destination.
+__device__ __forceinline__ void c48_dma16_raw(u32x4 rsrc, unsigned lds_addr, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc)
+               : "m0");
+}
+__device__ __forceinline__ unsigned c48_lds_addr(const void* p) {
+  return (unsigned)(__UINTPTR_TYPE__)(lds_ptr_c48_t) const_cast<void*>(p);  // LDS pointers are 32-bit offsets
+}
+__device__ __forceinline__ float c48_load4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+__device__ __forceinline__ void c48_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, 0, 0);
+}
+
+namespace {
+constexpr int C48 = 48, TH = 8, TW = 16, HH = TH + 2, HWD = TW + 2;
+constexpr int NPIXP = 192;                       // 180 halo pixels rounded up to 16
+constexpr int CHUNK_SLOTS = NPIXP * EGN_CKQ;     // float4 per 16-channel chunk of a halo buffer
+constexpr int HALO_SLOTS = 3 * CHUNK_SLOTS;      // 2304 float4 = 36.9 KB
+constexpr int W_SLOTS = 3 * 9 * EGN_CKQ * C48;   // 5184 float4 = 82.9 KB
+constexpr int NT = 3;
+}  // namespace
+
+// WAVES = 4: wave w owns tile rows 2w, 2w+1 (MT = 2); WAVES = 8: one row each (MT = 1), two
+// waves per SIMD so that one wave's epilogue / barrier wait hides under the other's MFMAs
+template <bool HAS_RES, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
+  constexpr int NTH = 64 * WAVES;
+  constexpr int MT = TH / WAVES;
+  constexpr int A_IT = (HALO_SLOTS + NTH - 1) / NTH;  // DMA instructions per lane and tile
+  extern __shared__ float4 smem[];
+  float4* sW = smem;             // [chunk][tap][quad][48]   (the packed filter, verbatim)
+  float4* sA = smem + W_SLOTS;   // [2][chunk][pixel][quad]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15;
+  const int kq = lane >> 4;
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (unsigned)((size_t)a.N * a.H * a.W * C48 * 4), 0x00020000);
+  // the same descriptor as raw words for the inline-asm DMA: base, stride 0, bytes, flags
+  const unsigned long long xaddr = reinterpret_cast<unsigned long long>(a.x);
+  const u32x4 rxv = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, (unsigned)((size_t)a.N * a.H * a.W * C48 * 4),
+                     0x00020000u};
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, (unsigned)(W_SLOTS * 16), 0x00020000);
+  const unsigned out_bytes = (unsigned)((size_t)a.N * a.Ho * a.Wo * C48 * 4);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, out_bytes, 0x00020000);
+
+  // the filter, once (W_SLOTS is a multiple of 64: whole waves)
+  for (int base = wave * 64; base < W_SLOTS; base += NTH) c48_dma16(rw, sW + base, (unsigned)(base + lane) * 16u);
+
+  // halo slot e = it*NTH + tid -> (chunk, pixel, quad); tile-independent parts
+  int rel[A_IT];  // byte offset relative to the tile's halo origin, -1 for the 12 pad pixels
+  int hyx[A_IT];  // hy << 8 | hx
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int e = it * NTH + tid;
+    const int c = e / CHUNK_SLOTS;
+    const int rem = e - c * CHUNK_SLOTS;
+    const int p = rem >> 2, q = rem & 3;
+    const int hy = p / HWD, hx = p - hy * HWD;
+    hyx[it] = (hy << 8) | hx;
+    rel[it] = (e < HALO_SLOTS && p < HH * HWD) ? ((hy * a.W + hx) * C48 + c * EGN_CK + q * 4) * 4 : -1;
+  }
+
+  const int tiles_per_img = a.tiles_x * a.tiles_y;
+  const int ntiles = tiles_per_img * a.N;
+
+// LDS-DMA of tile T's halo into buffer B (zero padding included, see below)
+#define C48_STAGE(T, B)                                                                              \
+  {                                                                                                  \
+    const int n_ = (T) / tiles_per_img;                                                              \
+    const int r_ = (T)-n_ * tiles_per_img;                                                           \
+    const int ty_ = r_ / a.tiles_x;                                                                  \
+    const int iy0_ = ty_ * TH - 1, ix0_ = (r_ - ty_ * a.tiles_x) * TW - 1;                           \
+    const int org_ = ((n_ * a.H + iy0_) * a.W + ix0_) * C48 * 4;                                     \
+    float4* dst_ = sA + (B)*HALO_SLOTS + wave * 64;                                                  \
+    const unsigned lds_ = c48_lds_addr(dst_);                                                        \
+    _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                            \
+      const int iy = iy0_ + (hyx[it] >> 8), ix = ix0_ + (hyx[it] & 255);                             \
+      const bool in_ = rel[it] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                   \
+      /* a lane outside the image gets the OOB offset: the buffer load returns 0 for it, */          \
+      /* so the zero padding is written by the same DMA (one instruction per wave and it) */         \
+      if (it * NTH + wave * 64 < HALO_SLOTS) /* wave-uniform */                                      \
+        c48_dma16_raw(rxv, lds_ + it * NTH * 16, in_ ? (unsigned)(org_ + rel[it]) : EGN_OOB);        \
+    }                                                                                                \
+  }
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) C48_STAGE(tile, 0)
+  int buf = 0;
+
+  // per-lane constants of the epilogue: channel = nt*16 + li, pixel x = 4*kq + r
+  float sc[NT], sh[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    sc[nt] = a.scale[nt * 16 + li];
+    sh[nt] = a.shift[nt * 16 + li];
+  }
+  const int act = a.act & EGN_ACT_MASK;
+  const bool res_after = (a.act & EGN_ACT_RES_AFTER) != 0;
+  int pixbase[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) pixbase[mt] = ((wave * MT + mt) * HWD + li) * EGN_CKQ + kq;
+
+  bool first = true;
+  for (; tile < ntiles; tile += gridDim.x) {
+    // this tile's halo DMA (and, the first time, the filter) must have landed and the
+    // the MT*NT*4 dword stores of the previous tile's epilogue are the newest vector-memory
+    // operations of the lane and may stay in flight
+    asm volatile("" ::: "memory");
+    if (first) __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0)  expcnt(7) lgkmcnt(0)
+    else if constexpr (MT == 2) __builtin_amdgcn_s_waitcnt(0x4078);  // vmcnt(24) expcnt(7) lgkmcnt(0)
+    else __builtin_amdgcn_s_waitcnt(0x007C);                         // vmcnt(12) expcnt(7) lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    first = false;
+    const int next = tile + gridDim.x;
+    if (next < ntiles) C48_STAGE(next, buf ^ 1)
+
+    const int n = tile / tiles_per_img;
+    const int r0 = tile - n * tiles_per_img;
+    const int ty = r0 / a.tiles_x;
+    const int oy0 = ty * TH, ox0 = (r0 - ty * a.tiles_x) * TW;
+
+    // output offsets (OOB = masked) and the residual values of this lane's 2x3x4 outputs
+    unsigned voff[MT][4];
+    float rv[MT][NT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int oy = oy0 + wave * MT + mt;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ox = ox0 + 4 * kq + r;
+        voff[mt][r] = (oy < a.Ho && ox < a.Wo) ? (unsigned)(((n * a.Ho + oy) * a.Wo + ox) * C48 + li) * 4u : EGN_OOB;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          rv[mt][nt][r] = HAS_RES ? c48_load4(rr, voff[mt][r] == EGN_OOB ? EGN_OOB : voff[mt][r] + nt * 64u) : 0.f;
+      }
+    }
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float4* curA = sA + buf * HALO_SLOTS;
+    float4 af[2][MT], bf[2][NT];
+#define C48_LOADF(S, K)                                                                             \
+  {                                                                                                 \
+    constexpr int c_ = (S) / 9, t_ = (S) % 9;                                                       \
+    constexpr int ds_ = ((t_ / 3) * HWD + (t_ % 3)) * EGN_CKQ + c_ * CHUNK_SLOTS;                   \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) af[K][mt] = curA[pixbase[mt] + ds_];          \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) bf[K][nt] = sW[((S)*EGN_CKQ + kq) * C48 + nt * 16 + li]; \
+  }
+#define C48_MFMA(K)                                                                                  \
+  _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { \
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[K][mt].x, bf[K][nt].x, acc[mt][nt], 0, 0, 0); \
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[K][mt].y, bf[K][nt].y, acc[mt][nt], 0, 0, 0); \
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[K][mt].z, bf[K][nt].z, acc[mt][nt], 0, 0, 0); \
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[K][mt].w, bf[K][nt].w, acc[mt][nt], 0, 0, 0); \
+  }
+#define C48_INTERLEAVE()                                                            \
+  _Pragma("unroll") for (int k_ = 0; k_ < MT * NT * 4; ++k_) {                       \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                               \
+    __builtin_amdgcn_sched_group_barrier(0x106, 1, 0);                               \
+  }
+// steps S and S+1: the ds_reads of the next step are in flight under the MFMAs of this one
+#define C48_PAIR(S)                     \
+  C48_LOADF((S) + 1, 1)                 \
+  C48_MFMA(0)                           \
+  C48_INTERLEAVE()                      \
+  C48_LOADF((S) + 2 < 27 ? (S) + 2 : 26, 0) \
+  C48_MFMA(1)                           \
+  C48_INTERLEAVE()
+
+    C48_LOADF(0, 0)
+    C48_PAIR(0) C48_PAIR(2) C48_PAIR(4) C48_PAIR(6) C48_PAIR(8) C48_PAIR(10) C48_PAIR(12)
+    C48_PAIR(14) C48_PAIR(16) C48_PAIR(18) C48_PAIR(20) C48_PAIR(22) C48_PAIR(24)
+    C48_MFMA(0)  // step 26 (loaded by the last pair)
+
+    // epilogue, straight from the accumulators
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[mt][nt][r] * sc[nt] + sh[nt];
+          if (!res_after) v += rv[mt][nt][r];
+          v = egn_act(v, act);
+          if (res_after) v = rv[mt][nt][r] + v;
+          c48_store4(ry, voff[mt][r] == EGN_OOB ? EGN_OOB : voff[mt][r] + nt * 64u, v);
+        }
+    buf ^= 1;
+  }
+#undef C48_STAGE
+#undef C48_LOADF
+#undef C48_MFMA
+#undef C48_INTERLEAVE
+#undef C48_PAIR
+}
+
+template <bool HAS_RES, int WAVES>
+static int c48_launch(const ConvArgs& a, size_t lds, int grid, hipStream_t stream) {
+  static bool raised = false;
+  if (!raised) {
+    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c48_kernel<HAS_RES, WAVES>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+    raised = true;
+  }
+  hipLaunchKernelGGL((conv_c48_kernel<HAS_RES, WAVES>), dim3(grid), dim3(64 * WAVES), lds, stream, a);
+  return (int)hipGetLastError();
+}
+
+int egn_conv_launch_c48(const ConvArgs& a, size_t lds, int waves, hipStream_t stream) {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  const int ntiles = a.tiles_x * a.tiles_y * a.N;
+  const int grid = ntiles < cus ? ntiles : cus;
+  if (waves == 8) return a.res ? c48_launch<true, 8>(a, lds, grid, stream) : c48_launch<false, 8>(a, lds, grid, stream);
+  return a.res ? c48_launch<true, 4>(a, lds, grid, stream) : c48_launch<false, 4>(a, lds, grid, stream);
+}

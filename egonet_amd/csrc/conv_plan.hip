@@ -17,6 +17,7 @@
 int egn_conv_launch_staged(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
 int egn_conv_launch_dma(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
 int egn_conv_launch_pers(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
+int egn_conv_launch_c48(const ConvArgs& a, size_t lds, int waves, hipStream_t stream);
 
 static const ConvConfig kConfigs[] = {
     // id wm wn mt nt ai bi dma (ai / bi = staging depth in dwordx4 per lane)
@@ -60,6 +61,8 @@ static const ConvConfig kConfigs[] = {
     {38, 2, 2, 2, 2, 8, 8, 3},
     {39, 1, 4, 4, 1, 8, 8, 3},
     {40, 1, 4, 2, 3, 8, 8, 3},
+    {41, 4, 1, 2, 3, 9, 0, 4},  // 48 -> 48 3x3 s1 only: filter resident in LDS, persistent (conv_c48.hip)
+    {42, 8, 1, 1, 3, 5, 0, 4},  // the same with 8 waves (two per SIMD)
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -79,7 +82,9 @@ extern "C" int egn_conv_config_info(int cfg, int* tile_m, int* tile_n) {
 extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (cfg < 1 || cfg > kNumConfigs || !buf || len < 8) return EGN_E_BADARG;
   const ConvConfig& c = kConfigs[cfg - 1];
-  if (c.dma == 3)
+  if (c.dma == 4)
+    snprintf(buf, len, "void conv_c48_kernel<%s, %d>(ConvArgs)", "true", c.wm);
+  else if (c.dma == 3)
     snprintf(buf, len, "void conv_pers_kernel<%d, %d, %d, %d, 8, 8>(ConvArgs)", c.wm, c.wn, c.mt, c.nt);
   else if (c.dma)
     snprintf(buf, len, "void conv_dma_kernel<%d, %d, %d, %d, 8, 8, 0>(ConvArgs)", c.wm, c.wn, c.mt, c.nt);
@@ -103,6 +108,7 @@ static size_t lds_stage_bytes(const ConvArgs& a, const ConvConfig& cf) {
   return ((main_loop > epi ? main_loop : epi) + 15) & ~(size_t)15;
 }
 static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
+  if (cf.dma == 4) return (size_t)(2 * 3 * 192 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // 2 halo buffers + filter
   if (cf.dma == 3) return lds_stage_bytes(a, cf) + (size_t)4 * 16 * (cf.nt * 16 + 4) * 4;
   return lds_stage_bytes(a, cf) + (size_t)cf.tile_m() * 4;
 }
@@ -111,6 +117,18 @@ static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
 // LDS fill work) over power-of-two tile shapes, subject to the LDS budget and
 // to the per-lane staging depth (ai / bi dwordx4 loads per stage).
 static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, double* cost_out) {
+  if (cf.dma == 4) {
+    // conv_c48.hip: exactly the 48 -> 48 3x3 stride-1 pad-1 NHWC layers, fixed 8 x 16 tile
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin != 48 || a.cs_in != 48 || a.Cout != 48 ||
+        a.cs_out != 48 || a.out_nchw)
+      return false;
+    a.TH = 8; a.TW = 16; a.TNB = 1; a.HH = 10; a.HW = 18;
+    a.npix = 180; a.npixp = 192; a.tps = 9;
+    a.tiles_x = (a.Wo + 15) / 16;
+    a.tiles_y = (a.Ho + 7) / 8;
+    if (cost_out) *cost_out = 0.0;
+    return true;
+  }
   const int tm = cf.tile_m();
   const int tn = cf.tile_n();
   double best = -1.0;
@@ -211,6 +229,7 @@ int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {
   if (cfg_id < 1 || cfg_id > kNumConfigs) return EGN_E_BADARG;
   const ConvConfig& cf = kConfigs[cfg_id - 1];
   const size_t lds = lds_bytes_for(a, cf);
+  if (cf.dma == 4) return egn_conv_launch_c48(a, lds, cf.wm, stream);
   if (cf.dma == 3) return egn_conv_launch_pers(a, (cfg_id - 1) % 10 + 1, lds, stream);
   return cf.dma ? egn_conv_launch_dma(a, (cfg_id - 1) % 10 + 1, lds, stream)
                 : egn_conv_launch_staged(a, cfg_id, lds, stream);

@@ -107,6 +107,29 @@ def test_conv_every_tile_config(cfg):
         assert (cfg - 1) % 10 < 6      # only the >= 128-row tiles overflow
 
 
+@pytest.mark.parametrize('n,h,w,res,act', [
+    (2, 64, 64, True, 1),        # the HRNet shape: 64 tiles
+    (1, 8, 16, False, 0),        # exactly one tile, every halo side is padding
+    (3, 19, 13, True, 1),        # partial tiles in x and y
+    (70, 64, 64, True, 1),       # 2240 tiles > 8 per persistent block: the double-buffered halo pipeline
+    (5, 40, 72, False, 1),
+])
+def test_conv_c48_resident_filter_kernel(n, h, w, res, act):
+    """Config 41 (csrc/conv_c48.hip): 48 -> 48 3x3, filter resident in LDS, persistent."""
+    import ctypes as C
+    from egonet_amd import _lib
+    L = _lib.lib()
+    assert L.egn_conv_num_configs() >= 42
+    for cfg in (41, 42):             # 4 waves x 2 tile rows, 8 waves x 1 tile row
+        err = _conv_case(n, h, w, 48, 48, 3, 1, 1, act=act, use_res=res, cfg=cfg, seed=n + h)
+        assert err < 2e-4, (cfg, err)
+    out = (C.c_int * 12)()
+    assert L.egn_conv_plan_query(2, 64, 64, 48, 48, 96, 96, 3, 3, 1, 1, 0, 41, out) != 0      # only 48 -> 48
+    assert L.egn_conv_plan_query(2, 64, 64, 48, 48, 48, 48, 3, 3, 2, 1, 0, 41, out) != 0      # only stride 1
+    buf = C.create_string_buffer(128)
+    assert L.egn_conv_config_name(41, buf, 128) == 0 and b'conv_c48_kernel' in buf.value
+
+
 def test_conv_heads_and_linear():
     assert _conv_case(2, 64, 64, 48, 33, 1, 1, 0, act=0, nchw=True, bias=True, seed=1) < 2e-4
     assert _conv_case(5, 4, 4, 66, 66, 4, 1, 0, act=2, nchw=True, bias=True, seed=2) < 2e-5     # 4x4 valid + sigmoid
