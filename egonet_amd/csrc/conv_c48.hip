@@ -66,7 +66,7 @@ constexpr int NT = 3;
 
 // WAVES = 4: wave w owns tile rows 2w, 2w+1 (MT = 2); WAVES = 8: one row each (MT = 1), two
 // waves per SIMD so that one wave's epilogue / barrier wait hides under the other's MFMAs
-template <bool HAS_RES, int WAVES>
+template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
   constexpr int NTH = 64 * WAVES;
   constexpr int MT = TH / WAVES;
@@ -147,6 +147,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
   }
   const int act = a.act & EGN_ACT_MASK;
   const bool res_after = (a.act & EGN_ACT_RES_AFTER) != 0;
+  const bool has_res = a.res != nullptr;
   int pixbase[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) pixbase[mt] = ((wave * MT + mt) * HWD + li) * EGN_CKQ + kq;
@@ -171,7 +172,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
     const int ty = r0 / a.tiles_x;
     const int oy0 = ty * TH, ox0 = (r0 - ty * a.tiles_x) * TW;
 
-    // output offsets (OOB = masked) and the residual values of this lane's 2x3x4 outputs
+    // output offsets (OOB = masked) and the residual values of this lane's MT x 3 x 4 outputs
+    // (without a residual every load gets the OOB offset and returns 0: no branch, and the
+    // number of vector-memory operations per tile -- which the vmcnt above counts on -- is fixed)
     unsigned voff[MT][4];
     float rv[MT][NT][4];
 #pragma unroll
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
         voff[mt][r] = (oy < a.Ho && ox < a.Wo) ? (unsigned)(((n * a.Ho + oy) * a.Wo + ox) * C48 + li) * 4u : EGN_OOB;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          rv[mt][nt][r] = HAS_RES ? c48_load4(rr, voff[mt][r] == EGN_OOB ? EGN_OOB : voff[mt][r] + nt * 64u) : 0.f;
+          rv[mt][nt][r] = c48_load4(rr, (!has_res || voff[mt][r] == EGN_OOB) ? EGN_OOB : voff[mt][r] + nt * 64u);
       }
     }
 
@@ -250,15 +253,15 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
 #undef C48_PAIR
 }
 
-template <bool HAS_RES, int WAVES>
+template <int WAVES>
 static int c48_launch(const ConvArgs& a, size_t lds, int grid, hipStream_t stream) {
   static bool raised = false;
   if (!raised) {
-    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c48_kernel<HAS_RES, WAVES>),
+    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c48_kernel<WAVES>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
     raised = true;
   }
-  hipLaunchKernelGGL((conv_c48_kernel<HAS_RES, WAVES>), dim3(grid), dim3(64 * WAVES), lds, stream, a);
+  hipLaunchKernelGGL((conv_c48_kernel<WAVES>), dim3(grid), dim3(64 * WAVES), lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -273,6 +276,5 @@ int egn_conv_launch_c48(const ConvArgs& a, size_t lds, int waves, hipStream_t st
   }
   const int ntiles = a.tiles_x * a.tiles_y * a.N;
   const int grid = ntiles < cus ? ntiles : cus;
-  if (waves == 8) return a.res ? c48_launch<true, 8>(a, lds, grid, stream) : c48_launch<false, 8>(a, lds, grid, stream);
-  return a.res ? c48_launch<true, 4>(a, lds, grid, stream) : c48_launch<false, 4>(a, lds, grid, stream);
+  return waves == 8 ? c48_launch<8>(a, lds, grid, stream) : c48_launch<4>(a, lds, grid, stream);
 }

@@ -83,7 +83,7 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (cfg < 1 || cfg > kNumConfigs || !buf || len < 8) return EGN_E_BADARG;
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 4)
-    snprintf(buf, len, "void conv_c48_kernel<%s, %d>(ConvArgs)", "true", c.wm);
+    snprintf(buf, len, "void conv_c48_kernel<%d>(ConvArgs)", c.wm);
   else if (c.dma == 3)
     snprintf(buf, len, "void conv_pers_kernel<%d, %d, %d, %d, 8, 8>(ConvArgs)", c.wm, c.wn, c.mt, c.nt);
   else if (c.dma)
