@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libegonet_hip.so')
+LIB_PATH = os.environ.get('EGONET_AMD_LIB') or os.path.join(_HERE, 'csrc', 'libegonet_hip.so')   # override: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'egonet_hip.h')
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_LEAKY = 0, 1, 2, 3

@@ -26,8 +26,26 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 // to LDS at wave-uniform `dst` + lane*16.  Kept out of the kernel template: a
 // call to the target builtin with template-dependent operands makes clang drop
 // the host-side stub of the kernel without a diagnostic (ROCm 7.2).
-__device__ __forceinline__ void egn_dma16(__amdgpu_buffer_rsrc_t r, float4* dst, unsigned voff, int soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, voff, soff, 0, 0);
+//
+// Issued as raw ISA, not through __builtin_amdgcn_raw_ptr_buffer_load_lds: the compiler
+// knows the builtin writes LDS and puts `s_waitcnt vmcnt(0)` in front of the next
+// ds_read -- which here belongs to the OTHER stage buffer -- so the DMA of stage s+1
+// would have to land before the MFMA loop of stage s may start (measured: that wait sat
+// in front of every stage's first fragment read).  The asm is invisible to the waitcnt
+// insertion; completion is enforced by the explicit vmcnt(0) in front of the stage
+// barrier, one whole MFMA loop after the issue.
+__device__ __forceinline__ void egn_dma16(u32x4 r, float4* dst, unsigned voff, int soff) {
+#ifdef EGN_DMA_VIA_BUILTIN  // A/B switch for tools/conv_probe.py builds only (-DEGN_DMA_VIA_BUILTIN)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)(r[1] & 0xffffu) << 32) | r[0]), 0, r[2], r[3]);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, voff, soff, 0, 0);
+  return;
+#endif
+  const unsigned lds = (unsigned)(__UINTPTR_TYPE__)(lds_ptr_t)dst;  // wave-uniform LDS byte address
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds), "v"(voff), "s"(r), "s"(soff)
+               : "m0");
 }
 
 // ABL != 0 are timing ablations (wrong results by construction, never planned):
@@ -65,10 +83,13 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
   const int tile_px = a.TH * a.TW;
 
   constexpr unsigned OOB = 0xF0000000u;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x), 0, (unsigned)((size_t)a.N * a.H * a.W * a.cs_in * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.w), 0, (unsigned)((size_t)a.nchunk * a.taps * CKQ * a.CoutP * 16), 0x00020000);
+  // buffer descriptors as raw words (base, stride 0, bytes, flags) for the inline-asm DMA
+  const unsigned long long xaddr = reinterpret_cast<unsigned long long>(a.x);
+  const unsigned long long waddr = reinterpret_cast<unsigned long long>(a.w);
+  const u32x4 rx = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu,
+                    (unsigned)((size_t)a.N * a.H * a.W * a.cs_in * 4), 0x00020000u};
+  const u32x4 rw = {(unsigned)waddr, (unsigned)(waddr >> 32) & 0xffffu,
+                    (unsigned)((size_t)a.nchunk * a.taps * CKQ * a.CoutP * 16), 0x00020000u};
 
   // halo element e = tid + it*256 -> LDS slot e = pixel p * 4 + quad q
   const int q = tid & 3;
@@ -216,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
     // stage s has landed (vmcnt(0) is part of the barrier while a DMA is in
     // flight) and every wave is done with the buffers stage s+1 overwrites
     if constexpr (kStage) {
+      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): this lane's share of stage s has landed
       __syncthreads();
       EGN_DMA(s + 1)
     }
@@ -223,7 +245,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
   }
   // last stage (peeled): the residual loads of the epilogue go out first and
   // are in flight under its MFMAs
-  if constexpr (kStage) __syncthreads();
+  if constexpr (kStage) {
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();
+  }
   ConvEpiRegs<MT, NT> er;
   const bool nhwc = !a.out_nchw && ABL != 3;
   if (nhwc) conv_epi_prefetch<WM, WN, MT, NT>(a, smem, tid, n0, er);
