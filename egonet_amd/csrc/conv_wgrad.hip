@@ -270,10 +270,16 @@ static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
   a.ci_tiles = (a.Cin + IW - 1) / IW;
   a.CoP = a.co_tiles * CW;
   a.CiP = a.ci_tiles * IW;
-  a.TW = std::min(pow2_ceil(a.Wo), 8);
+  // pixels per tile: 64, or 128 (8 x 16) for the 48-wide 3x3 variant, whose two tiles still
+  // fit twice per CU (65.7 KB): half as many barriers per MFMA
+  static const bool big_tiles = !(getenv("EGN_WGRAD_TP64") && atoi(getenv("EGN_WGRAD_TP64")));
+  const bool tp128 = big_tiles && v.ntapw == 9 && v.j == 3 && a.stride == 1;
+  if (tp128) v.a_it = 3;
+  const int tp_target = tp128 ? 128 : 64;
+  a.TW = std::min(pow2_ceil(a.Wo), tp128 ? 16 : 8);
   a.TH = std::min(pow2_ceil(a.Ho), 8);
-  a.TNB = std::max(1, 64 / (a.TH * a.TW));
-  const size_t budget = 64 * 1024;
+  a.TNB = std::max(1, tp_target / (a.TH * a.TW));
+  const size_t budget = tp128 ? 66 * 1024 : 64 * 1024;
   for (;;) {
     if (a.TH * a.TW * a.TNB < 4) a.TNB = 4 / (a.TH * a.TW);
     a.HH = (a.TH - 1) * a.stride + a.KH;
@@ -343,7 +349,8 @@ extern "C" int egn_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
   if (rc != 0) return rc;
   if ((size_t)ws_bytes < (size_t)a.nsplit * a.taps * a.CoP * a.CiP * sizeof(float)) return EGN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (v.ntapw == 9) rc = v.j == 3 ? wgrad_launch<9, 1, 1, 1, 3, 2, 5>(a, lds, st) : wgrad_launch<9, 1, 1, 1, 4, 2, 5>(a, lds, st);
+  if (v.ntapw == 9 && v.j == 3) rc = v.a_it == 3 ? wgrad_launch<9, 1, 1, 1, 3, 3, 5>(a, lds, st) : wgrad_launch<9, 1, 1, 1, 3, 2, 5>(a, lds, st);
+  else if (v.ntapw == 9) rc = wgrad_launch<9, 1, 1, 1, 4, 2, 5>(a, lds, st);
   else if (v.ntapw == 8) rc = v.j == 3 ? wgrad_launch<8, 2, 1, 1, 3, 2, 5>(a, lds, st) : wgrad_launch<8, 2, 1, 1, 4, 2, 5>(a, lds, st);
   else if (v.wm == 2 && v.wn == 2) rc = wgrad_launch<1, 1, 2, 2, 4, 4, 4>(a, lds, st);
   else if (v.wm == 2) rc = wgrad_launch<1, 1, 2, 1, 4, 8, 4>(a, lds, st);

@@ -292,10 +292,29 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ mask, float keep_scale, int relu,
                                                          const float* __restrict__ res, float* __restrict__ y,
                                                          int rows, int cols, int ld) {
+  // a thread keeps ONE float4 column group for all its rows, so the per-channel
+  // parameters are loaded once into registers; a block covers up to 256 column groups
+  // and 256 / groups rows per step: consecutive lanes read consecutive 16-byte pieces of
+  // consecutive rows (ld == row length for NHWC activations)
   const int ld4 = ld / 4;
-  const size_t total = (size_t)rows * ld4;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(e % ld4);
+  const int cgb = min(256, ld4 - (int)blockIdx.y * 256);
+  const int rpi = 256 / cgb;
+  const int r_local = threadIdx.x / cgb;
+  if (r_local >= rpi) return;
+  const int c4 = blockIdx.y * 256 + threadIdx.x - r_local * cgb;
+  float pm[4], pi[4], pg[4], pb[4];
+  bool ok[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c4 * 4 + k;
+    ok[k] = c < cols;
+    pm[k] = ok[k] ? mean[c] : 0.f;
+    pi[k] = ok[k] ? invstd[c] : 0.f;
+    pg[k] = ok[k] ? gamma[c] : 0.f;
+    pb[k] = ok[k] ? beta[c] : 0.f;
+  }
+  for (int r = blockIdx.x * rpi + r_local; r < rows; r += gridDim.x * rpi) {
+    const size_t e = (size_t)r * ld4 + c4;
     const float4 v = reinterpret_cast<const float4*>(z)[e];
     const float in[4] = {v.x, v.y, v.z, v.w};
     float out[4];
@@ -307,10 +326,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     const float ra[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int c = c4 * 4 + k;
       float o = 0.f;
-      if (c < cols) {
-        o = gamma[c] * ((in[k] - mean[c]) * invstd[c]) + beta[c] + ra[k];
+      if (ok[k]) {
+        o = pg[k] * ((in[k] - pm[k]) * pi[k]) + pb[k] + ra[k];
         if (relu) o = fmaxf(o, 0.f);
         if (mask) o *= mka[k] * keep_scale;
       }
@@ -320,13 +338,22 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   }
 }
 
+// grid of the row-streaming kernels above / below: x = row steps (capped), y = column blocks
+static dim3 rowstream_grid(int rows, int ld) {
+  const int ld4 = ld / 4;
+  const int gy = (ld4 + 255) / 256;
+  const int rpi = 256 / (ld4 < 256 ? ld4 : 256);
+  int gx = (rows + rpi - 1) / rpi;
+  if (gx > 2048) gx = 2048;
+  return dim3(gx, gy);
+}
+
 extern "C" int egn_bn_act_fwd_f32(const float* z, const float* mean, const float* invstd, const float* gamma,
                                   const float* beta, const float* mask, float keep_scale, int relu,
                                   const float* res, float* y, int rows, int cols, int ld, void* stream) {
   if (rows <= 0 || cols <= 0 || ld % 4 || ld < cols) return EGN_E_BADARG;
-  const size_t total = (size_t)rows * (ld / 4);
-  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, z, mean,
-                     invstd, gamma, beta, mask, keep_scale, relu, res, y, rows, cols, ld);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, rowstream_grid(rows, ld), dim3(256), 0, (hipStream_t)stream, z, mean, invstd,
+                     gamma, beta, mask, keep_scale, relu, res, y, rows, cols, ld);
   return (int)hipGetLastError();
 }
 
@@ -353,11 +380,29 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict_
                                                         const float* __restrict__ dbeta,
                                                         const float* __restrict__ dgamma, float* __restrict__ dz,
                                                         float* __restrict__ dres, int rows, int cols, int ld) {
+  // same row-streaming thread mapping as bn_act_fwd_kernel: per-channel values in registers
   const int ld4 = ld / 4;
-  const size_t total = (size_t)rows * ld4;
   const float inv_rows = 1.0f / (float)rows;
-  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(e % ld4);
+  const int cgb = min(256, ld4 - (int)blockIdx.y * 256);
+  const int rpi = 256 / cgb;
+  const int r_local = threadIdx.x / cgb;
+  if (r_local >= rpi) return;
+  const int c4 = blockIdx.y * 256 + threadIdx.x - r_local * cgb;
+  float pm[4], pi[4], pg[4], pb[4], pdb[4], pdg[4];
+  bool ok[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c4 * 4 + k;
+    ok[k] = c < cols;
+    pm[k] = ok[k] ? mean[c] : 0.f;
+    pi[k] = ok[k] ? invstd[c] : 0.f;
+    pg[k] = ok[k] ? gamma[c] : 0.f;
+    pb[k] = ok[k] ? beta[c] : 0.f;
+    pdb[k] = ok[k] ? dbeta[c] : 0.f;
+    pdg[k] = ok[k] ? dgamma[c] : 0.f;
+  }
+  for (int r = blockIdx.x * rpi + r_local; r < rows; r += gridDim.x * rpi) {
+    const size_t e = (size_t)r * ld4 + c4;
     const float4 zv = reinterpret_cast<const float4*>(z)[e];
     const float4 dv = reinterpret_cast<const float4*>(dy)[e];
     float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -371,14 +416,13 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict_
     float out[4], gated[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int c = c4 * 4 + k;
       float o = 0.f, d = 0.f;
-      if (c < cols) {
-        const float xhat = (zi[k] - mean[c]) * invstd[c];
+      if (ok[k]) {
+        const float xhat = (zi[k] - pm[k]) * pi[k];
         d = di[k];
         if (mask) d *= mi[k] * keep_scale;
-        if (relu && !(gamma[c] * xhat + beta[c] + ri[k] > 0.f)) d = 0.f;
-        o = gamma[c] * invstd[c] * (d - dbeta[c] * inv_rows - xhat * dgamma[c] * inv_rows);
+        if (relu && !(pg[k] * xhat + pb[k] + ri[k] > 0.f)) d = 0.f;
+        o = pg[k] * pi[k] * (d - pdb[k] * inv_rows - xhat * pdg[k] * inv_rows);
       }
       out[k] = o;
       gated[k] = d;
@@ -393,8 +437,7 @@ extern "C" int egn_bn_bwd_dz_f32(const float* dy, const float* z, const float* m
                                  int relu, const float* res, const float* dbeta, const float* dgamma, float* dz,
                                  float* dres, int rows, int cols, int ld, void* stream) {
   if (rows <= 0 || cols <= 0 || ld % 4 || ld < cols) return EGN_E_BADARG;
-  const size_t total = (size_t)rows * (ld / 4);
-  hipLaunchKernelGGL(bn_bwd_dz_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, z, mask,
+  hipLaunchKernelGGL(bn_bwd_dz_kernel, rowstream_grid(rows, ld), dim3(256), 0, (hipStream_t)stream, dy, z, mask,
                      keep_scale, mean, invstd, gamma, beta, relu, res, dbeta, dgamma, dz, dres, rows, cols, ld);
   return (int)hipGetLastError();
 }
