@@ -166,6 +166,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
     first = false;
     const int next = tile + gridDim.x;
     if (next < ntiles) C48_STAGE(next, buf ^ 1)
+    // the vmcnt bookkeeping above counts on program order: DMA, residual loads, stores.
+    // The asm has no memory clobber (on purpose), so pin the order for the compiler here.
+    asm volatile("" ::: "memory");
 
     const int n = tile / tiles_per_img;
     const int r0 = tile - n * tiles_per_img;

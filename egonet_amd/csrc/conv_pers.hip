@@ -29,8 +29,15 @@
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-__device__ __forceinline__ void egn_pdma16(__amdgpu_buffer_rsrc_t r, float4* dst, unsigned voff, int soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, voff, soff, 0, 0);
+// raw ISA like conv_dma.hip's egn_dma16 (the builtin makes the compiler wait for the DMA
+// in front of the next ds_read of the other buffer); completion: explicit vmcnt(0) in
+// front of the stage barriers
+__device__ __forceinline__ void egn_pdma16(u32x4 r, float4* dst, unsigned voff, int soff) {
+  const unsigned lds = (unsigned)(__UINTPTR_TYPE__)(lds_ptr_t)dst;
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds), "v"(voff), "s"(r), "s"(soff)
+               : "m0");
 }
 
 constexpr unsigned EGN_NOPIX = 0xFFFFFFFFu;
@@ -67,10 +74,12 @@ __global__ __launch_bounds__(256, 2) void conv_pers_kernel(ConvArgs a) {
   const int tiles_xy = a.tiles_x * a.tiles_y;
   const int ntiles = tiles_xy * ((a.N + a.TNB - 1) / a.TNB) * tiles_n;
 
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x), 0, (unsigned)((size_t)a.N * a.H * a.W * a.cs_in * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.w), 0, (unsigned)((size_t)a.nchunk * a.taps * CKQ * a.CoutP * 16), 0x00020000);
+  const unsigned long long xaddr = reinterpret_cast<unsigned long long>(a.x);
+  const unsigned long long waddr = reinterpret_cast<unsigned long long>(a.w);
+  const u32x4 rx = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu,
+                    (unsigned)((size_t)a.N * a.H * a.W * a.cs_in * 4), 0x00020000u};
+  const u32x4 rw = {(unsigned)waddr, (unsigned)(waddr >> 32) & 0xffffu,
+                    (unsigned)((size_t)a.nchunk * a.taps * CKQ * a.CoutP * 16), 0x00020000u};
   const unsigned ybytes = a.out_nchw ? 0u : (unsigned)((size_t)a.N * howo * a.cs_out * 4);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, ybytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr =
@@ -267,11 +276,13 @@ __global__ __launch_bounds__(256, 2) void conv_pers_kernel(ConvArgs a) {
     for (int s = 0; s + 1 < nst; ++s) {
       // stage s has landed (vmcnt(0) + lgkmcnt(0) are part of the barrier) and every
       // wave is done with the buffers the next fill overwrites
+      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0): the raw-ISA DMA is invisible to the compiler
       __syncthreads();
       EGN_FILL(s + 1, gs + 1, gc + ((s + 1) / nspc - s / nspc), n_base, oy0, ox0, n0)
       EGN_PCOMPUTE(s)
     }
     // ---- last stage of the tile (peeled) ----
+    __builtin_amdgcn_s_waitcnt(0x0070);
     __syncthreads();
     if (has_next) EGN_FILL(0, gs + 1, gc + 1, nn_base, noy0, nox0, nn0)  // stage 0 of the next tile
     // residual of the first 16-row slab: in flight under the last stage's MFMAs
