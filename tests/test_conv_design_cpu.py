@@ -103,3 +103,27 @@ def test_planner_limits():
     # bad arguments are reported, not crashed on
     out = (C.c_int * 12)()
     assert _lib.lib().egn_conv_plan_query(1, 8, 8, 6, 6, 8, 8, 3, 3, 1, 1, 0, 0, out) == -1   # cs_in % 4
+
+
+def test_filter_resident_configs_plan_only_the_48_channel_3x3_layers():
+    """Configs 41 / 42 (csrc/conv_c48.hip): fixed 8x16 tile, filter (82 944 B) + two
+    48-channel halo buffers (2 x 36 864 B) in LDS, refused for every other layer."""
+    L = _lib.lib()
+    assert L.egn_conv_num_configs() == 42
+    for cfg, waves in ((41, 4), (42, 8)):
+        plan = _plan((64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0), cfg=cfg)
+        cfg_id, wm, wn, mt, nt, th, tw, tnb, tps, lds = plan[:10]
+        assert (cfg_id, wm, wn, mt, nt) == (cfg, waves, 1, 8 // waves, 3)
+        assert (th, tw, tnb, tps) == (8, 16, 1, 9) and lds == 82944 + 2 * 36864
+        name = C.create_string_buffer(96)
+        assert L.egn_conv_config_name(cfg, name, 96) == 0
+        assert name.value == b'void conv_c48_kernel<%d>(ConvArgs)' % waves
+        out = (C.c_int * 12)()
+        for bad in ((64, 64, 64, 48, 48, 96, 96, 3, 3, 1, 1, 0),      # 48 -> 96
+                    (64, 64, 64, 96, 96, 48, 48, 3, 3, 1, 1, 0),      # 96 -> 48
+                    (64, 64, 64, 48, 48, 48, 48, 3, 3, 2, 1, 0),      # stride 2
+                    (64, 64, 64, 48, 48, 48, 48, 1, 1, 1, 0, 0),      # 1x1
+                    (64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 1)):     # NCHW output
+            assert L.egn_conv_plan_query(*bad, cfg, out) != 0
+        # ragged maps still plan (partial tiles are masked in the kernel)
+        assert _plan((3, 19, 13, 48, 48, 48, 48, 3, 3, 1, 1, 0), cfg=cfg)[5:8] == [8, 16, 1]
