@@ -54,7 +54,7 @@ def crop_boxes(img, centers, scales, out_wh, mean=IMAGENET_MEAN, std=IMAGENET_ST
 def load_rgb(path):
     from PIL import Image
     with Image.open(path) as im:
-        return np.asarray(im.convert('RGB'))
+        return np.array(im.convert('RGB'))          # a writable copy (torch.as_tensor warns otherwise)
 
 
 def crop_instances(model, annot_dict, images=None):
