@@ -63,6 +63,8 @@ SIGNATURES = {
     'egn_sigmoid_bwd_f32': (_i, [_p, _p, _p, C.c_long, _p]),
     'egn_packed_weight_floats': (C.c_long, [_i] * 5),
     'egn_pack_conv_weight_f32': (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),
+    'egn_pack_desc_bytes': (_i, []),
+    'egn_pack_conv_weights_batch_f32': (_i, [_p, _i, C.c_long, _p]),
     'egn_zero_insert2_f32': (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'egn_fuse_bwd_f32': (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     'egn_gaussian_targets_f32': (_i, [_p, _p, _i, _i, _i, _i, _d, _d, _d, _p, _p, _p]),

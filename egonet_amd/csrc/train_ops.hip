@@ -619,6 +619,64 @@ extern "C" int egn_pack_conv_weight_f32(const float* w, int Cout, int Cin, int K
   return (int)hipGetLastError();
 }
 
+// All filters of a model in ONE launch: the training step packs every conv weight twice
+// per iteration (forward + data-gradient filter, ~600 small launches for HRNet-W48);
+// the weights only change in the optimizer step, so the step packs them all up front.
+// descs (device memory): one egn_pack_desc per (weight, direction), `begin` = index of
+// its first float4 in the global enumeration, ascending; the kernel finds its
+// descriptor by binary search.
+struct egn_pack_desc {
+  const float* w;
+  float* dst;
+  int Cout, Cin, taps, dgrad;
+  long long begin;  // first float4 of this descriptor
+};
+
+__global__ __launch_bounds__(256) void pack_conv_weights_batch_kernel(const egn_pack_desc* __restrict__ descs, int n,
+                                                                      long long total) {
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {  // last descriptor with begin <= e
+      const int mid = (lo + hi + 1) >> 1;
+      if (descs[mid].begin <= e) lo = mid; else hi = mid - 1;
+    }
+    const egn_pack_desc d = descs[lo];
+    const long long le = e - d.begin;
+    const int n_out = d.dgrad ? d.Cin : d.Cout;
+    const int n_in = d.dgrad ? d.Cout : d.Cin;
+    const int CoP = (n_out + 15) & ~15;
+    const int o = (int)(le % CoP);
+    long long r_ = le / CoP;
+    const int quad = (int)(r_ % 4);
+    r_ /= 4;
+    const int tap = (int)(r_ % d.taps);
+    const int chunk = (int)(r_ / d.taps);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (o < n_out) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = chunk * EGN_CK + quad * 4 + r;
+        if (i < n_in)
+          v[r] = d.dgrad ? d.w[((size_t)i * d.Cin + o) * d.taps + (d.taps - 1 - tap)]
+                         : d.w[((size_t)o * d.Cin + i) * d.taps + tap];
+      }
+    }
+    reinterpret_cast<float4*>(d.dst)[le] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+extern "C" int egn_pack_desc_bytes(void) { return (int)sizeof(egn_pack_desc); }
+
+extern "C" int egn_pack_conv_weights_batch_f32(const void* descs_dev, int n, long total_float4, void* stream) {
+  if (!descs_dev || n <= 0 || total_float4 <= 0) return EGN_E_BADARG;
+  size_t g = ((size_t)total_float4 + 255) / 256;
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(pack_conv_weights_batch_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const egn_pack_desc*>(descs_dev), n, (long long)total_float4);
+  return (int)hipGetLastError();
+}
+
 // up[n][2y][2x][:] = dy[n][y][x][:], everything else zero (data gradient of a
 // stride-2 convolution = stride-1 convolution over the zero-inserted dy)
 __global__ __launch_bounds__(256) void zero_insert2_kernel(const float4* __restrict__ dy, float4* __restrict__ up,

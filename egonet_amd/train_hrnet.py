@@ -84,6 +84,73 @@ class FlatParams(object):
                                                     betas[1], eps, _lib.ptr(self.step_dev), stream), 'adam')
 
 
+class PackedFilters(object):
+    """The packed forward / data-gradient filters of every conv weight of a model.
+
+    The weights change once per iteration (in the optimizer step), so from the second
+    step on ALL filters are packed by one launch at the start of the step
+    (``egn_pack_conv_weights_batch_f32``) instead of ~600 small ones; the first step
+    packs them one by one while it discovers which (weight, direction) pairs exist."""
+
+    _DESC = [('w', '<u8'), ('dst', '<u8'), ('Cout', '<i4'), ('Cin', '<i4'), ('taps', '<i4'), ('dgrad', '<i4'),
+             ('begin', '<i8')]
+
+    def __init__(self, device):
+        self.dev = device
+        self.L = _lib.lib()
+        self.entries = {}          # (id(weight), dgrad) -> (weight, packed tensor)
+        self.table = None          # device descriptor table once the set is known
+        self.total = 0
+        self.ptrs = None
+
+    def get(self, weight, dgrad, stream):
+        ent = self.entries.get((id(weight), dgrad))
+        if ent is not None and self.table is not None:
+            return ent[1]
+        cout, cin, kh, kw = weight.shape
+        if ent is None:
+            wp = torch.empty(self.L.egn_packed_weight_floats(cout, cin, kh, kw, dgrad), dtype=torch.float32,
+                             device=self.dev)
+            self.entries[(id(weight), dgrad)] = (weight, wp)
+            self.table = None
+        else:
+            wp = ent[1]
+        _lib.check(self.L.egn_pack_conv_weight_f32(_lib.ptr(weight), cout, cin, kh, kw, dgrad, _lib.ptr(wp), stream),
+                   'pack')
+        return wp
+
+    def _pointers(self):
+        return [w.data_ptr() for (w, _) in self.entries.values()]
+
+    def finalize(self):
+        """Build the device descriptor table for the (weight, direction) pairs seen so far."""
+        import numpy as np
+        if self.table is not None or not self.entries:
+            return
+        desc = np.zeros(len(self.entries), dtype=np.dtype(self._DESC, align=True))
+        assert desc.dtype.itemsize == self.L.egn_pack_desc_bytes(), (desc.dtype.itemsize, self.L.egn_pack_desc_bytes())
+        begin = 0
+        for i, ((_, dgrad), (w, wp)) in enumerate(self.entries.items()):
+            cout, cin, kh, kw = w.shape
+            desc[i] = (w.data_ptr(), wp.data_ptr(), cout, cin, kh * kw, dgrad, begin)
+            begin += wp.numel() // 4
+        self.total = begin
+        self.table = torch.from_numpy(desc.view(np.uint8)).to(self.dev)
+        self.ptrs = self._pointers()
+
+    def pack_all(self, stream):
+        """One launch for every filter; False if the table is not built yet (first step) or a
+        parameter was re-allocated since (``.to()`` / ``load_state_dict`` on a new storage)."""
+        if self.table is None:
+            return False
+        if self._pointers() != self.ptrs:
+            self.table = None
+            return False
+        _lib.check(self.L.egn_pack_conv_weights_batch_f32(_lib.ptr(self.table), len(self.entries), self.total,
+                                                          stream), 'pack all')
+        return True
+
+
 class _Tape(object):
     """Recorder interface of ``engine._Recorder`` that EXECUTES train-mode layers."""
 
@@ -145,11 +212,7 @@ class _Tape(object):
 
     # -- launches -----------------------------------------------------------
     def _pack(self, weight, dgrad):
-        cout, cin, kh, kw = weight.shape
-        wp = self._empty(self.L.egn_packed_weight_floats(cout, cin, kh, kw, dgrad))
-        _lib.check(self.L.egn_pack_conv_weight_f32(_lib.ptr(weight), cout, cin, kh, kw, dgrad, _lib.ptr(wp), self.st),
-                   'pack')
-        return wp
+        return self.o.packs.get(weight, dgrad, self.st)
 
     def _conv_launch(self, x, wp, shift, y, n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, act):
         key = (n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, False, False)
@@ -362,6 +425,7 @@ class HRNetTrainStep(object):
         self._wgrad_ws = None
         self.loss_dev = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.walker = HRNetEngine(model)
+        self.packs = PackedFilters(self.dev)
         self.last_maps = self.last_coords = None
         self.debug_hook = None        # tools/train_debug.py: per-layer checks of the BatchNorm backward
 
@@ -388,6 +452,7 @@ class HRNetTrainStep(object):
         with torch.cuda.device(self.dev):
             st = _lib.current_stream(self.dev)
             self.flat.grad.zero_()
+            self.packs.pack_all(st)          # every forward / data-gradient filter, one launch
             tape = _Tape(self, images)
             self.walker._record(n, cin, h, w, None, r=tape)
             torch._foreach_add_([bn.num_batches_tracked for bn in tape.bns], 1)
@@ -442,6 +507,7 @@ class HRNetTrainStep(object):
                 self.grad_sync(self.flat.grad)
             if update:
                 self.flat.adam_step(self.lr, self.betas, self.eps, st)
+            self.packs.finalize()     # first step: the set of filters is known now
             m._engine = None          # the inference engine caches folded weights
             if self.debug_hook is not None:
                 self.last_tape = tape

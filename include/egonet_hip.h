@@ -258,6 +258,14 @@ int egn_sigmoid_bwd_f32(const float* dy, const float* y, float* dz, long n,
 long egn_packed_weight_floats(int Cout, int Cin, int KH, int KW, int dgrad);
 int egn_pack_conv_weight_f32(const float* w, int Cout, int Cin, int KH, int KW,
                              int dgrad, float* dst, void* stream);
+/* Every filter of a model packed in ONE launch (the weights only change in the
+ * optimizer step; a W48 training step needs ~600 packs).  descs: DEVICE array of
+ *   struct { const float* w; float* dst; int32 Cout, Cin, taps, dgrad; int64 begin; }
+ * (egn_pack_desc_bytes() bytes each), `begin` = running sum of the float4 counts
+ * egn_packed_weight_floats()/4 of the preceding descriptors. */
+int egn_pack_desc_bytes(void);
+int egn_pack_conv_weights_batch_f32(const void* descs_dev, int n, long total_float4,
+                                    void* stream);
 /* up[n][2y][2x][:] = dy[n][y][x][:], zero elsewhere; up is [N,H,W,cs] */
 int egn_zero_insert2_f32(const float* dy, float* up, int N, int Ho, int Wo,
                          int H, int W, int cs, void* stream);

@@ -382,6 +382,30 @@ def test_conv_wgrad_refuses_unsupported():
                                   _lib.ptr(a), 256, _st()) != 0                       # cs_in % 4
 
 
+def test_all_filters_packed_in_one_launch_equal_the_single_packs():
+    from egonet_amd.train_hrnet import PackedFilters
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    ws = [torch.randn(*s, generator=g).cuda() for s in ((48, 48, 3, 3), (33, 48, 1, 1), (66, 35, 3, 3), (66, 66, 4, 4))]
+    pf = PackedFilters(torch.device('cuda', torch.cuda.current_device()))
+    assert pf.pack_all(_st()) is False                        # nothing known yet
+    for w in ws:
+        for dgrad in (0, 1):
+            pf.get(w, dgrad, _st())
+    pf.finalize()
+    for w in ws:                                              # the optimizer step changes the weights in place
+        w.mul_(1.5).add_(0.25)
+    assert pf.pack_all(_st()) is True
+    for w in ws:
+        cout, cin, kh, kw = w.shape
+        for dgrad in (0, 1):
+            want = torch.zeros(L.egn_packed_weight_floats(cout, cin, kh, kw, dgrad), device='cuda')
+            _lib.check(L.egn_pack_conv_weight_f32(_lib.ptr(w), cout, cin, kh, kw, dgrad, _lib.ptr(want), _st()))
+            assert torch.equal(pf.get(w, dgrad, _st()), want)
+    ws[1].data = ws[1].data.clone()                           # storage moved: the table is rebuilt, not trusted
+    assert pf.pack_all(_st()) is False
+
+
 def test_bad_arguments_are_refused():
     L = _lib.lib()
     a = torch.zeros(16, device='cuda')
