@@ -427,7 +427,7 @@ class HRNetTrainStep(object):
         self.walker = HRNetEngine(model)
         self.packs = PackedFilters(self.dev)
         self.last_maps = self.last_coords = None
-        self.debug_hook = None        # tools/train_debug.py: per-layer checks of the BatchNorm backward
+        self.debug_hook = None        # tests/train_debug.py: per-layer checks of the BatchNorm backward
 
     def wgrad_ws(self, nbytes):
         if self._wgrad_ws is None or self._wgrad_ws.numel() * 4 < nbytes:

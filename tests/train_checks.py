@@ -3,7 +3,7 @@
 End-to-end gradient comparisons of a deep ReLU network in fp32 are limited by
 ReLU ties: an element whose pre-activation is within rounding of 0 gets gate 1
 in one implementation and 0 in another, and everything below it changes by a
-finite amount (measured on MI355X, tools/train_debug.py: HRNet-W48, 2 crops:
+finite amount (measured on MI355X, tests/train_debug.py: HRNet-W48, 2 crops:
 99 of 30.8 M block-output gates differ from torch's own GPU autograd ->
 gradient cosine 0.99985; tiny net without a flipped gate: relative L2 1e-5).
 

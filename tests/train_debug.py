@@ -1,7 +1,7 @@
 """Diagnostics of the native HRNet training step against the CPU oracle and against
 torch's own GPU autograd.
 
-    python tools/train_debug.py [tiny_heatmap|tiny_coords|w48] [batch] [seed] [check] [torchcmp]
+    python tests/train_debug.py [tiny_heatmap|tiny_coords|w48] [batch] [seed] [check] [torchcmp]
 
   (default)  per-tensor gradient error vs the CPU oracle (fp32) and, for the tiny
              nets, the oracle's own fp32-vs-fp64 floor

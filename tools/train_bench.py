@@ -1,12 +1,11 @@
 """BASELINE config 3: FC lifter forward + backward + Adam, batch 4096 2D->3D
 key-point sets on one MI355X, native HIP path (egonet_amd.train_lifter).
 
-    python tools/train_bench.py [--batch 4096] [--steps 50] [--warmup 5] [--cpu]
+    python tools/train_bench.py [--batch 4096] [--steps 50] [--warmup 5] [--graph]
 
-Prints one JSON line: sets/s, ms/step, the GEMM flop rate (3 GEMMs per Linear:
-forward, dgrad, wgrad; 2*M*N*K each) and, with --cpu, the CPU oracle timed on a
-few steps of the same batch (test infrastructure, reported beside, never the
-thing measured).
+Prints one JSON line: sets/s, ms/step and the GEMM flop rate (3 GEMMs per
+Linear: forward, dgrad, wgrad; 2*M*N*K each).  The CPU oracle's rate on the same
+batch is printed by tests/cpu_baselines.py (test infrastructure).
 """
 import argparse
 import json
@@ -38,7 +37,6 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dropout', type=float, default=0.5)
-    ap.add_argument('--cpu', action='store_true')
     ap.add_argument('--graph', action='store_true', help='replay the step as one hipGraph')
     a = ap.parse_args()
     cfg = configs.w48_config()
@@ -87,18 +85,6 @@ def main():
         'config': {'workload': 'train_lifting FCModel(66->96, 1024x2 blocks) fwd+bwd+Adam', 'batch': a.batch,
                    'dropout': a.dropout, 'steps': a.steps, 'warmup': a.warmup, 'hipgraph': bool(a.graph)},
     }
-    if a.cpu:
-        from oracle.lifter_train_oracle import LifterTrainOracle
-        torch.set_num_threads(min(16, os.cpu_count() or 1))
-        orc = LifterTrainOracle(sd, lr=1e-3)
-        orc.step(x, y)
-        t0 = time.perf_counter()
-        n = 3
-        for _ in range(n):
-            orc.step(x, y)
-        dt = (time.perf_counter() - t0) / n
-        out['cpu_baseline'] = {'value': round(a.batch / dt, 1), 'unit': 'sets/s', 'cores': torch.get_num_threads(),
-                               'kind': 'port', 'sample': '%d steps of the same batch (p=0)' % n}
     print(json.dumps(out))
 
 
