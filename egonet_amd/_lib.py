@@ -60,6 +60,8 @@ SIGNATURES = {
     'egn_add_f32': (_i, [_p, _p, _p, C.c_long, _p]),
     'egn_mse_f32': (_i, [_p, _p, _i, _i, _i, _i, C.c_float, _i, _p, _p, _p]),
     'egn_l1_f32': (_i, [_p, _p, C.c_long, C.c_float, _p, _p, _p]),
+    'egn_cross_ratio_ws_bytes': (C.c_long, [_i, _i]),
+    'egn_cross_ratio_f32': (_i, [_p, _i, _i, _p, _i, _d, C.c_float, _i, C.c_float, _p, _p, _p, _p]),
     'egn_sigmoid_bwd_f32': (_i, [_p, _p, _p, C.c_long, _p]),
     'egn_packed_weight_floats': (C.c_long, [_i] * 5),
     'egn_pack_conv_weight_f32': (_i, [_p, _i, _i, _i, _i, _i, _p, _p]),

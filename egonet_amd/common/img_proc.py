@@ -19,6 +19,19 @@ from .. import _lib
 SIZE = 200.0
 
 
+def get_cr_indices():
+    """The 12 four-point lines of the 33-joint cuboid the cross-ratio term runs over
+    (car_instance.py:83-119): joint 0 = centre, 1..8 = corners, 9+l / 21+l = the two
+    interpolated points on edge l, whose end corners are (parent[l], child[l]) -- edges
+    0-3 along h, 4-7 along l, 8-11 along w.  Row l = [parent, 9+l, 21+l, child]."""
+    parent = [1, 3, 5, 7, 1, 2, 3, 4, 1, 2, 5, 6]
+    child = [2, 4, 6, 8, 5, 6, 7, 8, 3, 4, 7, 8]
+    return np.array([[parent[e], 9 + e, 21 + e, child[e]] for e in range(12)], dtype=np.int64)
+
+
+CR_INDICES_BBOX12 = get_cr_indices()
+
+
 def _decode(t, mode, want_idx=True):
     if not (torch.is_tensor(t) and t.is_cuda):
         raise TypeError('decode kernels need a CUDA tensor; there is no CPU fallback')
@@ -42,6 +55,17 @@ def soft_arg_max(batch_heatmaps):
     return xy, mx
 
 
+def soft_arg_max_np(batch_heatmaps):
+    """img_proc.py:639-676: centre of mass with weights hm / sum(hm), zeroed where
+    the maximum is <= 0.  numpy in -> numpy out like the reference (which, as a side
+    effect not reproduced here, also normalises the caller's array in place)."""
+    assert isinstance(batch_heatmaps, np.ndarray), 'batch_heatmaps should be numpy.ndarray'
+    assert batch_heatmaps.ndim == 4, 'batch_images should be 4-ndim'
+    t = torch.from_numpy(np.ascontiguousarray(batch_heatmaps, dtype=np.float32)).cuda()
+    xy, mx, _ = _decode(t, 2, want_idx=False)
+    return xy.cpu().numpy(), mx.cpu().numpy()
+
+
 def hard_arg_max(batch_heatmaps):
     """(preds, maxvals, flat arg-max index [N,K] int32) on the device."""
     return _decode(batch_heatmaps, 0, want_idx=True)
@@ -57,6 +81,40 @@ def get_max_preds(batch_heatmaps):
         return xy.cpu().numpy(), mx.cpu().numpy()
     xy, mx, _ = _decode(batch_heatmaps, 0, want_idx=False)
     return xy, mx
+
+
+# -- crop affine (host, per instance) ----------------------------------------
+
+def get_affine_transform(center, scale, rot, output_size, shift=(0.0, 0.0), inv=0):
+    """2x3 float64 affine of the crop defined by (center, scale*200 px, rotation in degrees)
+    onto an ``output_size`` = (h, w) window -- img_proc.py:26-64.  Like there, the map is
+    fixed by three point pairs held in float32 (centre; the point half a source width
+    'above' it, rotated; the right-angle completion of the two) and solved exactly
+    (cv2.getAffineTransform); ``inv`` swaps the roles (window -> image)."""
+    scale_px = np.asarray(scale, dtype=np.float64) * SIZE
+    center = np.asarray(center, dtype=np.float64)
+    shift = np.asarray(shift, dtype=np.float64)
+    dst_h, dst_w = output_size
+    rad = np.pi * rot / 180
+    up = -0.5 * scale_px[0]                                   # (0, -src_w/2) rotated by rad
+    src_dir = np.array([-up * np.sin(rad), up * np.cos(rad)])
+    tri = np.zeros((2, 3, 2), dtype=np.float32)               # [src|dst][point][xy]
+    tri[0, 0] = center + scale_px * shift
+    tri[0, 1] = center + src_dir + scale_px * shift
+    tri[1, 0] = [dst_w * 0.5, dst_h * 0.5]
+    tri[1, 1] = np.array([dst_w * 0.5, dst_h * 0.5]) + np.array([0, dst_w * -0.5], np.float32)
+    for t in tri:                                             # third point: b + perp(a - b)
+        d = t[0] - t[1]
+        t[2] = t[1] + np.array([-d[1], d[0]], dtype=np.float32)
+    a, b = (tri[1], tri[0]) if inv else (tri[0], tri[1])
+    m = np.hstack([a.astype(np.float64), np.ones((3, 1))])
+    return np.linalg.solve(m, b.astype(np.float64)).T
+
+
+def affine_transform_modified(pts, t):
+    """[n,2] points through a 2x3 affine (img_proc.py:71-78)."""
+    pts = np.asarray(pts)
+    return (t @ np.hstack([pts, np.ones((len(pts), 1))]).T)[:2].T
 
 
 # -- bounding-box helpers (host, per box) -----------------------------------

@@ -45,9 +45,18 @@ struct WgradArgs {
 // tiles for the 48 / 96 channel branches, 9 instead of 16 MFMAs per K step).
 // PF = software pipeline: the next pixel tile's global loads are issued into
 // registers before the MFMA loop of the current one (A_IT / B_IT float4 per lane).
-template <int NTAPW, int TPW, int WM, int WN, int J, int A_IT, int B_IT>
-__global__ __launch_bounds__(64 * NTAPW * WM * WN) void conv_wgrad_kernel(WgradArgs a) {
-  constexpr int NT = 64 * NTAPW * WM * WN;
+//
+// KS > 1 = K slices inside the block: KS groups of NTAPW*WM*WN waves share the staged
+// tiles, group ks takes the K steps s = ks (mod KS), and the groups' accumulators are
+// summed through LDS (fixed order) before the ONE partial of the block is written.
+// <3,3,1,1,3,..,4>: three waves own one filter column each (TPW = 3 taps, 27 MFMAs per
+// K step and four LDS reads), four K slices -> 12 waves = 3 per SIMD, where the
+// 9-waves-one-per-tap layout leaves the SIMDs with 3/2/2/2 waves (130 VGPRs: one block
+// per CU) -- the 3x3 layers of the 48/96/192/384-channel branches.
+template <int NTAPW, int TPW, int WM, int WN, int J, int A_IT, int B_IT, int KS = 1>
+__global__ __launch_bounds__(64 * NTAPW * WM * WN * KS) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int NT = 64 * NTAPW * WM * WN * KS;
+  constexpr int NW1 = NTAPW * WM * WN;       // waves of one K slice
   constexpr int WT = 16 * J;                 // channels per wave tile
   constexpr int CW = WT * WM, IW = WT * WN;  // channels per block tile
   constexpr int CW4 = CW / 4, IW4 = IW / 4;
@@ -58,7 +67,9 @@ __global__ __launch_bounds__(64 * NTAPW * WM * WN) void conv_wgrad_kernel(WgradA
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ks = wave_all / NW1;
+  const int wave = wave_all % NW1;
   const int tapw = wave / (WM * WN);
   const int wm = (wave / WN) % WM;
   const int wn = wave % WN;
@@ -153,7 +164,7 @@ __global__ __launch_bounds__(64 * NTAPW * WM * WN) void conv_wgrad_kernel(WgradA
     if (tile + 1 < t_end) EGN_WG_LOAD(tile + 1);  // in flight during the MFMA loop below
     const float* pa = sA + wm * WT + J * li;
     const float* pb = sB + wn * WT + J * li;
-    for (int s = 0; s < a.TP / 4; ++s) {
+    for (int s = ks; s < a.TP / 4; s += KS) {
       const int p = 4 * s + kq;
       const int b = p >> a.lg_thw, rem = p & thw_mask;
       const int hbase = (b * a.HH + (rem >> a.lg_tw) * a.stride) * a.HWd + (rem & tw_mask) * a.stride;
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(64 * NTAPW * WM * WN) void conv_wgrad_kernel(WgradA
       for (int j = 0; j < J; ++j) av[j] = pa[p * LDA + j];
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
-        if (tap_off[t] >= 0) {
+        if (KS > 1 || tap_off[t] >= 0) {   // the K-sliced variant only runs full 3x3 filters
           float bv[J];
 #pragma unroll
           for (int j = 0; j < J; ++j) bv[j] = pb[(hbase + tap_off[t]) * LDB + j];
@@ -176,6 +187,32 @@ __global__ __launch_bounds__(64 * NTAPW * WM * WN) void conv_wgrad_kernel(WgradA
     }
   }
 #undef EGN_WG_LOAD
+
+  if constexpr (KS > 1) {
+    // sum the K slices: slice r parks its accumulators in LDS, slice 0 adds them, r = 1..KS-1
+    f32x4* rbuf = reinterpret_cast<f32x4*>(wsm) + (size_t)wave * (TPW * J * J) * 64 + lane;
+    for (int r = 1; r < KS; ++r) {
+      __syncthreads();
+      if (ks == r) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+          for (int ja = 0; ja < J; ++ja)
+#pragma unroll
+            for (int jb = 0; jb < J; ++jb) rbuf[((t * J + ja) * J + jb) * 64] = acc[t][ja][jb];
+      }
+      __syncthreads();
+      if (ks == 0) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+          for (int ja = 0; ja < J; ++ja)
+#pragma unroll
+            for (int jb = 0; jb < J; ++jb) acc[t][ja][jb] += rbuf[((t * J + ja) * J + jb) * 64];
+      }
+    }
+    if (ks != 0) return;
+  }
 
   // partial [split][tap][CoP][CiP]: lane owns rows J*(4kq+r)+ja, columns J*li .. J*li+J-1
 #pragma unroll
@@ -196,26 +233,51 @@ __global__ __launch_bounds__(64 * NTAPW * WM * WN) void conv_wgrad_kernel(WgradA
 }
 
 // dw[co][ci][tap] = sum_s part[s][tap][co][ci]   (fixed order: deterministic)
-// block = 64 elements x 4 split lanes: lane l sums splits l, l+4, ...; the four
-// lane sums are combined in lane order
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           int nsplit, int taps, int Cout, int Cin, int CoP, int CiP) {
-  __shared__ float red[4][64];
-  const size_t total = (size_t)taps * Cout * Cin;
-  const int el = threadIdx.x & 63, lane = threadIdx.x >> 6;
-  const size_t e = (size_t)blockIdx.x * 64 + el;
-  float s = 0.f;
-  int ci = 0, co = 0, tap = 0;
-  if (e < total) {
-    ci = (int)(e % Cin);
-    co = (int)((e / Cin) % Cout);
-    tap = (int)(e / ((size_t)Cin * Cout));
-    for (int k = lane; k < nsplit; k += 4) s += part[((size_t)(k * taps + tap) * CoP + co) * CiP + ci];
+// The partial slabs are dense [tap][CoP][CiP] (CiP % 4 == 0): block = 32 float4 elements
+// x LANES split lanes (32 for many splits, 8 for few), 512 B contiguous per wave load and
+// split; lane l sums splits l, l+LANES, ... (eight loads in flight), the lane sums are
+// combined in lane order.
+template <int LANES>
+__global__ __launch_bounds__(32 * LANES) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                  int nsplit, int taps, int Cout, int Cin, int CoP,
+                                                                  int CiP) {
+  __shared__ float4 red[LANES][32];
+  const int ci4n = CiP >> 2;
+  const size_t total4 = (size_t)taps * CoP * ci4n;
+  const int el = threadIdx.x & 31, lane = threadIdx.x >> 5;
+  const size_t e = (size_t)blockIdx.x * 32 + el;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < total4) {
+    const size_t stride4 = total4;
+    const float4* q = reinterpret_cast<const float4*>(part) + e;
+    for (int k0 = lane; k0 < nsplit; k0 += 8 * LANES) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = k0 + LANES * u;
+        v[u] = k < nsplit ? q[(size_t)k * stride4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
   }
   red[lane][el] = s;
   __syncthreads();
-  if (lane == 0 && e < total)
-    dw[((size_t)co * Cin + ci) * taps + tap] = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+  if (lane == 0 && e < total4) {
+    float4 t = red[0][el];
+#pragma unroll 4
+    for (int r = 1; r < LANES; ++r) { const float4 o = red[r][el]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+    const int ci = (int)(e % ci4n) * 4;
+    const int co = (int)((e / ci4n) % CoP);
+    const int tap = (int)(e / ((size_t)ci4n * CoP));
+    if (co < Cout) {
+      float* d = dw + ((size_t)co * Cin + ci) * taps + tap;
+      if (ci + 0 < Cin) d[0] = t.x;
+      if (ci + 1 < Cin) d[(size_t)taps] = t.y;
+      if (ci + 2 < Cin) d[(size_t)2 * taps] = t.z;
+      if (ci + 3 < Cin) d[(size_t)3 * taps] = t.w;
+    }
+  }
 }
 
 static int ilog2_exact(int v) {
@@ -234,14 +296,15 @@ constexpr int EGN_WGRAD_MAX_SPLITS = 512;
 struct WgradVariant {
   int ntapw, tpw, wm, wn;
   int j, a_it, b_it;  // channels per lane, register-staging depth (float4 per lane) of the dy / x tiles
+  int ks;             // K slices inside the block (0 = 1)
 };
 
 static int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 // 48-wide (J = 3) or 64-wide (J = 4) wave tiles: whichever pads Cout x Cin less
-static int pick_j(int cout, int cin, int wm, int wn) {
+static int pick_j(int cout, int cin, int wm, int wn, bool prefer3 = false) {
   const long c3 = (long)pad_to(cout, 48 * wm) * pad_to(cin, 48 * wn);
   const long c4 = (long)pad_to(cout, 64 * wm) * pad_to(cin, 64 * wn);
-  return c3 < c4 ? 3 : 4;
+  return (c3 < c4 || (prefer3 && c3 == c4)) ? 3 : 4;
 }
 
 static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
@@ -258,13 +321,18 @@ static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
         : (a.Cin > 64)              ? WgradVariant{1, 1, 1, 2, 4, 4, 8}
                                     : WgradVariant{1, 1, 1, 1, pick_j(a.Cout, a.Cin, 1, 1), 8, 8};
   } else if (a.taps <= 9) {
-    v = WgradVariant{9, 1, 1, 1, pick_j(a.Cout, a.Cin, 1, 1), 2, 5};  // waves whose tap does not exist idle
+    static const bool sliced = !(getenv("EGN_WGRAD_KSLICE") && !atoi(getenv("EGN_WGRAD_KSLICE")));
+    const int j = pick_j(a.Cout, a.Cin, 1, 1, sliced && a.KH == 3 && a.KW == 3);
+    if (sliced && a.KH == 3 && a.KW == 3 && j == 3)
+      v = WgradVariant{3, 3, 1, 1, 3, 2, 5, 4};                        // one wave per filter column x 4 K slices
+    else
+      v = WgradVariant{9, 1, 1, 1, j, 2, 5};                           // waves whose tap does not exist idle
   } else if (a.taps <= 16) {
     v = WgradVariant{8, 2, 1, 1, pick_j(a.Cout, a.Cin, 1, 1), 2, 5};
   } else {
     return EGN_E_BADARG;
   }
-  const int NT = 64 * v.ntapw * v.wm * v.wn;
+  const int NT = 64 * v.ntapw * v.wm * v.wn * std::max(1, v.ks);
   const int CW = 16 * v.j * v.wm, IW = 16 * v.j * v.wn;
   a.co_tiles = (a.Cout + CW - 1) / CW;
   a.ci_tiles = (a.Cin + IW - 1) / IW;
@@ -273,8 +341,9 @@ static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
   // pixels per tile: 64, or 128 (8 x 16) for the 48-wide 3x3 variant, whose two tiles still
   // fit twice per CU (65.7 KB): half as many barriers per MFMA
   static const bool big_tiles = !(getenv("EGN_WGRAD_TP64") && atoi(getenv("EGN_WGRAD_TP64")));
-  const bool tp128 = big_tiles && v.ntapw == 9 && v.j == 3 && a.stride == 1;
-  if (tp128) v.a_it = 3;
+  const bool tp128 = big_tiles && (v.ntapw == 9 || v.ks == 4) && v.j == 3 && a.stride == 1;
+  if (tp128 && v.ks == 4) v.b_it = 3;      // 768 threads: 128 x 12 and 180 x 12 float4 in 2 + 3 rounds
+  else if (tp128) v.a_it = 3;
   const int tp_target = tp128 ? 128 : 64;
   a.TW = std::min(pow2_ceil(a.Wo), tp128 ? 16 : 8);
   a.TH = std::min(pow2_ceil(a.Ho), 8);
@@ -295,6 +364,8 @@ static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
     else if (lds <= 150 * 1024 && regs_ok) break;
     else return EGN_E_BADARG;
   }
+  if (v.ks > 1)  // the K slices meet in LDS: ntapw waves x tpw*j*j accumulators x 64 lanes x 16 B
+    lds = std::max(lds, (size_t)v.ntapw * v.wm * v.wn * v.tpw * v.j * v.j * 64 * 16);
   a.lg_tw = ilog2_exact(a.TW);
   a.lg_thw = ilog2_exact(a.TH * a.TW);
   a.tiles_x = (a.Wo + a.TW - 1) / a.TW;
@@ -316,11 +387,15 @@ static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
   return 0;
 }
 
-template <int NTAPW, int TPW, int WM, int WN, int J, int A_IT, int B_IT>
+template <int NTAPW, int TPW, int WM, int WN, int J, int A_IT, int B_IT, int KS = 1>
 static int wgrad_launch(const WgradArgs& a, size_t lds, hipStream_t stream) {
-  auto k = conv_wgrad_kernel<NTAPW, TPW, WM, WN, J, A_IT, B_IT>;
-  if (lds > 64 * 1024) EGN_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k, dim3(a.co_tiles * a.ci_tiles, a.nsplit), dim3(64 * NTAPW * WM * WN), lds, stream, a);
+  auto k = conv_wgrad_kernel<NTAPW, TPW, WM, WN, J, A_IT, B_IT, KS>;
+  static bool raised = false;  // per instantiation; one device per process (a driver call per launch costs ~10 us of host time)
+  if (!raised) {
+    EGN_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+    raised = true;
+  }
+  hipLaunchKernelGGL(k, dim3(a.co_tiles * a.ci_tiles, a.nsplit), dim3(64 * NTAPW * WM * WN * KS), lds, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -349,7 +424,8 @@ extern "C" int egn_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
   if (rc != 0) return rc;
   if ((size_t)ws_bytes < (size_t)a.nsplit * a.taps * a.CoP * a.CiP * sizeof(float)) return EGN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (v.ntapw == 9 && v.j == 3) rc = v.a_it == 3 ? wgrad_launch<9, 1, 1, 1, 3, 3, 5>(a, lds, st) : wgrad_launch<9, 1, 1, 1, 3, 2, 5>(a, lds, st);
+  if (v.ks == 4) rc = v.b_it == 3 ? wgrad_launch<3, 3, 1, 1, 3, 2, 3, 4>(a, lds, st) : wgrad_launch<3, 3, 1, 1, 3, 2, 5, 4>(a, lds, st);
+  else if (v.ntapw == 9 && v.j == 3) rc = v.a_it == 3 ? wgrad_launch<9, 1, 1, 1, 3, 3, 5>(a, lds, st) : wgrad_launch<9, 1, 1, 1, 3, 2, 5>(a, lds, st);
   else if (v.ntapw == 9) rc = wgrad_launch<9, 1, 1, 1, 4, 2, 5>(a, lds, st);
   else if (v.ntapw == 8) rc = v.j == 3 ? wgrad_launch<8, 2, 1, 1, 3, 2, 5>(a, lds, st) : wgrad_launch<8, 2, 1, 1, 4, 2, 5>(a, lds, st);
   else if (v.wm == 2 && v.wn == 2) rc = wgrad_launch<1, 1, 2, 2, 4, 4, 4>(a, lds, st);
@@ -357,8 +433,12 @@ extern "C" int egn_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
   else if (v.wn == 2) rc = wgrad_launch<1, 1, 1, 2, 4, 4, 8>(a, lds, st);
   else rc = v.j == 3 ? wgrad_launch<1, 1, 1, 1, 3, 8, 8>(a, lds, st) : wgrad_launch<1, 1, 1, 1, 4, 8, 8>(a, lds, st);
   if (rc != 0) return rc;
-  const size_t total = (size_t)a.taps * Cout * Cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, a.part, dw, a.nsplit,
-                     a.taps, Cout, Cin, a.CoP, a.CiP);
+  const size_t total4 = (size_t)a.taps * a.CoP * (a.CiP / 4);
+  if (a.nsplit > 64)
+    hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3((unsigned)((total4 + 31) / 32)), dim3(1024), 0, st, a.part, dw,
+                       a.nsplit, a.taps, Cout, Cin, a.CoP, a.CiP);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, st, a.part, dw,
+                       a.nsplit, a.taps, Cout, Cin, a.CoP, a.CiP);
   return (int)hipGetLastError();
 }

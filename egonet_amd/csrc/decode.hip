@@ -7,6 +7,9 @@
 // soft (img_proc.py:678-707): softmax over the flattened map, then
 //   x = sum_w w * sum_h p, y = sum_h h * sum_w p  ==  sum_i p_i * (x_i, y_i);
 //   maxvals = raw maximum.
+// soft-np (img_proc.py:639-676 soft_arg_max_np): same moments with the weights
+//   hm / sum(hm) (the np.clip there acts on a copy that is not used), zeroed where
+//   max <= 0.
 #include "egn_internal.h"
 
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
   } else {
     float s = 0.f, sx = 0.f, sy = 0.f;
     for (int i = lane; i < hw; i += 64) {
-      const float e = __expf(p[i] - best);
+      const float e = mode == 1 ? __expf(p[i] - best) : p[i];
       const int y = i / W;
       const int x = i - y * W;
       s += e;
@@ -63,6 +66,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
     sy = wave_sum(sy);
     ox = sx / s;
     oy = sy / s;
+    if (mode == 2 && !(best > 0.0f)) { ox = 0.f; oy = 0.f; }
   }
   if (lane == 0) {
     out_xy[2 * (size_t)map] = ox;
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
 
 extern "C" int egn_decode_heatmaps_f32(const float* hm, int N, int K, int H, int W, int mode,
                                        float* out_xy, float* out_max, int32_t* out_idx, void* stream) {
-  if (N < 0 || K <= 0 || H <= 0 || W <= 0 || (mode != 0 && mode != 1)) return EGN_E_BADARG;
+  if (N < 0 || K <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2) return EGN_E_BADARG;
   const int nmaps = N * K;
   if (nmaps == 0) return 0;
   const int waves_per_block = 4;

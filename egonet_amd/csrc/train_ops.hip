@@ -146,39 +146,52 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(ColArgs p, doubl
     }
     float f0[4] = {0, 0, 0, 0}, f1[4] = {0, 0, 0, 0};
     int cnt = 0;
-    for (int r = r_lo + rl; r < r_hi; r += RL) {
-      const size_t i = (size_t)r * p.ld + c0;
-      const float4 v4 = *reinterpret_cast<const float4*>(p.a + i);
-      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-      if (p.mode == 0) {
+    // four rows per round: their loads are issued together (one block per CU and a chain
+    // of dependent round trips otherwise -- the kernel is latency bound, not bandwidth bound)
+    for (int r = r_lo + rl; r < r_hi; r += 4 * RL) {
+      float4 v4[4], d4[4], m4[4], r4[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) f0[k] += v[k];
-      } else if (p.mode == 1) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { f0[k] += v[k]; f1[k] += v[k] * v[k]; }
-      } else {
-        const float4 d4 = *reinterpret_cast<const float4*>(p.dy + i);
-        float d[4] = {d4.x, d4.y, d4.z, d4.w};
-        if (p.mask) {
-          const float4 m4 = *reinterpret_cast<const float4*>(p.mask + i);
-          d[0] *= m4.x * p.keep_scale; d[1] *= m4.y * p.keep_scale;
-          d[2] *= m4.z * p.keep_scale; d[3] *= m4.w * p.keep_scale;
-        }
-        float rs[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.res) {
-          const float4 r4 = *reinterpret_cast<const float4*>(p.res + i);
-          rs[0] = r4.x; rs[1] = r4.y; rs[2] = r4.z; rs[3] = r4.w;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float xhat = (v[k] - mean[k]) * istd[k];
-          float dd = d[k];
-          if (p.relu && !(gm[k] * xhat + bt[k] + rs[k] > 0.f)) dd = 0.f;
-          f0[k] += dd;
-          f1[k] += dd * xhat;
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + u * RL;
+        const bool ok = rr < r_hi;
+        const size_t i = (size_t)(ok ? rr : r) * p.ld + c0;
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        v4[u] = ok ? *reinterpret_cast<const float4*>(p.a + i) : zero;
+        if (p.mode == 2) {
+          d4[u] = ok ? *reinterpret_cast<const float4*>(p.dy + i) : zero;   // dy = 0: the row adds nothing
+          if (p.mask) m4[u] = *reinterpret_cast<const float4*>(p.mask + i);
+          if (p.res) r4[u] = *reinterpret_cast<const float4*>(p.res + i);
         }
       }
-      if (++cnt == 64) {  // flush the fp32 partials to double every 64 terms
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float v[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+        if (p.mode == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) f0[k] += v[k];
+        } else if (p.mode == 1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { f0[k] += v[k]; f1[k] += v[k] * v[k]; }
+        } else {
+          float d[4] = {d4[u].x, d4[u].y, d4[u].z, d4[u].w};
+          if (p.mask) {
+            d[0] *= m4[u].x * p.keep_scale; d[1] *= m4[u].y * p.keep_scale;
+            d[2] *= m4[u].z * p.keep_scale; d[3] *= m4[u].w * p.keep_scale;
+          }
+          float rs[4] = {0.f, 0.f, 0.f, 0.f};
+          if (p.res) { rs[0] = r4[u].x; rs[1] = r4[u].y; rs[2] = r4[u].z; rs[3] = r4[u].w; }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float xhat = (v[k] - mean[k]) * istd[k];
+            float dd = d[k];
+            if (p.relu && !(gm[k] * xhat + bt[k] + rs[k] > 0.f)) dd = 0.f;
+            f0[k] += dd;
+            f1[k] += dd * xhat;
+          }
+        }
+      }
+      cnt += 4;
+      if (cnt >= 64) {  // flush the fp32 partials to double every 64 terms
 #pragma unroll
         for (int k = 0; k < 4; ++k) { s0[k] += f0[k]; s1[k] += f1[k]; f0[k] = 0.f; f1[k] = 0.f; }
         cnt = 0;

@@ -399,8 +399,10 @@ class _Tape(object):
 class HRNetTrainStep(object):
     """``step(images, target, joints_xy)`` = one iteration of trainer.py:183-209."""
 
+    CR_CRITERIA = {'mse': 0, 'l1': 1, 'sl1': 2}      # loss_dict, function.py:17-20
+
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, w_hm=1.0, w_coor=0.1, grad_sync=None,
-                 sigma=1):
+                 sigma=1, w_cr=None, cr_type='sl1', cr_indices=None, target_cr=4.0 / 3.0, cr_loss_thres=0.15):
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise ValueError('HRNetTrainStep needs the model on a GPU')
@@ -414,8 +416,26 @@ class HRNetTrainStep(object):
         self.L = _lib.lib()
         self.lr, self.betas, self.eps = lr, betas, eps
         self.w_hm, self.w_coor = float(w_hm), float(w_coor or 0.0)
+        # cross-ratio term (function.py:113-153, train_IGRs.py:44-46): off unless a weight is
+        # given ('None' in the shipped YAML) AND apply_cr_loss is set (trainer.py:168-169:
+        # from the second epoch on)
+        self.w_cr = None if w_cr in (None, 'None') else float(w_cr)
+        self.apply_cr_loss = False
+        self.cr_idx = None
+        if self.w_cr is not None:
+            if model.head_type != 'coordinates':
+                raise NotImplementedError('the cross-ratio term needs the coordinate head')
+            if cr_indices is None:
+                from .common.img_proc import CR_INDICES_BBOX12
+                cr_indices = CR_INDICES_BBOX12
+            idx = torch.as_tensor(cr_indices, dtype=torch.int32).reshape(-1, 4)
+            if int(idx.min()) < 0 or int(idx.max()) >= model.num_joints:
+                raise ValueError('cr_indices outside 0..%d' % (model.num_joints - 1))
+            self.cr_idx = idx.contiguous().to(p0.device)
+            self.cr_crit = self.CR_CRITERIA[cr_type]
+            self.target_cr, self.cr_loss_thres = float(target_cr), float(cr_loss_thres)
         self.grad_sync = grad_sync
-        self.sigma = sigma            # heatmapModel.sigma: targets drawn on the device when step(target=None)
+        self.sigma = sigma           # heatmapModel.sigma: targets drawn on the device when step(target=None)
         self.last_target_weight = None
         self.flat = FlatParams(model.parameters())
         widest = max(p.shape[0] for p in model.parameters()) + 32
@@ -463,16 +483,27 @@ class HRNetTrainStep(object):
                 cd = tape.user['head2.4'].view(n, 2 * J)          # compact [N, 2K] = coords [N,K,2]
                 self.last_coords = cd.view(n, J, 2)
                 self.last_maps = tape.maps_user
-                if self.w_coor:
-                    if joints_xy is None:
-                        raise ValueError('the coordinate term needs joints_xy')
-                    gt = torch.as_tensor(joints_xy, dtype=torch.float32).to(self.dev)[..., :2].clone()
-                    gt[..., 0] /= w            # function.py:160-161 (img_size = (width, height))
-                    gt[..., 1] /= h
-                    gt = gt.contiguous()
+                use_cr = self.w_cr is not None and self.apply_cr_loss
+                if self.w_coor or use_cr:
                     dc = tape._empty(cd.numel())
-                    _lib.check(L.egn_l1_f32(_lib.ptr(cd), _lib.ptr(gt), cd.numel(), self.w_coor, _lib.ptr(dc),
-                                            _lib.ptr(self.loss_dev), st), 'l1')
+                    if self.w_coor:
+                        if joints_xy is None:
+                            raise ValueError('the coordinate term needs joints_xy')
+                        gt = torch.as_tensor(joints_xy, dtype=torch.float32).to(self.dev)[..., :2].clone()
+                        gt[..., 0] /= w            # function.py:160-161 (img_size = (width, height))
+                        gt[..., 1] /= h
+                        gt = gt.contiguous()
+                        _lib.check(L.egn_l1_f32(_lib.ptr(cd), _lib.ptr(gt), cd.numel(), self.w_coor, _lib.ptr(dc),
+                                                _lib.ptr(self.loss_dev), st), 'l1')
+                    else:
+                        dc.zero_()
+                    if use_cr:
+                        nl = self.cr_idx.shape[0]
+                        ws = tape._empty(L.egn_cross_ratio_ws_bytes(n, nl) // 4)
+                        _lib.check(L.egn_cross_ratio_f32(_lib.ptr(cd), n, J, _lib.ptr(self.cr_idx), nl,
+                                                         self.target_cr, self.cr_loss_thres, self.cr_crit, self.w_cr,
+                                                         _lib.ptr(dc), _lib.ptr(self.loss_dev), _lib.ptr(ws), st),
+                                   'cross_ratio')
                     dpad = tape._empty(n * coords.cs)             # back to the padded NHWC row layout
                     _lib.check(L.egn_nchw_to_nhwc_f32(_lib.ptr(dc), _lib.ptr(dpad), n, 2 * J, 1, 1, coords.cs, st))
                     tape.grad[id(coords)] = [dpad, True]

@@ -48,20 +48,37 @@ def prepare_optim(model, cfgs):
     return optim, sche
 
 
+_CRITERION_NAMES = {'MSELoss': 'mse', 'L1Loss': 'l1', 'SmoothL1Loss': 'sl1'}      # loss_dict, function.py:17-20
+_OFF = (None, 'None', 0, 0.0)
+
+
 def _loss_weights(loss_func, cfgs):
+    """(w_hm, w_coor, cross-ratio keywords of HRNetTrainStep) from a JointsCompositeLoss-like
+    object (comp_dict / cr_indices / target_cr / cr_loss_thres, function.py:61-93 and
+    train_IGRs.py:33-46) or, without one, from cfgs['heatmapModel']."""
+    hm = cfgs.get('heatmapModel', {})
     comp = getattr(loss_func, 'comp_dict', None)
     if comp is not None:
-        w_hm = comp['hm'][1] if 'hm' in comp else 0.0
-        w_coor = comp['coor'][1] if 'coor' in comp else 0.0
-        if 'cr' in comp and comp['cr'][1] not in (None, 'None', 0, 0.0):
-            raise NotImplementedError('the cross-ratio loss term (function.py:113-153) is not implemented natively')
-        return float(w_hm), float(w_coor)
-    hm = cfgs.get('heatmapModel', {})
-    wl = hm.get('loss_weight_list', [1.0, 0.1, 'None'])
-    spec = hm.get('loss_spec_list', ['mse', 'l1', 'None'])
-    if len(wl) > 2 and wl[2] not in (None, 'None', 0, 0.0) and spec[2] not in (None, 'None'):
-        raise NotImplementedError('the cross-ratio loss term (function.py:113-153) is not implemented natively')
-    return (float(wl[0]) if spec[0] != 'None' else 0.0), (float(wl[1]) if spec[1] != 'None' else 0.0)
+        spec = [_CRITERION_NAMES.get(type(comp[k][0]).__name__, type(comp[k][0]).__name__) if k in comp else 'None'
+                for k in ('hm', 'coor', 'cr')]
+        wl = [comp[k][1] if k in comp else 'None' for k in ('hm', 'coor', 'cr')]
+    else:
+        wl = list(hm.get('loss_weight_list', [1.0, 0.1, 'None']))
+        spec = list(hm.get('loss_spec_list', ['mse', 'l1', 'None']))
+    if spec[0] not in ('mse', 'None') or spec[1] not in ('l1', 'None'):
+        raise NotImplementedError('native loss: heat-map term mse, coordinate term l1 (the shipped configs); got %r'
+                                  % (spec[:2],))
+    w_hm = float(wl[0]) if spec[0] != 'None' else 0.0
+    w_coor = float(wl[1]) if spec[1] != 'None' else 0.0
+    cr = {}
+    if spec[2] != 'None' and wl[2] not in _OFF:
+        if spec[2] not in ('mse', 'l1', 'sl1'):
+            raise NotImplementedError('cross-ratio criterion %r' % spec[2])
+        cr = dict(w_cr=float(wl[2]), cr_type=spec[2],
+                  cr_indices=getattr(loss_func, 'cr_indices', None),
+                  target_cr=getattr(loss_func, 'target_cr', None) or 4.0 / 3.0,
+                  cr_loss_thres=getattr(loss_func, 'cr_loss_thres', hm.get('cr_loss_threshold', 0.15)))
+    return w_hm, w_coor, cr
 
 
 def make_step(model, cfgs, loss_func=None, optim=None):
@@ -71,11 +88,13 @@ def make_step(model, cfgs, loss_func=None, optim=None):
         and torch.distributed.get_world_size() > 1 else None
     inner = model.module if hasattr(model, 'module') else model          # DataParallel / DDP wrappers
     if isinstance(inner, PoseHighResolutionNet):
-        w_hm, w_coor = _loss_weights(loss_func, cfgs)
+        w_hm, w_coor, cr = _loss_weights(loss_func, cfgs)
         sigma = cfgs.get('heatmapModel', {}).get('sigma', 1)
         if inner.head_type == 'heatmap':
-            w_coor = 0.0
-        return HRNetTrainStep(inner, lr=lr, w_hm=w_hm, w_coor=w_coor, grad_sync=sync, sigma=sigma)
+            w_coor, cr = 0.0, {}
+        step = HRNetTrainStep(inner, lr=lr, w_hm=w_hm, w_coor=w_coor, grad_sync=sync, sigma=sigma, **cr)
+        step.apply_cr_loss = bool(getattr(loss_func, 'apply_cr_loss', False))
+        return step
     if isinstance(inner, FCmodel.FCModel):
         return LifterTrainStep(inner, lr=lr, grad_sync=sync)
     raise TypeError('no native training step for %s' % type(inner).__name__)
@@ -95,6 +114,8 @@ def train(train_dataset, model, loss_func, optim, sche, cfgs, logger, metric_fun
     dev = step.dev
     x_buffer, y_buffer = [], []
     for epoch in range(1, total_epochs + 1):
+        if epoch > 1 and is_hc:
+            step.apply_cr_loss = True                       # trainer.py:168-169: L_cr from the second epoch on
         model.train()
         if sche is not None:
             sche.step()                                     # trainer.py:177, before the epoch like the reference

@@ -107,7 +107,9 @@ int egn_fill_coord_ramps_f32(float* y, int N, int H, int W, int cs, int c0,
  *   out_max  [N,K]   fp32   raw maximum
  *   out_idx  [N,K]   int32  flat arg-max index (first max on ties); may be NULL
  * mode 0 = hard arg-max (coordinates zeroed where max <= 0),
- * mode 1 = soft-arg-max (softmax over H*W, no mask).
+ * mode 1 = soft-arg-max (softmax over H*W, no mask),
+ * mode 2 = soft_arg_max_np (img_proc.py:639-676: weights hm/sum(hm),
+ *          coordinates zeroed where max <= 0).
  * ---------------------------------------------------------------------- */
 int egn_decode_heatmaps_f32(const float* hm, int N, int K, int H, int W,
                             int mode, float* out_xy, float* out_max,
@@ -246,6 +248,18 @@ int egn_mse_f32(const float* pred, const float* tgt, int rows, int cols,
  * (nn.L1Loss, the coordinate term, function.py:155-168) */
 int egn_l1_f32(const float* pred, const float* tgt, long n, float weight,
                float* dpred, double* loss, void* stream);
+/* cross-ratio term L_cr (function.py:113-153 calc_cross_ratio_loss + get_cr_mask,
+ * img_proc.py:709-720 appro_cr): coords [N,K,2] f32, idx [L,4] int32 device
+ * array of joint indices (A,B,C,D) per line (car_instance.py:83-97 'bbox12');
+ * cr = |AC|^2|BD|^2 / (|BC|^2|AD|^2) / target_cr^2; a line counts when the
+ * smallest non-zero distance among its four points > thres;
+ * *loss += weight * sum(crit(cr,1)) / #lines kept; dcoords (may be NULL)
+ * += the gradient.  crit: 0 mse, 1 l1, 2 smooth-l1.  ws: egn_cross_ratio_ws_bytes */
+long egn_cross_ratio_ws_bytes(int N, int L);
+int egn_cross_ratio_f32(const float* coords, int N, int K, const int* idx,
+                        int L, double target_cr, float thres, int crit,
+                        float weight, float* dcoords, double* loss, float* ws,
+                        void* stream);
 /* dz = dy*y*(1-y): backward of the coordinate head's Sigmoid (hrnet.py:461-466) */
 int egn_sigmoid_bwd_f32(const float* dy, const float* y, float* dz, long n,
                         void* stream);

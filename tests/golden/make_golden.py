@@ -185,6 +185,92 @@ def main():
     with open(os.path.join(HERE, 'format.json'), 'w') as f:
         json.dump(recs, f, indent=1)
     print('format.json')
+    # ---- 0d: cross-ratio term of the reference's JointsCompositeLoss (function.py:113-153,
+    #          200-202) with the 'bbox12' lines and target 4/3 (train_IGRs.py:44-46):
+    #          value and gradient w.r.t. the coordinates; random coordinates (part of the
+    #          lines masked), a tight cluster (every line masked -> 0), all three criteria,
+    #          and the whole composite loss with the term switched on
+    import libs.dataset.KITTI.car_instance as ref_car
+    cr_idx = ref_car.cr_indices_dict['bbox12']
+    assert (cr_idx == ref_car.get_cr_indices()).all()
+    g4 = torch.Generator().manual_seed(404)
+    crc_ = {'cr_indices': cr_idx}
+    coords_cases = {
+        'rand': torch.rand(6, 33, 2, generator=g4),
+        'wide': torch.rand(3, 33, 2, generator=g4) * 0.5 + 0.25,
+        'cluster': torch.rand(2, 33, 2, generator=g4) * 0.05 + 0.4,
+    }
+    for tag, cc in coords_cases.items():
+        for spec in ('sl1', 'l1', 'mse'):
+            for thres in (0.15, 0.1):
+                lf = ref_loss.JointsCompositeLoss(spec_list=['mse', 'l1', spec], img_size=[256, 256],
+                                                  hm_size=[64, 64], loss_weights=[1.0, 0.1, 0.5],
+                                                  cr_loss_thres=thres)
+                lf.cr_indices, lf.target_cr = cr_idx, 4 / 3
+                c = cc.clone().requires_grad_(True)
+                mask = lf.get_cr_mask(c.detach().numpy(), thres)
+                val = lf.calc_cross_ratio_loss(c, lf.target_cr, mask)
+                key = '%s/%s/%g' % (tag, spec, thres)
+                crc_[key + '/mask'] = mask.numpy()
+                if torch.is_tensor(val):
+                    val.backward()
+                    crc_[key + '/loss'] = np.array(float(val))
+                    crc_[key + '/grad'] = c.grad.numpy().copy()
+                else:                                    # no line kept: the reference returns int 0
+                    crc_[key + '/loss'] = np.array(float(val))
+                    crc_[key + '/grad'] = np.zeros_like(cc.numpy())
+        crc_[tag + '/coords'] = cc.numpy()
+    # whole loss: maps + coordinates + cross ratio, apply_cr_loss on (trainer.py:168-169)
+    lf = ref_loss.JointsCompositeLoss(spec_list=['mse', 'l1', 'sl1'], img_size=[256, 256], hm_size=[64, 64],
+                                      loss_weights=[1.0, 0.1, 0.05], cr_loss_thres=0.15)
+    lf.cr_indices, lf.target_cr, lf.apply_cr_loss = cr_idx, 4 / 3, True
+    maps = torch.rand(6, 33, 8, 8, generator=g4).requires_grad_(True)
+    tgt4 = torch.rand(6, 33, 8, 8, generator=g4)
+    jt4 = torch.rand(6, 33, 3, generator=g4) * 256
+    c = coords_cases['rand'].clone().requires_grad_(True)
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        tot = lf((maps, c), tgt4, None, {'transformed_joints': jt4.numpy().copy()})
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    tot.backward()
+    crc_.update({'full/maps': maps.detach().numpy(), 'full/target': tgt4.numpy(), 'full/joints': jt4.numpy(),
+                 'full/loss': np.array(float(tot)), 'full/dcoords': c.grad.numpy().copy(),
+                 'full/dmaps': maps.grad.numpy().copy()})
+    save('cr_loss.npz', **crc_)
+    # ---- 0e: the validation metric get_distance_src (criterions.py:68-143) with rotated
+    #          crops, visibility flags, extra (unlabeled) predictions; coordinate-head
+    #          output, heat-maps with hard and with numpy-soft arg-max.  cv2's
+    #          getAffineTransform is the exact 3-point solve of _install_stubs.
+    import libs.metric.criterions as ref_crit
+    g5 = np.random.RandomState(55)
+    nb5, k5 = 5, 33
+    meta5 = {'center': g5.uniform(200, 900, (4, 2)).astype(np.float32),
+             'scale': np.repeat(g5.uniform(0.3, 1.5, (4, 1)), 2, axis=1).astype(np.float32),
+             'rotation': np.array([0.0, 12.5, -30.0, 0.0]),
+             'original_joints': np.concatenate([g5.uniform(100, 1000, (4, k5, 2)),
+                                                (g5.uniform(0, 1, (4, k5, 1)) > 0.2).astype(np.float64)], axis=2)}
+    coords5 = g5.uniform(0.05, 0.95, (nb5, k5, 2)).astype(np.float32)
+    hm5 = g5.uniform(0, 1, (nb5, k5, 16, 16)).astype(np.float32) ** 4
+    hm5[0, 0] = -hm5[0, 0]                                        # an all-negative map: coordinates zeroed
+    met = {'center': meta5['center'], 'scale': meta5['scale'], 'rotation': meta5['rotation'],
+           'original_joints': meta5['original_joints'], 'coords': coords5, 'heatmaps': hm5}
+    runs = {'coords': ((torch.from_numpy(hm5), torch.from_numpy(coords5.copy())), 'hard'),
+            'hard': (hm5.copy(), 'hard'), 'soft': (hm5.copy(), 'soft')}
+    for tag, (out5, am) in runs.items():
+        avg, cnt, others = ref_crit.get_distance_src(out5, dict(meta5), arg_max=am, image_size=(64.0, 64.0))
+        met[tag + '/avg'] = np.array(avg)
+        met[tag + '/cnt'] = np.array(cnt)
+        met[tag + '/src_coord'] = others['src_coord']
+        met[tag + '/correct_cnt'] = others['correct_cnt']
+        met[tag + '/joints_pred'] = others['joints_pred']
+    meta_norot = {k: v for k, v in meta5.items() if k != 'rotation'}
+    avg, cnt, others = ref_crit.get_distance_src(hm5.copy(), meta_norot, arg_max='hard', image_size=(64.0, 64.0))
+    met['norot/avg'], met['norot/src_coord'] = np.array(avg), others['src_coord']
+    save('metric.npz', **met)
+    if '--cr-only' in sys.argv:
+        return
     if '--train-only' in sys.argv:
         return
 

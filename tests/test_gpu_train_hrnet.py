@@ -217,3 +217,38 @@ def test_w48_gradients_vs_oracle_full_size():
     gl2, cos, med = gradient_agreement(dict(net.named_parameters()), orc.grads())
     print('end-to-end gradient agreement: rel-L2 %.2e cosine %.6f median per-tensor rel-L2 %.2e' % (gl2, cos, med))
     assert cos > 0.999 and gl2 < 5e-2, (gl2, cos, med)
+
+
+def test_cross_ratio_term_in_the_step_vs_oracle():
+    """Tiny 33-joint coordinate model with the cross-ratio term on (weight 0.05, 'bbox12'
+    lines, target 4/3): loss and gradients against the oracle, whose loss restatement is
+    pinned to the reference's (tests/golden/cr_loss.npz).  The term only counts once
+    apply_cr_loss is set (trainer.py:168-169)."""
+    from egonet_amd.common.img_proc import get_cr_indices
+    cfg = configs.tiny_config('coordinates', num_joints=33)
+    net, sd = _tiny_model(cfg, seed=9)
+    gen = torch.Generator().manual_seed(4)
+    x = synth.synth_crops(3, 3, 64, 64, seed=8)
+    tgt = torch.rand(3, 33, 16, 16, generator=gen)
+    jt = torch.rand(3, 33, 2, generator=gen) * 64
+    # untrained head: coordinates in 0.15..0.86; threshold 0.05 keeps 31 of the 36 lines
+    cr = dict(w_cr=0.05, cr_indices=get_cr_indices(), cr_loss_thres=0.05)
+    orc = HRNetTrainOracle(sd, cfg, lr=1e-3, cr=cr)
+    want_loss, _, want_coords = orc.step(x, tgt, jt, update=False)
+    plain = HRNetTrainOracle(sd, cfg, lr=1e-3).step(x, tgt, jt, update=False)[0]
+    assert abs(want_loss - plain) > 1e-3 * abs(plain)                     # the term is live in this case
+    tr = HRNetTrainStep(net, lr=1e-3, w_cr=0.05, cr_loss_thres=0.05)
+    off = float(tr.step(x.cuda(), tgt.cuda(), jt.cuda(), update=False).item())
+    assert abs(off - plain) < 2e-5 * abs(plain)                           # first epoch: term off
+    tr.apply_cr_loss = True
+    loss = float(tr.step(x.cuda(), tgt.cuda(), jt.cuda(), update=False).item())
+    # train-mode BatchNorm over 3 x 4 x 4 values in the coordinate head amplifies fp32 noise
+    got_coords = tr.last_coords.cpu()
+    assert float((got_coords - want_coords).abs().max()) < 2e-4, float((got_coords - want_coords).abs().max())
+    # the term alone, on the coordinates the device produced (pinned loss restatement)
+    from oracle.hrnet_train_oracle import cross_ratio_loss
+    want_term = 0.05 * float(cross_ratio_loss(got_coords, get_cr_indices(), 4 / 3, 0.05, 'sl1'))
+    assert abs((loss - off) - want_term) < 1e-3 * want_term + 1e-6, (loss - off, want_term)
+    assert abs(loss - want_loss) < 2e-3 * abs(want_loss), (loss, want_loss)
+    gl2, cos, med = gradient_agreement(dict(net.named_parameters()), orc.grads())
+    assert cos > 0.9999 and gl2 < 1e-2 and med < 5e-3, (gl2, cos, med)

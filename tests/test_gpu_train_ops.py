@@ -435,3 +435,51 @@ def test_gaussian_targets_vs_reference(tag):
     t1, w1 = img_proc.generate_target(g[tag + '/joints'][1], g[tag + '/vis'][1], prm)    # the per-sample API
     np.testing.assert_allclose(t1, want[1], rtol=0, atol=2e-7)
     np.testing.assert_array_equal(w1, g[tag + '/weight'][1])
+
+
+CR_CASES = [(t, s, th) for t in ('rand', 'wide', 'cluster') for s in ('sl1', 'l1', 'mse') for th in (0.15, 0.1)]
+
+
+def _cross_ratio(coords, idx, thres, spec, weight, dcoords=None, target_cr=4 / 3):
+    L = _lib.lib()
+    n, k = coords.shape[:2]
+    idx_d = torch.as_tensor(idx, dtype=torch.int32).contiguous().cuda()
+    nl = idx_d.shape[0]
+    ws = torch.empty(L.egn_cross_ratio_ws_bytes(n, nl) // 4, device='cuda')
+    loss = torch.zeros(1, dtype=torch.float64, device='cuda')
+    _lib.check(L.egn_cross_ratio_f32(_lib.ptr(coords), n, k, _lib.ptr(idx_d), nl, target_cr, thres,
+                                     {'mse': 0, 'l1': 1, 'sl1': 2}[spec], weight, _lib.ptr(dcoords), _lib.ptr(loss),
+                                     _lib.ptr(ws), _st()), 'cross_ratio')
+    return float(loss.item()), ws.view(n, nl, -1)
+
+
+@pytest.mark.parametrize('tag,spec,thres', CR_CASES)
+def test_cross_ratio_term_vs_reference(tag, spec, thres):
+    """csrc/cross_ratio.hip against the REFERENCE's calc_cross_ratio_loss / get_cr_mask
+    (tests/golden/cr_loss.npz): value, kept lines, gradient w.r.t. the coordinates."""
+    from conftest import golden
+    g = golden('cr_loss.npz')
+    key = '%s/%s/%g' % (tag, spec, thres)
+    c = torch.from_numpy(g[tag + '/coords']).cuda()
+    dc = torch.zeros_like(c)
+    loss, ws = _cross_ratio(c, g['cr_indices'], thres, spec, 1.0, dc)
+    np.testing.assert_array_equal(ws[..., 9].cpu().numpy(), g[key + '/mask'][..., 0])      # bit exact line mask
+    ref = g[key + '/grad']
+    np.testing.assert_allclose(loss, float(g[key + '/loss']), rtol=5e-6, atol=0)
+    np.testing.assert_allclose(dc.cpu().numpy(), ref, rtol=0, atol=5e-6 * max(1.0, float(np.abs(ref).max())))
+
+
+def test_cross_ratio_term_accumulates_and_scales():
+    from conftest import golden
+    g = golden('cr_loss.npz')
+    c = torch.from_numpy(g['rand/coords']).cuda()
+    base = torch.full_like(c, 0.25)
+    dc = base.clone()
+    loss, _ = _cross_ratio(c, g['cr_indices'], 0.15, 'sl1', 0.05, dc)
+    ref = g['rand/sl1/0.15/grad']
+    np.testing.assert_allclose(loss, 0.05 * float(g['rand/sl1/0.15/loss']), rtol=5e-6)
+    np.testing.assert_allclose((dc - base).cpu().numpy(), 0.05 * ref, rtol=0, atol=1e-6 * float(np.abs(ref).max()))
+    loss2, _ = _cross_ratio(c, g['cr_indices'], 0.15, 'sl1', 0.05, None)          # value only
+    assert loss2 == loss
+    L = _lib.lib()
+    assert L.egn_cross_ratio_f32(_lib.ptr(c), 6, 33, None, 12, 4 / 3, 0.15, 2, 1.0, None, None, None, _st()) != 0

@@ -227,3 +227,42 @@ def test_lifter_train_oracle_vs_reference():
     for k, v in sd3.items():
         np.testing.assert_allclose(orc.sd[k].detach().numpy(), v.numpy(), rtol=0, atol=2e-6, err_msg=k)
     assert int(orc.sd['batch_norm1.num_batches_tracked']) == 3
+
+
+CR_CASES = [(t, s, th) for t in ('rand', 'wide', 'cluster') for s in ('sl1', 'l1', 'mse') for th in (0.15, 0.1)]
+
+
+@pytest.mark.parametrize('tag,spec,thres', CR_CASES)
+def test_cross_ratio_oracle_vs_reference(tag, spec, thres):
+    """Value, line mask and gradient of the reference's cross-ratio term
+    (function.py:113-153) on the 'bbox12' lines."""
+    from oracle.hrnet_train_oracle import cross_ratio_loss, cross_ratio_mask
+    from egonet_amd.common.img_proc import get_cr_indices
+    g = golden('cr_loss.npz')
+    idx = g['cr_indices']
+    np.testing.assert_array_equal(get_cr_indices(), idx)
+    key = '%s/%s/%g' % (tag, spec, thres)
+    c = torch.from_numpy(g[tag + '/coords']).clone().requires_grad_(True)
+    np.testing.assert_array_equal(cross_ratio_mask(c, idx, thres).numpy(), g[key + '/mask'][..., 0])
+    loss = cross_ratio_loss(c, idx, 4 / 3, thres, spec)
+    loss.backward()
+    ref = g[key + '/grad']
+    np.testing.assert_allclose(float(loss), float(g[key + '/loss']), rtol=2e-6, atol=0)
+    np.testing.assert_allclose(c.grad.numpy(), ref, rtol=0, atol=2e-6 * max(1.0, float(np.abs(ref).max())))
+    if tag == 'cluster':
+        assert g[key + '/mask'].sum() == 0 and float(loss) == 0.0      # every line fore-shortened
+    else:
+        assert 0 < g[key + '/mask'].sum() < g[key + '/mask'].size
+
+
+def test_composite_loss_with_cross_ratio_vs_reference():
+    from oracle.hrnet_train_oracle import composite_loss
+    g = golden('cr_loss.npz')
+    maps = torch.from_numpy(g['full/maps']).clone().requires_grad_(True)
+    c = torch.from_numpy(g['rand/coords']).clone().requires_grad_(True)
+    loss = composite_loss((maps, c), torch.from_numpy(g['full/target']), torch.from_numpy(g['full/joints'][..., :2]),
+                          (256, 256), 1.0, 0.1, w_cr=0.05, cr_indices=g['cr_indices'])
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(g['full/loss']), rtol=2e-6)
+    np.testing.assert_allclose(c.grad.numpy(), g['full/dcoords'], rtol=0, atol=1e-6 * float(np.abs(g['full/dcoords']).max()))
+    np.testing.assert_allclose(maps.grad.numpy(), g['full/dmaps'], rtol=0, atol=1e-9)
