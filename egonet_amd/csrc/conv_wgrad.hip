@@ -437,8 +437,11 @@ extern "C" int egn_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
   if (a.nsplit > 64)
     hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3((unsigned)((total4 + 31) / 32)), dim3(1024), 0, st, a.part, dw,
                        a.nsplit, a.taps, Cout, Cin, a.CoP, a.CiP);
-  else
+  else if (a.nsplit > 4)
     hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, st, a.part, dw,
+                       a.nsplit, a.taps, Cout, Cin, a.CoP, a.CiP);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3((unsigned)((total4 + 31) / 32)), dim3(64), 0, st, a.part, dw,
                        a.nsplit, a.taps, Cout, Cin, a.CoP, a.CiP);
   return (int)hipGetLastError();
 }

@@ -234,9 +234,28 @@ class _Tape(object):
 
     def _dgrad(self, dy, ho, wo, cs_out, weight, stride, pad, x):
         cout, cin, kh, kw = weight.shape
-        if kh != kw:
-            raise NotImplementedError('data gradient of a non-square %dx%d convolution' % (kh, kw))
         L = self.L
+        if kh != kw:
+            # the Pedestrian model's final 4x3 'valid' conv over the whole 4x3 map (hrnet.py:457-460):
+            # one output pixel, so dx[n, (ky,kx), ci] = sum_co dy[n, co] * W[co, ci, ky, kx] is a GEMM
+            # whose output rows are the NHWC map itself
+            if not (pad == 0 and stride == 1 and x.h == kh and x.w == kw and ho == 1 and wo == 1):
+                raise NotImplementedError('data gradient of a non-square %dx%d convolution that does not '
+                                          'cover its whole input' % (kh, kw))
+            wt = torch.zeros(kh * kw, x.cs, cout, dtype=torch.float32, device=self.dev)
+            wt[:, :cin] = weight.detach().permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
+            wt = wt.view(kh * kw * x.cs, cout, 1, 1)
+            rows = kh * kw * x.cs
+            wq = torch.empty(L.egn_packed_weight_floats(rows, cout, 1, 1, 0), dtype=torch.float32, device=self.dev)
+            _lib.check(L.egn_pack_conv_weight_f32(_lib.ptr(wt), rows, cout, 1, 1, 0, _lib.ptr(wq), self.st), 'pack')
+            dx = self._empty(x.n * rows)
+            shift = self.o.zeros if self.o.zeros.numel() >= rows + 16 else torch.zeros(rows + 16, device=self.dev)
+            ones = self.o.ones if self.o.ones.numel() >= rows + 16 else torch.ones(rows + 16, device=self.dev)
+            cfg = tuner.choose(self.dev, (x.n, 1, 1, cout, cs_out, rows, rows, 1, 1, 1, 0, False, False))
+            _lib.check(L.egn_conv2d_f32(_lib.ptr(dy), _lib.ptr(wq), _lib.ptr(ones), _lib.ptr(shift), None, _lib.ptr(dx),
+                                        x.n, 1, 1, cout, cs_out, rows, rows, 1, 1, 1, 0, ACT_NONE, 0, cfg, self.st),
+                       'conv')
+            return dx
         wq = self._pack(weight, 1)
         if stride == 2:
             up = self._empty(x.n * x.h * x.w * cs_out)

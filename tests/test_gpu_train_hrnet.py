@@ -252,3 +252,29 @@ def test_cross_ratio_term_in_the_step_vs_oracle():
     assert abs(loss - want_loss) < 2e-3 * abs(want_loss), (loss, want_loss)
     gl2, cos, med = gradient_agreement(dict(net.named_parameters()), orc.grads())
     assert cos > 0.9999 and gl2 < 1e-2 and med < 5e-3, (gl2, cos, med)
+
+
+def test_pedestrian_shape_non_square_step_vs_oracle():
+    """192 x 256 (W x H) crops like KITTI_train_IGRs_Ped.yml: 48 x 64 maps and a 4 x 3 'valid'
+    final conv in the coordinate head (hrnet.py:457-460) -- forward, 12-tap weight gradient and
+    the data gradient as a GEMM over the whole 4 x 3 map."""
+    cfg = configs.tiny_config('coordinates', input_size=(192, 256))
+    net, sd = _tiny_model(cfg, seed=13)
+    assert tuple(net.head2[4].weight.shape[2:]) == (4, 3)
+    gen = torch.Generator().manual_seed(6)
+    x = synth.synth_crops(2, 3, 256, 192, seed=12)
+    tgt = torch.rand(2, 5, 64, 48, generator=gen)
+    jt = torch.rand(2, 5, 2, generator=gen) * torch.tensor([192.0, 256.0])
+    orc = HRNetTrainOracle(sd, cfg, lr=1e-3)
+    want_loss, want_maps, want_coords = orc.step(x, tgt, jt, update=False)
+    tr = HRNetTrainStep(net, lr=1e-3)
+    with LayerChecks(tr) as chk:
+        loss = float(tr.step(x.cuda(), tgt.cuda(), jt.cuda(), update=False).item())
+    assert abs(loss - want_loss) < 5e-5 * abs(want_loss), (loss, want_loss)
+    np.testing.assert_allclose(tr.last_maps.cpu().numpy(), want_maps.numpy(), rtol=0, atol=2e-4)
+    assert float((tr.last_coords.cpu() - want_coords).abs().max()) < 2e-4
+    worst = chk.worst()
+    assert worst['wgrad'] < 2e-5 and worst['dgrad'] < 2e-5 and worst['bn'] < 1e-4, worst
+    assert any(s[5] == 4 and e < 2e-5 for e, s in chk.dgrad)        # the 4x3 layer went through the check
+    gl2, cos, med = gradient_agreement(dict(net.named_parameters()), orc.grads())
+    assert cos > 0.999 and med < 5e-3, (gl2, cos, med)
