@@ -114,28 +114,77 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
   const int tiles_per_img = a.tiles_x * a.tiles_y;
   const int ntiles = tiles_per_img * a.N;
 
-// LDS-DMA of tile T's halo into buffer B (zero padding included, see below)
-#define C48_STAGE(T, B)                                                                              \
+// Halo DMA of a tile in two parts, so that the address arithmetic of tile t+2 can be
+// scheduled INTO the MFMA steps of tile t (all waves of a CU change tiles together -- one
+// barrier per tile -- so every VALU instruction between the barrier and the first MFMA is
+// a cycle the MFMA pipe idles): C48_OFFS computes the per-lane byte offsets (zero padding
+// included: a lane outside the image gets the OOB offset, the buffer load returns 0 for it,
+// so the padding is written by the same DMA), C48_ISSUE is only the A_IT DMA instructions.
+#define C48_ORIGIN(T, N_, TY_, TX_)                 \
+  {                                                 \
+    N_ = (T) / tiles_per_img;                       \
+    const int r_ = (T)-N_ * tiles_per_img;          \
+    TY_ = r_ / a.tiles_x;                           \
+    TX_ = r_ - TY_ * a.tiles_x;                     \
+  }
+#define C48_OFF1(IT, N_, TY_, TX_, OUT)                                                              \
   {                                                                                                  \
-    const int n_ = (T) / tiles_per_img;                                                              \
-    const int r_ = (T)-n_ * tiles_per_img;                                                           \
-    const int ty_ = r_ / a.tiles_x;                                                                  \
-    const int iy0_ = ty_ * TH - 1, ix0_ = (r_ - ty_ * a.tiles_x) * TW - 1;                           \
-    const int org_ = ((n_ * a.H + iy0_) * a.W + ix0_) * C48 * 4;                                     \
+    const int iy0_ = TY_ * TH - 1, ix0_ = TX_ * TW - 1;                                              \
+    const int org_ = ((N_ * a.H + iy0_) * a.W + ix0_) * C48 * 4;                                     \
+    const int iy = iy0_ + (hyx[IT] >> 8), ix = ix0_ + (hyx[IT] & 255);                               \
+    const bool in_ = rel[IT] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                     \
+    OUT[IT] = in_ ? (unsigned)(org_ + rel[IT]) : EGN_OOB;                                            \
+  }
+#define C48_OFFS(T, OUT)                                                     \
+  {                                                                          \
+    int n_, ty_, tx_;                                                        \
+    C48_ORIGIN(T, n_, ty_, tx_)                                              \
+    _Pragma("unroll") for (int it = 0; it < A_IT; ++it) C48_OFF1(it, n_, ty_, tx_, OUT) \
+  }
+#define C48_ISSUE(B, OFF)                                                                            \
+  {                                                                                                  \
     float4* dst_ = sA + (B)*HALO_SLOTS + wave * 64;                                                  \
     const unsigned lds_ = c48_lds_addr(dst_);                                                        \
-    _Pragma("unroll") for (int it = 0; it < A_IT; ++it) {                                            \
-      const int iy = iy0_ + (hyx[it] >> 8), ix = ix0_ + (hyx[it] & 255);                             \
-      const bool in_ = rel[it] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                   \
-      /* a lane outside the image gets the OOB offset: the buffer load returns 0 for it, */          \
-      /* so the zero padding is written by the same DMA (one instruction per wave and it) */         \
+    _Pragma("unroll") for (int it = 0; it < A_IT; ++it)                                              \
       if (it * NTH + wave * 64 < HALO_SLOTS) /* wave-uniform */                                      \
-        c48_dma16_raw(rxv, lds_ + it * NTH * 16, in_ ? (unsigned)(org_ + rel[it]) : EGN_OOB);        \
+        c48_dma16_raw(rxv, lds_ + it * NTH * 16, OFF[it]);                                           \
+  }
+// byte offsets of this lane's MT x 4 output pixels (channel li of the first 16; + nt*64 for the
+// others), EGN_OOB = masked.  EGN_OOB + 128 is still out of range: no select per access.
+#define C48_VOFF1(N_, TY_, TX_, OUT)                                                                 \
+  {                                                                                                  \
+    const int oy0_ = TY_ * TH, ox0_ = TX_ * TW;                                                      \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                              \
+      const int oy = oy0_ + wave * MT + mt;                                                          \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                \
+        const int ox = ox0_ + 4 * kq + r;                                                            \
+        OUT[mt][r] =                                                                                 \
+            (oy < a.Ho && ox < a.Wo) ? (unsigned)(((N_ * a.Ho + oy) * a.Wo + ox) * C48 + li) * 4u : EGN_OOB; \
+      }                                                                                              \
     }                                                                                                \
   }
+#define C48_VOFF(T, OUT)            \
+  {                                 \
+    int n_, ty_, tx_;               \
+    C48_ORIGIN(T, n_, ty_, tx_)     \
+    C48_VOFF1(n_, ty_, tx_, OUT)    \
+  }
+// a piece of next-tile address arithmetic pinned between two MFMA steps: the MFMAs issued
+// before it are still running in the pipe (32 cycles each) while it executes
+#define C48_BETWEEN(CODE)              \
+  __builtin_amdgcn_sched_barrier(0);   \
+  CODE                                 \
+  __builtin_amdgcn_sched_barrier(0);
 
   int tile = blockIdx.x;
-  if (tile < ntiles) C48_STAGE(tile, 0)
+  unsigned doff[A_IT];    // DMA offsets of the tile staged next (tile + gridDim.x inside the loop)
+  unsigned voff[MT][4];   // output offsets of the current tile
+  if (tile < ntiles) {
+    C48_OFFS(tile, doff)
+    C48_ISSUE(0, doff)
+  }
+  C48_OFFS(tile + (int)gridDim.x, doff)
+  C48_VOFF(tile, voff)
   int buf = 0;
 
   // per-lane constants of the epilogue: channel = nt*16 + li, pixel x = 4*kq + r
@@ -165,33 +214,26 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
     asm volatile("" ::: "memory");
     first = false;
     const int next = tile + gridDim.x;
-    if (next < ntiles) C48_STAGE(next, buf ^ 1)
+    if (next < ntiles) C48_ISSUE(buf ^ 1, doff)
     // the vmcnt bookkeeping above counts on program order: DMA, residual loads, stores.
     // The asm has no memory clobber (on purpose), so pin the order for the compiler here.
     asm volatile("" ::: "memory");
 
-    const int n = tile / tiles_per_img;
-    const int r0 = tile - n * tiles_per_img;
-    const int ty = r0 / a.tiles_x;
-    const int oy0 = ty * TH, ox0 = (r0 - ty * a.tiles_x) * TW;
-
-    // output offsets (OOB = masked) and the residual values of this lane's MT x 3 x 4 outputs
-    // (without a residual every load gets the OOB offset and returns 0: no branch, and the
-    // number of vector-memory operations per tile -- which the vmcnt above counts on -- is fixed)
-    unsigned voff[MT][4];
+    // the residual values of this lane's MT x 3 x 4 outputs (without a residual every load gets
+    // the OOB offset and returns 0: no branch, and the number of vector-memory operations per
+    // tile -- which the vmcnt above counts on -- is fixed)
     float rv[MT][NT][4];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int oy = oy0 + wave * MT + mt;
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int ox = ox0 + 4 * kq + r;
-        voff[mt][r] = (oy < a.Ho && ox < a.Wo) ? (unsigned)(((n * a.Ho + oy) * a.Wo + ox) * C48 + li) * 4u : EGN_OOB;
+        const unsigned ro = has_res ? voff[mt][r] : EGN_OOB;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          rv[mt][nt][r] = c48_load4(rr, (!has_res || voff[mt][r] == EGN_OOB) ? EGN_OOB : voff[mt][r] + nt * 64u);
+        for (int nt = 0; nt < NT; ++nt) rv[mt][nt][r] = c48_load4(rr, ro + nt * 64u);
       }
-    }
+    // address arithmetic of the tiles to come (computed in pieces between the MFMA steps below)
+    unsigned doff_n[A_IT], voff_n[MT][4];
+    int dn_ = 0, dty_ = 0, dtx_ = 0, vn_ = 0, vty_ = 0, vtx_ = 0;
 
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -229,9 +271,33 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
   C48_MFMA(1)                           \
   C48_INTERLEAVE()
 
+    static_assert(A_IT <= 9, "one C48_BETWEEN slot per DMA offset below");
     C48_LOADF(0, 0)
-    C48_PAIR(0) C48_PAIR(2) C48_PAIR(4) C48_PAIR(6) C48_PAIR(8) C48_PAIR(10) C48_PAIR(12)
-    C48_PAIR(14) C48_PAIR(16) C48_PAIR(18) C48_PAIR(20) C48_PAIR(22) C48_PAIR(24)
+    C48_PAIR(0)
+    C48_BETWEEN(C48_ORIGIN(next, vn_, vty_, vtx_))
+    C48_PAIR(2)
+    C48_BETWEEN(C48_ORIGIN(next + (int)gridDim.x, dn_, dty_, dtx_))
+    C48_PAIR(4)
+    C48_BETWEEN(C48_VOFF1(vn_, vty_, vtx_, voff_n))
+    C48_PAIR(6)
+    C48_BETWEEN(if constexpr (A_IT > 0) C48_OFF1(0, dn_, dty_, dtx_, doff_n))
+    C48_PAIR(8)
+    C48_BETWEEN(if constexpr (A_IT > 1) C48_OFF1(1, dn_, dty_, dtx_, doff_n))
+    C48_PAIR(10)
+    C48_BETWEEN(if constexpr (A_IT > 2) C48_OFF1(2, dn_, dty_, dtx_, doff_n))
+    C48_PAIR(12)
+    C48_BETWEEN(if constexpr (A_IT > 3) C48_OFF1(3, dn_, dty_, dtx_, doff_n))
+    C48_PAIR(14)
+    C48_BETWEEN(if constexpr (A_IT > 4) C48_OFF1(4, dn_, dty_, dtx_, doff_n))
+    C48_PAIR(16)
+    C48_BETWEEN(if constexpr (A_IT > 5) C48_OFF1(5, dn_, dty_, dtx_, doff_n))
+    C48_PAIR(18)
+    C48_BETWEEN(if constexpr (A_IT > 6) C48_OFF1(6, dn_, dty_, dtx_, doff_n))
+    C48_PAIR(20)
+    C48_BETWEEN(if constexpr (A_IT > 7) C48_OFF1(7, dn_, dty_, dtx_, doff_n))
+    C48_PAIR(22)
+    C48_BETWEEN(if constexpr (A_IT > 8) C48_OFF1(8, dn_, dty_, dtx_, doff_n))
+    C48_PAIR(24)
     C48_MFMA(0)  // step 26 (loaded by the last pair)
 
     // epilogue, straight from the accumulators
@@ -245,11 +311,23 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
           if (!res_after) v += rv[mt][nt][r];
           v = egn_act(v, act);
           if (res_after) v = rv[mt][nt][r] + v;
-          c48_store4(ry, voff[mt][r] == EGN_OOB ? EGN_OOB : voff[mt][r] + nt * 64u, v);
+          c48_store4(ry, voff[mt][r] + nt * 64u, v);
         }
     buf ^= 1;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) doff[it] = doff_n[it];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) voff[mt][r] = voff_n[mt][r];
   }
-#undef C48_STAGE
+#undef C48_ORIGIN
+#undef C48_OFF1
+#undef C48_OFFS
+#undef C48_ISSUE
+#undef C48_VOFF1
+#undef C48_VOFF
+#undef C48_BETWEEN
 #undef C48_LOADF
 #undef C48_MFMA
 #undef C48_INTERLEAVE

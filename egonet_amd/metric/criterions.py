@@ -48,6 +48,8 @@ def _decode(output, arg_max):
     """(local coordinates [N,K,2] numpy, maxvals or None, heat-map width or None)."""
     if type(output) is tuple:                         # (maps, coords in [0,1]): the coordinate head
         return output[1].data.cpu().numpy().astype(np.float32), None, None
+    if isinstance(output, torch.Tensor) and not output.is_cuda:
+        output = output.cuda()                        # the decode kernels run on the device
     if isinstance(output, np.ndarray) and arg_max == 'soft':
         pred, mv = lip.soft_arg_max_np(output)
         return pred, mv, output.shape[3]

@@ -122,9 +122,19 @@ def test_train_runs_the_hc_loop_with_metric_callback_and_snapshot(tmp_path):
     assert list(snap) == list(net.state_dict()) and int(snap['bn1.num_batches_tracked']) == 4
     fresh = hrnet.get_pose_net(cfg, is_train=False)
     fresh.load_state_dict(snap)                                      # HC.pth layout
-    # frozen configurations and unsupported loss terms are refused up front
+    # the cross-ratio term: its 'bbox12' lines need the 33-joint model; other criteria are refused
     cfg2 = configs.clone(cfg)
     cfg2['heatmapModel']['loss_spec_list'] = ['mse', 'l1', 'sl1']
     cfg2['heatmapModel']['loss_weight_list'] = [1.0, 0.1, 0.01]
+    with pytest.raises(ValueError):
+        trainer.make_step(net, cfg2)                                 # 5 joints: indices out of range
+    cfg3 = _train_cfg(configs.tiny_config('coordinates', num_joints=33), epochs=1, batch=4, report=1)
+    cfg3['heatmapModel'].update(loss_spec_list=['mse', 'l1', 'sl1'], loss_weight_list=[1.0, 0.1, 0.01],
+                                cr_loss_threshold=0.1)
+    net33 = hrnet.get_pose_net(cfg3, is_train=False).cuda()
+    step = trainer.make_step(net33, cfg3)
+    assert step.w_cr == 0.01 and step.cr_loss_thres == 0.1 and step.cr_idx.shape == (12, 4)
+    assert step.apply_cr_loss is False                               # the trainer switches it on in epoch 2
+    cfg2['heatmapModel']['loss_spec_list'] = ['sl1', 'l1', 'None']
     with pytest.raises(NotImplementedError):
         trainer.make_step(net, cfg2)

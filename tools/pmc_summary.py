@@ -18,7 +18,7 @@ def main():
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 name = row.get('Kernel_Name', '')
-                if 'conv_mfma' not in name and 'fuse' not in name and 'decode' not in name:
+                if 'conv_' not in name and 'fuse' not in name and 'decode' not in name:
                     continue
                 key = (name[:60], row.get('Grid_Size', ''), row.get('LDS_Block_Size', ''), row.get('VGPR_Count', ''),
                        row.get('Accum_VGPR_Count', ''), row.get('Scratch_Size', ''))
