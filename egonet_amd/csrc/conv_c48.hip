@@ -336,11 +336,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
 
 template <int WAVES>
 static int c48_launch(const ConvArgs& a, size_t lds, int grid, hipStream_t stream) {
-  static bool raised = false;
-  if (!raised) {
+  static bool raised[EGN_MAX_DEVICES];  // per instantiation and device
+  if (egn_first_use_on_device(raised)) {
     EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c48_kernel<WAVES>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-    raised = true;
   }
   hipLaunchKernelGGL((conv_c48_kernel<WAVES>), dim3(grid), dim3(64 * WAVES), lds, stream, a);
   return (int)hipGetLastError();

@@ -269,11 +269,10 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
 
 template <int WM, int WN, int MT, int NT, int ABL>
 static int launch_abl(const ConvArgs& a, size_t lds, hipStream_t stream) {
-  static bool raised = false;  // per instantiation; one device per process
-  if (!raised) {
+  static bool raised[EGN_MAX_DEVICES];  // per instantiation and device
+  if (egn_first_use_on_device(raised)) {
     EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN, MT, NT, 8, 8, ABL>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-    raised = true;
   }
   const int tiles_b = (a.N + a.TNB - 1) / a.TNB;
   dim3 grid(a.tiles_x * a.tiles_y * tiles_b, (a.CoutP + WN * NT * 16 - 1) / (WN * NT * 16));
@@ -283,11 +282,10 @@ static int launch_abl(const ConvArgs& a, size_t lds, hipStream_t stream) {
 
 template <int WM, int WN, int MT, int NT>
 static int launch_one(const ConvArgs& a, size_t lds, hipStream_t stream) {
-  static bool raised = false;  // per instantiation; one device per process
-  if (!raised) {
+  static bool raised[EGN_MAX_DEVICES];  // per instantiation and device
+  if (egn_first_use_on_device(raised)) {
     EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_dma_kernel<WM, WN, MT, NT, 8, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-    raised = true;
   }
   const int tiles_b = (a.N + a.TNB - 1) / a.TNB;
   dim3 grid(a.tiles_x * a.tiles_y * tiles_b, (a.CoutP + WN * NT * 16 - 1) / (WN * NT * 16));

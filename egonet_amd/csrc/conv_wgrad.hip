@@ -390,10 +390,9 @@ static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
 template <int NTAPW, int TPW, int WM, int WN, int J, int A_IT, int B_IT, int KS = 1>
 static int wgrad_launch(const WgradArgs& a, size_t lds, hipStream_t stream) {
   auto k = conv_wgrad_kernel<NTAPW, TPW, WM, WN, J, A_IT, B_IT, KS>;
-  static bool raised = false;  // per instantiation; one device per process (a driver call per launch costs ~10 us of host time)
-  if (!raised) {
+  static bool raised[EGN_MAX_DEVICES];  // per instantiation and device
+  if (egn_first_use_on_device(raised)) {
     EGN_CHECK_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-    raised = true;
   }
   hipLaunchKernelGGL(k, dim3(a.co_tiles * a.ci_tiles, a.nsplit), dim3(64 * NTAPW * WM * WN * KS), lds, stream, a);
   return (int)hipGetLastError();

@@ -4,6 +4,17 @@
 #include <stdint.h>
 #include "../../include/egonet_hip.h"
 
+// hipFuncSetAttribute is per device: a flag per device (the reference drives several GPUs from one
+// process through nn.DataParallel, one thread each), set on the first launch there
+constexpr int EGN_MAX_DEVICES = 64;
+static inline bool egn_first_use_on_device(bool* seen) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= EGN_MAX_DEVICES) return true;
+  if (seen[d]) return false;
+  seen[d] = true;
+  return true;
+}
+
 #define EGN_CHECK_HIP(expr)                      \
   do {                                           \
     hipError_t _e = (expr);                      \
