@@ -33,6 +33,7 @@ torch autograd / MIOpen are not involved:
   call per bucket, ``egonet_amd.parallel``).
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -163,6 +164,9 @@ class _Tape(object):
         self.data = {}            # id(Buf) -> 1-D fp32 tensor
         self.grad = {}            # id(Buf) -> [tensor, owned]
         self.keep = []            # Bufs (ids stay unique while the tape lives)
+        self.side = owner.wgrad_stream      # weight gradients run here, beside the backward chain
+        self.side_st = None if self.side is None else C.c_void_p(self.side.cuda_stream)
+        self.side_keep = []       # tensors the side stream reads: alive until it is joined
         self.back = []            # backward closures, forward order
         self.named = {}           # tag -> Buf
         self.user = {}            # tag -> NCHW copy for the caller
@@ -228,9 +232,28 @@ class _Tape(object):
         if need < 0:
             raise NotImplementedError('weight gradient of a %dx%d convolution' % (kh, kw))
         ws = self.o.wgrad_ws(need)
+        st = self.st
+        if self.side is not None:
+            # nothing on the backward chain waits for a weight gradient (only the optimizer does):
+            # issue it on the side stream once dy exists, so the latency-bound BatchNorm / reduction
+            # kernels of the chain overlap its MFMA work.  One side stream: the launches share ws.
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            self.side.wait_event(ev)
+            self.side_keep.append((xd, dy))
+            st = self.side_st
         _lib.check(L.egn_conv2d_wgrad_f32(_lib.ptr(xd), _lib.ptr(dy), _lib.ptr(weight.grad), x.n, x.h, x.w, cin, x.cs,
-                                          cout, cs_out, kh, kw, stride, pad, _lib.ptr(ws), ws.numel() * 4, self.st),
+                                          cout, cs_out, kh, kw, stride, pad, _lib.ptr(ws), ws.numel() * 4, st),
                    'wgrad')
+
+    def join_side(self):
+        """The side stream's weight gradients are complete for everything issued after this on the
+        main stream (gradient all-reduce, Adam); the tensors they read may be released."""
+        if self.side is not None and self.side_keep:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            torch.cuda.current_stream(self.dev).wait_event(ev)
+            self.side_keep = []
 
     def _dgrad(self, dy, ho, wo, cs_out, weight, stride, pad, x):
         cout, cin, kh, kw = weight.shape
@@ -462,6 +485,9 @@ class HRNetTrainStep(object):
         self.zeros = torch.zeros(_round_up(widest, 16), dtype=torch.float32, device=self.dev)
         self.col_ws = torch.zeros(self.L.egn_colreduce_ws_bytes(widest) // 4, dtype=torch.float32, device=self.dev)
         self._wgrad_ws = None
+        # weight gradients on a second stream (EGONET_AMD_WGRAD_STREAM=0: everything on one stream)
+        self.wgrad_stream = torch.cuda.Stream(device=self.dev) \
+            if os.environ.get('EGONET_AMD_WGRAD_STREAM', '1') != '0' else None
         self.loss_dev = torch.zeros(1, dtype=torch.float64, device=self.dev)
         self.walker = HRNetEngine(model)
         self.packs = PackedFilters(self.dev)
@@ -470,7 +496,11 @@ class HRNetTrainStep(object):
 
     def wgrad_ws(self, nbytes):
         if self._wgrad_ws is None or self._wgrad_ws.numel() * 4 < nbytes:
-            self._wgrad_ws = torch.empty(nbytes // 4 + 1024, dtype=torch.float32, device=self.dev)
+            # allocated in the pool of the stream that uses it: when it has to grow, the old block is
+            # only handed to later work of that same stream
+            with torch.cuda.stream(self.wgrad_stream if self.wgrad_stream is not None
+                                   else torch.cuda.current_stream(self.dev)):
+                self._wgrad_ws = torch.empty(nbytes // 4 + 1024, dtype=torch.float32, device=self.dev)
         return self._wgrad_ws
 
     @torch.no_grad()
@@ -553,6 +583,7 @@ class HRNetTrainStep(object):
             tape._accum(aug, da)
             for fn in reversed(tape.back):
                 fn()
+            tape.join_side()
             if self.grad_sync is not None:
                 self.grad_sync(self.flat.grad)
             if update:

@@ -44,6 +44,7 @@ class LayerChecks(object):
 
         def wgrad(tape, x, xd, dy, cs_out, weight, stride, pad):
             orig_w(tape, x, xd, dy, cs_out, weight, stride, pad)
+            torch.cuda.synchronize()           # the launch may be on the trainer's side stream
             cout, cin, kh, kw = weight.shape
             ho, wo = (x.h + 2 * pad - kh) // stride + 1, (x.w + 2 * pad - kw) // stride + 1
             wt = torch.zeros(cout, cin, kh, kw, dtype=torch.float64, requires_grad=True)
