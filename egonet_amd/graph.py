@@ -27,6 +27,11 @@ class GraphedStep(object):
             if t is not None and not (torch.is_tensor(t) and t.is_cuda):
                 raise ValueError('GraphedStep inputs must be CUDA tensors (they become the static graph inputs)')
         self.trainer = trainer
+        # the trainer's side stream for weight gradients helps eager steps (-4 %); inside a graph the
+        # forked branch replays slower than one chain (78.4 vs 76 ms measured), so capture one stream
+        if getattr(trainer, 'wgrad_stream', None) is not None:
+            trainer.wgrad_stream = None
+            trainer._wgrad_ws = None
         self.static = [None if t is None else t.clone() for t in inputs]
         self.kwargs = kwargs
         dev = next(t for t in self.static if t is not None).device
