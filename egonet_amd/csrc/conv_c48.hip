@@ -66,8 +66,14 @@ constexpr int NT = 3;
 
 // WAVES = 4: wave w owns tile rows 2w, 2w+1 (MT = 2); WAVES = 8: one row each (MT = 1), two
 // waves per SIMD so that one wave's epilogue / barrier wait hides under the other's MFMAs
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
+//
+// REGF (4 waves only): every wave copies ALL its B fragments (27 steps x 3 float4 = 324 registers,
+// one wave per SIMD owns the whole 512-entry file) out of LDS once, and the K loop reads only the
+// A fragments: 24 MFMAs per 2 ds_read_b128 instead of 12 per 4.  In isolation
+// (tools/micro/mfma_lds.hip vs mfma_regfilter.hip) that loop runs at 141 TFLOP/s where the
+// LDS-fed one reaches 113-125: the ds_reads woven between the MFMAs are what the pipe waits for.
+template <int WAVES, bool REGF>
+__device__ __forceinline__ void c48_body(const ConvArgs& a) {
   constexpr int NTH = 64 * WAVES;
   constexpr int MT = TH / WAVES;
   constexpr int A_IT = (HALO_SLOTS + NTH - 1) / NTH;  // DMA instructions per lane and tile
@@ -201,6 +207,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) pixbase[mt] = ((wave * MT + mt) * HWD + li) * EGN_CKQ + kq;
 
+  float4 bfr[REGF ? 27 : 1][NT];
+  if constexpr (REGF) {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0070);  // the filter DMA has landed
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int s_ = 0; s_ < 27; ++s_)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bfr[s_][nt] = sW[(s_ * EGN_CKQ + kq) * C48 + nt * 16 + li];
+  }
+
   bool first = true;
   for (; tile < ntiles; tile += gridDim.x) {
     // this tile's halo DMA (and, the first time, the filter) must have landed and the
@@ -248,14 +266,18 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
     constexpr int c_ = (S) / 9, t_ = (S) % 9;                                                       \
     constexpr int ds_ = ((t_ / 3) * HWD + (t_ % 3)) * EGN_CKQ + c_ * CHUNK_SLOTS;                   \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) af[K][mt] = curA[pixbase[mt] + ds_];          \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) bf[K][nt] = sW[((S)*EGN_CKQ + kq) * C48 + nt * 16 + li]; \
+    if constexpr (!REGF) {                                                                          \
+      _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) bf[K][nt] = sW[((S)*EGN_CKQ + kq) * C48 + nt * 16 + li]; \
+    }                                                                                               \
   }
-#define C48_MFMA(K)                                                                                  \
+// step S with the A fragments of register set K; B from register set K or, REGF, from bfr[S]
+#define C48_MFMA(K, S)                                                                               \
   _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) { \
-    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[K][mt].x, bf[K][nt].x, acc[mt][nt], 0, 0, 0); \
-    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[K][mt].y, bf[K][nt].y, acc[mt][nt], 0, 0, 0); \
-    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[K][mt].z, bf[K][nt].z, acc[mt][nt], 0, 0, 0); \
-    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[K][mt].w, bf[K][nt].w, acc[mt][nt], 0, 0, 0); \
+    const float4 b_ = REGF ? bfr[REGF ? (S) : 0][nt] : bf[K][nt];                                    \
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[K][mt].x, b_.x, acc[mt][nt], 0, 0, 0);     \
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[K][mt].y, b_.y, acc[mt][nt], 0, 0, 0);     \
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[K][mt].z, b_.z, acc[mt][nt], 0, 0, 0);     \
+    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[K][mt].w, b_.w, acc[mt][nt], 0, 0, 0);     \
   }
 #define C48_INTERLEAVE()                                                            \
   _Pragma("unroll") for (int k_ = 0; k_ < MT * NT * 4; ++k_) {                       \
@@ -265,10 +287,10 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
 // steps S and S+1: the ds_reads of the next step are in flight under the MFMAs of this one
 #define C48_PAIR(S)                     \
   C48_LOADF((S) + 1, 1)                 \
-  C48_MFMA(0)                           \
+  C48_MFMA(0, S)                        \
   C48_INTERLEAVE()                      \
   C48_LOADF((S) + 2 < 27 ? (S) + 2 : 26, 0) \
-  C48_MFMA(1)                           \
+  C48_MFMA(1, (S) + 1)                  \
   C48_INTERLEAVE()
 
     static_assert(A_IT <= 9, "one C48_BETWEEN slot per DMA offset below");
@@ -298,7 +320,7 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
     C48_PAIR(22)
     C48_BETWEEN(if constexpr (A_IT > 8) C48_OFF1(8, dn_, dty_, dtx_, doff_n))
     C48_PAIR(24)
-    C48_MFMA(0)  // step 26 (loaded by the last pair)
+    C48_MFMA(0, 26)  // step 26 (loaded by the last pair)
 
     // epilogue, straight from the accumulators
 #pragma unroll
@@ -335,6 +357,13 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
 }
 
 template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
+  c48_body<WAVES, false>(a);
+}
+// the register-resident-filter variant (config 43)
+__global__ __launch_bounds__(256, 1) void conv_c48r_kernel(ConvArgs a) { c48_body<4, true>(a); }
+
+template <int WAVES>
 static int c48_launch(const ConvArgs& a, size_t lds, int grid, hipStream_t stream) {
   static bool raised[EGN_MAX_DEVICES];  // per instantiation and device
   if (egn_first_use_on_device(raised)) {
@@ -356,5 +385,14 @@ int egn_conv_launch_c48(const ConvArgs& a, size_t lds, int waves, hipStream_t st
   }
   const int ntiles = a.tiles_x * a.tiles_y * a.N;
   const int grid = ntiles < cus ? ntiles : cus;
+  if (waves == 0) {  // register-resident filter
+    static bool raised[EGN_MAX_DEVICES];
+    if (egn_first_use_on_device(raised)) {
+      EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_c48r_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+    }
+    hipLaunchKernelGGL(conv_c48r_kernel, dim3(grid), dim3(256), lds, stream, a);
+    return (int)hipGetLastError();
+  }
   return waves == 8 ? c48_launch<8>(a, lds, grid, stream) : c48_launch<4>(a, lds, grid, stream);
 }

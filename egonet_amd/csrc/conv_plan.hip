@@ -63,6 +63,7 @@ static const ConvConfig kConfigs[] = {
     {40, 1, 4, 2, 3, 8, 8, 3},
     {41, 4, 1, 2, 3, 9, 0, 4},  // 48 -> 48 3x3 s1 only: filter resident in LDS, persistent (conv_c48.hip)
     {42, 8, 1, 1, 3, 5, 0, 4},  // the same with 8 waves (two per SIMD)
+    {43, 4, 1, 2, 3, 9, 1, 4},  // 4 waves, each with the whole filter in REGISTERS (bi = 1 marks it)
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -82,7 +83,9 @@ extern "C" int egn_conv_config_info(int cfg, int* tile_m, int* tile_n) {
 extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (cfg < 1 || cfg > kNumConfigs || !buf || len < 8) return EGN_E_BADARG;
   const ConvConfig& c = kConfigs[cfg - 1];
-  if (c.dma == 4)
+  if (c.dma == 4 && c.bi == 1)
+    snprintf(buf, len, "conv_c48r_kernel(ConvArgs)");
+  else if (c.dma == 4)
     snprintf(buf, len, "void conv_c48_kernel<%d>(ConvArgs)", c.wm);
   else if (c.dma == 3)
     snprintf(buf, len, "void conv_pers_kernel<%d, %d, %d, %d, 8, 8>(ConvArgs)", c.wm, c.wn, c.mt, c.nt);
@@ -229,7 +232,7 @@ int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {
   if (cfg_id < 1 || cfg_id > kNumConfigs) return EGN_E_BADARG;
   const ConvConfig& cf = kConfigs[cfg_id - 1];
   const size_t lds = lds_bytes_for(a, cf);
-  if (cf.dma == 4) return egn_conv_launch_c48(a, lds, cf.wm, stream);
+  if (cf.dma == 4) return egn_conv_launch_c48(a, lds, cf.bi == 1 ? 0 : cf.wm, stream);
   if (cf.dma == 3) return egn_conv_launch_pers(a, (cfg_id - 1) % 10 + 1, lds, stream);
   return cf.dma ? egn_conv_launch_dma(a, (cfg_id - 1) % 10 + 1, lds, stream)
                 : egn_conv_launch_staged(a, cfg_id, lds, stream);

@@ -106,18 +106,20 @@ def test_planner_limits():
 
 
 def test_filter_resident_configs_plan_only_the_48_channel_3x3_layers():
-    """Configs 41 / 42 (csrc/conv_c48.hip): fixed 8x16 tile, filter (82 944 B) + two
-    48-channel halo buffers (2 x 36 864 B) in LDS, refused for every other layer."""
+    """Configs 41 / 42 / 43 (csrc/conv_c48.hip): fixed 8x16 tile, filter (82 944 B) + two
+    48-channel halo buffers (2 x 36 864 B) in LDS, refused for every other layer.  43 = four
+    waves that copy the whole filter into registers."""
     L = _lib.lib()
-    assert L.egn_conv_num_configs() == 42
-    for cfg, waves in ((41, 4), (42, 8)):
+    assert L.egn_conv_num_configs() == 43
+    for cfg, waves in ((41, 4), (42, 8), (43, 4)):
         plan = _plan((64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0), cfg=cfg)
         cfg_id, wm, wn, mt, nt, th, tw, tnb, tps, lds = plan[:10]
         assert (cfg_id, wm, wn, mt, nt) == (cfg, waves, 1, 8 // waves, 3)
         assert (th, tw, tnb, tps) == (8, 16, 1, 9) and lds == 82944 + 2 * 36864
         name = C.create_string_buffer(96)
         assert L.egn_conv_config_name(cfg, name, 96) == 0
-        assert name.value == b'void conv_c48_kernel<%d>(ConvArgs)' % waves
+        assert name.value == (b'conv_c48r_kernel(ConvArgs)' if cfg == 43 else
+                              b'void conv_c48_kernel<%d>(ConvArgs)' % waves)
         out = (C.c_int * 12)()
         for bad in ((64, 64, 64, 48, 48, 96, 96, 3, 3, 1, 1, 0),      # 48 -> 96
                     (64, 64, 64, 96, 96, 48, 48, 3, 3, 1, 1, 0),      # 96 -> 48
