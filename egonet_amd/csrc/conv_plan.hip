@@ -64,6 +64,7 @@ static const ConvConfig kConfigs[] = {
     {41, 4, 1, 2, 3, 9, 0, 4},  // 48 -> 48 3x3 s1 only: filter resident in LDS, persistent (conv_c48.hip)
     {42, 8, 1, 1, 3, 5, 0, 4},  // the same with 8 waves (two per SIMD)
     {43, 4, 1, 2, 3, 9, 1, 4},  // 4 waves, each with the whole filter in REGISTERS (bi = 1 marks it)
+    {44, 8, 1, 2, 3, 3, 2, 4},  // 8 waves x 2 rows on a 16 x 16 tile, halo as a ring of chunks (bi = 2)
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -83,7 +84,9 @@ extern "C" int egn_conv_config_info(int cfg, int* tile_m, int* tile_n) {
 extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (cfg < 1 || cfg > kNumConfigs || !buf || len < 8) return EGN_E_BADARG;
   const ConvConfig& c = kConfigs[cfg - 1];
-  if (c.dma == 4 && c.bi == 1)
+  if (c.dma == 4 && c.bi == 2)
+    snprintf(buf, len, "conv_c48t_kernel(ConvArgs)");
+  else if (c.dma == 4 && c.bi == 1)
     snprintf(buf, len, "conv_c48r_kernel(ConvArgs)");
   else if (c.dma == 4)
     snprintf(buf, len, "void conv_c48_kernel<%d>(ConvArgs)", c.wm);
@@ -111,6 +114,7 @@ static size_t lds_stage_bytes(const ConvArgs& a, const ConvConfig& cf) {
   return ((main_loop > epi ? main_loop : epi) + 15) & ~(size_t)15;
 }
 static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
+  if (cf.dma == 4 && cf.bi == 2) return (size_t)(3 * 336 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // chunk ring + filter
   if (cf.dma == 4) return (size_t)(2 * 3 * 192 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // 2 halo buffers + filter
   if (cf.dma == 3) return lds_stage_bytes(a, cf) + (size_t)4 * 16 * (cf.nt * 16 + 4) * 4;
   return lds_stage_bytes(a, cf) + (size_t)cf.tile_m() * 4;
@@ -125,10 +129,10 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin != 48 || a.cs_in != 48 || a.Cout != 48 ||
         a.cs_out != 48 || a.out_nchw)
       return false;
-    a.TH = 8; a.TW = 16; a.TNB = 1; a.HH = 10; a.HW = 18;
-    a.npix = 180; a.npixp = 192; a.tps = 9;
+    a.TH = cf.bi == 2 ? 16 : 8; a.TW = 16; a.TNB = 1; a.HH = a.TH + 2; a.HW = 18;
+    a.npix = a.HH * 18; a.npixp = cf.bi == 2 ? 336 : 192; a.tps = 9;
     a.tiles_x = (a.Wo + 15) / 16;
-    a.tiles_y = (a.Ho + 7) / 8;
+    a.tiles_y = (a.Ho + a.TH - 1) / a.TH;
     if (cost_out) *cost_out = 0.0;
     return true;
   }
@@ -232,7 +236,7 @@ int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {
   if (cfg_id < 1 || cfg_id > kNumConfigs) return EGN_E_BADARG;
   const ConvConfig& cf = kConfigs[cfg_id - 1];
   const size_t lds = lds_bytes_for(a, cf);
-  if (cf.dma == 4) return egn_conv_launch_c48(a, lds, cf.bi == 1 ? 0 : cf.wm, stream);
+  if (cf.dma == 4) return egn_conv_launch_c48(a, lds, cf.bi == 2 ? -1 : cf.bi == 1 ? 0 : cf.wm, stream);
   if (cf.dma == 3) return egn_conv_launch_pers(a, (cfg_id - 1) % 10 + 1, lds, stream);
   return cf.dma ? egn_conv_launch_dma(a, (cfg_id - 1) % 10 + 1, lds, stream)
                 : egn_conv_launch_staged(a, cfg_id, lds, stream);

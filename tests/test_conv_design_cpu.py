@@ -110,7 +110,7 @@ def test_filter_resident_configs_plan_only_the_48_channel_3x3_layers():
     48-channel halo buffers (2 x 36 864 B) in LDS, refused for every other layer.  43 = four
     waves that copy the whole filter into registers."""
     L = _lib.lib()
-    assert L.egn_conv_num_configs() == 43
+    assert L.egn_conv_num_configs() == 44
     for cfg, waves in ((41, 4), (42, 8), (43, 4)):
         plan = _plan((64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0), cfg=cfg)
         cfg_id, wm, wn, mt, nt, th, tw, tnb, tps, lds = plan[:10]
@@ -129,3 +129,18 @@ def test_filter_resident_configs_plan_only_the_48_channel_3x3_layers():
             assert L.egn_conv_plan_query(*bad, cfg, out) != 0
         # ragged maps still plan (partial tiles are masked in the kernel)
         assert _plan((3, 19, 13, 48, 48, 48, 48, 3, 3, 1, 1, 0), cfg=cfg)[5:8] == [8, 16, 1]
+
+
+def test_tall_tile_filter_resident_config():
+    """Config 44: 16 x 16 tile, 8 waves x 2 rows, the halo as a ring of three 16-channel chunks
+    (3 x 21 504 B) next to the filter."""
+    L = _lib.lib()
+    plan = _plan((64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0), cfg=44)
+    cfg_id, wm, wn, mt, nt, th, tw, tnb, tps, lds = plan[:10]
+    assert (cfg_id, wm, mt, nt, th, tw, tnb, tps) == (44, 8, 2, 3, 16, 16, 1, 9)
+    assert lds == 82944 + 3 * 21504 and lds <= 160 * 1024 - 512
+    name = C.create_string_buffer(96)
+    assert L.egn_conv_config_name(44, name, 96) == 0 and name.value == b'conv_c48t_kernel(ConvArgs)'
+    out = (C.c_int * 12)()
+    assert L.egn_conv_plan_query(64, 64, 64, 48, 48, 96, 96, 3, 3, 1, 1, 0, 44, out) != 0
+    assert _plan((3, 19, 13, 48, 48, 48, 48, 3, 3, 1, 1, 0), cfg=44)[5:8] == [16, 16, 1]

@@ -119,8 +119,8 @@ def test_conv_c48_resident_filter_kernel(n, h, w, res, act):
     import ctypes as C
     from egonet_amd import _lib
     L = _lib.lib()
-    assert L.egn_conv_num_configs() >= 43
-    for cfg in (41, 42, 43):         # 4 waves x 2 tile rows, 8 waves x 1 row, 4 waves + filter in registers
+    assert L.egn_conv_num_configs() >= 44
+    for cfg in (41, 42, 43, 44):     # 4 waves x 2 rows, 8 x 1, 4 + filter in registers, 8 x 2 on a 16-row tile
         err = _conv_case(n, h, w, 48, 48, 3, 1, 1, act=act, use_res=res, cfg=cfg, seed=n + h)
         assert err < 2e-4, (cfg, err)
     out = (C.c_int * 12)()
