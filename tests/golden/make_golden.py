@@ -17,6 +17,9 @@ stored in full (tiny nets) or regenerated from ``egonet_amd.synth`` (per-key
 seeded, construction-order independent) for the full-size W48 / lifter nets.
 
 Usage:  python tests/golden/make_golden.py            (from the repo root)
+        --train-only   stop after the training-side fixtures (sections 0 .. 0e)
+        --cr-only      stop after the cross-ratio / metric fixtures (0d, 0e)
+The generation is deterministic: re-running leaves the committed files byte-identical.
 """
 import json
 import os
