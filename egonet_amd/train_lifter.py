@@ -19,6 +19,7 @@ Dropout uses a torch-generated keep mask (the reference's mask stream cannot be
 reproduced bit for bit anyway); parity tests run with p = 0.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -64,6 +65,11 @@ class LifterTrainStep(object):
         self.zeros = torch.zeros(widest, dtype=torch.float32, device=self.dev)   # conv shift for dgrad / wgrad
         self.L = _lib.lib()
         self.loss_dev = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        # weight gradients on a side stream, beside the backward chain (as in train_hrnet;
+        # EGONET_AMD_WGRAD_STREAM=0: one stream)
+        self.wgrad_stream = torch.cuda.Stream(device=self.dev) \
+            if os.environ.get('EGONET_AMD_WGRAD_STREAM', '1') != '0' else None
+        self._side_used = False
 
     # -- helpers -----------------------------------------------------------
     def _buf(self, name, *shape):
@@ -113,8 +119,23 @@ class LifterTrainStep(object):
             raise _lib.EgonetHipError('wgrad: unsupported shape')
         ws = self._buf('wgrad_ws', max(need // 4, self._wgrad_floats))
         self._wgrad_floats = ws.numel()
+        st = self._st()
+        if self.wgrad_stream is not None:
+            # a and dz are named buffers of this unit that nothing overwrites before the join
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            self.wgrad_stream.wait_event(ev)
+            st = C.c_void_p(self.wgrad_stream.cuda_stream)
+            self._side_used = True
         _lib.check(L.egn_conv2d_wgrad_f32(_lib.ptr(a), _lib.ptr(dz), _lib.ptr(grad_w), rows, 1, 1, inf, ld_a, outf,
-                                          ld_dz, 1, 1, 1, 0, _lib.ptr(ws), ws.numel() * 4, self._st()), 'wgrad')
+                                          ld_dz, 1, 1, 1, 0, _lib.ptr(ws), ws.numel() * 4, st), 'wgrad')
+
+    def _join_side(self):
+        if self.wgrad_stream is not None and self._side_used:
+            ev = torch.cuda.Event()
+            ev.record(self.wgrad_stream)
+            torch.cuda.current_stream(self.dev).wait_event(ev)
+            self._side_used = False
 
     # -- the step -----------------------------------------------------------
     @torch.no_grad()
@@ -199,7 +220,7 @@ class LifterTrainStep(object):
                                                  _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), 1, None,
                                                  B, u.outf, u.outf, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(ws),
                                                  st), 'bn_bwd_sums')
-                dz = self._buf('dz', B, u.outf)
+                dz = self._buf('dz%d' % ui, B, u.outf)     # per unit: the side stream reads it until the join
                 _lib.check(L.egn_bn_bwd_dz_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
                                                _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), 1, None,
                                                _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(dz), None, B, u.outf,
@@ -217,6 +238,7 @@ class LifterTrainStep(object):
                     _lib.check(L.egn_add_f32(_lib.ptr(d_block_out), _lib.ptr(da), _lib.ptr(nxt), B * u.inf, st))
                     d_block_out = nxt
 
+            self._join_side()
             if self.grad_sync is not None:
                 self.grad_sync(self.flat.grad)
             if update:
