@@ -194,11 +194,18 @@ __global__ __launch_bounds__(256, 2) void conv_dma_kernel(ConvArgs a) {
 // wave can issue ~6 other instructions meanwhile.  Ask the scheduler to put one
 // DS-read / VALU / SALU instruction (the next tap's fragment reads and their
 // address math) behind every MFMA instead of a block of them in front.
+// Measured [MI355X r1]: the compiler's own placement is better for the selected tiles (MT*NT = 6:
+// 24 MFMAs per 5 reads) -- 96 ch 100.5 -> 95.7 us, 192 ch 94.3 -> 92.0 us, backbone 26.70 -> 26.37 ms
+// -- so the hint is off unless the library is built with -DEGN_DMA_INTERLEAVE.
+#ifndef EGN_DMA_INTERLEAVE
+#define EGN_INTERLEAVE()
+#else
 #define EGN_INTERLEAVE()                                                             \
   _Pragma("unroll") for (int k_ = 0; k_ < MT * NT * 4; ++k_) {                       \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* 1 MFMA */                  \
     __builtin_amdgcn_sched_group_barrier(0x106, 1, 0); /* 1 DS read | VALU | SALU */ \
   }
+#endif
 
 // MFMA loop of stage S on sA[chunk & 1] / sB[S & 1]; the ds_reads of tap t+1 are
 // issued before the MFMAs of tap t (register double buffer afA/afB)
