@@ -36,11 +36,10 @@ import ctypes as C
 import os
 
 import torch
-import torch.nn as nn
 
 from . import _lib, tuner
 from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID
-from .engine import Buf, HRNetEngine, SLOT_USER0, _round_up
+from .engine import Buf, HRNetEngine, _round_up
 
 
 class FlatParams(object):
