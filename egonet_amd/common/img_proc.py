@@ -9,8 +9,6 @@ Decode runs on the GPU (``csrc/decode.hip``, one wavefront per heat-map):
 Host helpers (pure Python, per bounding box): ``modify_bbox`` & co.
 (img_proc.py:411-459).
 """
-import ctypes as C
-
 import numpy as np
 import torch
 

@@ -18,7 +18,6 @@ Crop extraction (``crop_instances``, cv2.warpAffine) and plotting are outside
 the hot path: ``forward(annot_dict)`` needs ``cv2`` and
 imports it lazily.
 """
-import ctypes as C
 import math
 from os.path import join as pjoin
 
