@@ -395,6 +395,8 @@ class HRNetEngine(object):
         self.programs = {}        # (device, N, H, W, decode) -> Program
         self._stamp = None
         self.lanes = os.environ.get('EGONET_AMD_LANES', '1') != '0'   # branch-level concurrency
+        # fuse output i -> branch i of the next module on the same lane, no join in between
+        self.chain_regions = os.environ.get('EGONET_AMD_CHAIN', '1') != '0'
 
     # -- recording ---------------------------------------------------------
     def _block(self, r, x, blk, tag):
@@ -426,13 +428,18 @@ class HRNetEngine(object):
                        tag='%s.%d' % (tag, s))
         return t
 
-    def _module(self, r, xs, mod, tag):
+    def _module(self, r, xs, mod, tag, region_open=False, keep_open=False):
+        """``region_open``: the previous module left its fuse region open -- output i was
+        produced on lane i, which is exactly what branch i of this module reads, so the
+        branches continue on their lanes without a join/fork pair in between (lane 0 does
+        not wait for the coarse lanes' fuse work).  ``keep_open``: leave this module's fuse
+        region open for the next one (same stage, same branch count).  Returns (outs, open)."""
         xs = list(xs)
         # the resolution branches are independent (hrnet.py:286-287): one launch
         # lane each, so their kernels overlap each other's prologue / epilogue /
         # tail and the small coarse-branch grids do not leave the chip idle
         lanes = self.lanes and mod.num_branches > 1
-        if lanes:
+        if lanes and not region_open:
             r.fork()
         for b, branch in enumerate(mod.branches):
             if lanes:
@@ -442,7 +449,7 @@ class HRNetEngine(object):
         if lanes:
             r.join()
         if mod.fuse_layers is None:
-            return xs
+            return xs, False
         outs = []
         if lanes:                       # the fuse outputs are independent too (hrnet.py:291-298)
             r.fork()
@@ -461,9 +468,10 @@ class HRNetEngine(object):
                 else:
                     terms.append((self._unit_chain(r, xs[j], row[j], q), 0))
             outs.append(r.fuse(terms, True, tag='%s.fuse%d' % (tag, i)))
-        if lanes:
+        stay = lanes and keep_open and self.chain_regions and len(outs) == mod.num_branches
+        if lanes and not stay:
             r.join()
-        return outs
+        return outs, stay
 
     def _record(self, n, cin, h, w, decode_mode, r=None):
         """Walk the module tree once, issuing every layer to the recorder ``r``.
@@ -488,8 +496,12 @@ class HRNetEngine(object):
                                      tag='transition%d.%d' % (idx, i)))
                 else:
                     xs.append(self._unit_chain(r, ys[-1], tr, 'transition%d.%d' % (idx, i)))
-            for k, mod in enumerate(getattr(m, 'stage%d' % (idx + 1))):
-                xs = self._module(r, xs, mod, 'stage%d.%d' % (idx + 1, k))
+            stage = getattr(m, 'stage%d' % (idx + 1))
+            open_ = False
+            for k, mod in enumerate(stage):
+                nxt = stage[k + 1] if k + 1 < len(stage) else None
+                keep = nxt is not None and nxt.num_branches == mod.num_branches
+                xs, open_ = self._module(r, xs, mod, 'stage%d.%d' % (idx + 1, k), region_open=open_, keep_open=keep)
             ys = xs
         trunk = ys[0]
         J = m.num_joints
