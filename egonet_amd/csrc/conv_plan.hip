@@ -18,6 +18,8 @@ int egn_conv_launch_staged(const ConvArgs& a, int cfg_id, size_t lds, hipStream_
 int egn_conv_launch_dma(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
 int egn_conv_launch_pers(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
 int egn_conv_launch_c48(const ConvArgs& a, size_t lds, int waves, hipStream_t stream);
+int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t stream);
+size_t egn_conv_wino_lds_bytes(int variant);
 
 static const ConvConfig kConfigs[] = {
     // id wm wn mt nt ai bi dma (ai / bi = staging depth in dwordx4 per lane)
@@ -65,6 +67,14 @@ static const ConvConfig kConfigs[] = {
     {42, 8, 1, 1, 3, 5, 0, 4},  // the same with 8 waves (two per SIMD)
     {43, 4, 1, 2, 3, 9, 1, 4},  // 4 waves, each with the whole filter in REGISTERS (bi = 1 marks it)
     {44, 8, 1, 2, 3, 3, 2, 4},  // 8 waves x 2 rows on a 16 x 16 tile, halo as a ring of chunks (bi = 2)
+    // fused Winograd F(2x2,3x3) (conv_wino.hip): 3x3 s1 p1, Cin % 16 == 0, Cout % 48 == 0.  `w` must be
+    // the TRANSFORMED filter (egn_wino_pack_weight_f32 / engine.pack_wino_weight), not the direct pack.
+    {45, 4, 1, 1, 3, 6, 0, 5},  // 16 x 16 pixel tile of one image (bi = variant 0)
+    {46, 4, 1, 1, 3, 7, 1, 5},  // four 8 x 8 images per block (bi = variant 1)
+    {47, 4, 1, 1, 3, 6, 0x10, 5},  // timing ablations of 45 (WRONG RESULTS, tools/wino_probe.py only):
+    {48, 4, 1, 1, 3, 6, 0x20, 5},  // no DMA / no input transform / no epilogue memory ops / no barriers
+    {49, 4, 1, 1, 3, 6, 0x30, 5},
+    {50, 4, 1, 1, 3, 6, 0x40, 5},
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -79,12 +89,23 @@ extern "C" int egn_conv_config_info(int cfg, int* tile_m, int* tile_n) {
   return 0;
 }
 
+// 0 = direct kernels (wpack from egn_pack_conv_weight_f32), 1 = Winograd kernels (wpack from
+// egn_wino_pack_weight_f32), -1 = not selectable (timing ablations, invalid ids)
+extern "C" int egn_conv_config_kind(int cfg) {
+  if (cfg < 1 || cfg > kNumConfigs) return -1;
+  const ConvConfig& c = kConfigs[cfg - 1];
+  if (c.dma != 5) return 0;
+  return (c.bi >> 4) ? -1 : 1;
+}
+
 // kernel symbol of a config as rocprofv3 prints it (lets bench.py line its
 // hipEvent timings up with the kernel-trace statistics)
 extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (cfg < 1 || cfg > kNumConfigs || !buf || len < 8) return EGN_E_BADARG;
   const ConvConfig& c = kConfigs[cfg - 1];
-  if (c.dma == 4 && c.bi == 2)
+  if (c.dma == 5)
+    snprintf(buf, len, "void conv_wino_kernel<%s, %d>(ConvArgs)", (c.bi & 15) == 1 ? "8, 8, 4" : "16, 16, 1", c.bi >> 4);
+  else if (c.dma == 4 && c.bi == 2)
     snprintf(buf, len, "conv_c48t_kernel(ConvArgs)");
   else if (c.dma == 4 && c.bi == 1)
     snprintf(buf, len, "conv_c48r_kernel(ConvArgs)");
@@ -114,6 +135,7 @@ static size_t lds_stage_bytes(const ConvArgs& a, const ConvConfig& cf) {
   return ((main_loop > epi ? main_loop : epi) + 15) & ~(size_t)15;
 }
 static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
+  if (cf.dma == 5) return egn_conv_wino_lds_bytes(cf.bi);
   if (cf.dma == 4 && cf.bi == 2) return (size_t)(3 * 336 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // chunk ring + filter
   if (cf.dma == 4) return (size_t)(2 * 3 * 192 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // 2 halo buffers + filter
   if (cf.dma == 3) return lds_stage_bytes(a, cf) + (size_t)4 * 16 * (cf.nt * 16 + 4) * 4;
@@ -124,6 +146,21 @@ static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
 // LDS fill work) over power-of-two tile shapes, subject to the LDS budget and
 // to the per-lane staging depth (ai / bi dwordx4 loads per stage).
 static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, double* cost_out) {
+  if (cf.dma == 5) {
+    // conv_wino.hip: 3x3 stride-1 pad-1 NHWC layers with unpadded channel strides, even maps
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % EGN_CK || a.cs_in != a.Cin ||
+        a.Cout % 48 || a.cs_out != a.Cout || a.out_nchw || (a.Ho & 1) || (a.Wo & 1))
+      return false;
+    if ((cf.bi & 15) == 1) { a.TH = 8; a.TW = 8; a.TNB = 4; }
+    else { a.TH = 16; a.TW = 16; a.TNB = 1; }
+    if ((cf.bi & 15) == 1 && (a.Ho > 8 || a.Wo > 8)) return false;   // the batched variant is for the 8 x 8 maps
+    a.HH = a.TH + 2; a.HW = a.TW + 2;
+    a.npix = a.TNB * a.HH * a.HW; a.npixp = (a.npix + 15) & ~15; a.tps = 16;
+    a.tiles_x = (a.Wo + a.TW - 1) / a.TW;
+    a.tiles_y = (a.Ho + a.TH - 1) / a.TH;
+    if (cost_out) *cost_out = 0.0;
+    return true;
+  }
   if (cf.dma == 4) {
     // conv_c48.hip: exactly the 48 -> 48 3x3 stride-1 pad-1 NHWC layers, fixed 8 x 16 tile
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin != 48 || a.cs_in != 48 || a.Cout != 48 ||
@@ -236,6 +273,7 @@ int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {
   if (cfg_id < 1 || cfg_id > kNumConfigs) return EGN_E_BADARG;
   const ConvConfig& cf = kConfigs[cfg_id - 1];
   const size_t lds = lds_bytes_for(a, cf);
+  if (cf.dma == 5) return egn_conv_launch_wino(a, lds, cf.bi, stream);
   if (cf.dma == 4) return egn_conv_launch_c48(a, lds, cf.bi == 2 ? -1 : cf.bi == 1 ? 0 : cf.wm, stream);
   if (cf.dma == 3) return egn_conv_launch_pers(a, (cfg_id - 1) % 10 + 1, lds, stream);
   return cf.dma ? egn_conv_launch_dma(a, (cfg_id - 1) % 10 + 1, lds, stream)

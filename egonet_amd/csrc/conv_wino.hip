@@ -1,0 +1,515 @@
+// conv_wino.hip -- 3x3 / stride 1 / pad 1 convolution (NHWC, fp32) as FUSED WINOGRAD F(2x2, 3x3)
+// on the fp32 matrix pipe.
+//
+// Why: HRNet's 3x3 s1 layers (hrnet.py:68-92 BasicBlock convs, 208 of the 306 conv launches, 89 % of
+// the forward's FLOPs) are bound by the fp32 FMA rate, not by HBM (AI 72..600 FLOP/B).  Against an
+// FMA roof the only lever left after tuning the direct kernels (conv_c48.hip: 74.5 % of peak) is to
+// issue fewer FMAs: Winograd's minimal filtering computes a 2x2 output patch from a 4x4 input patch
+// with 16 multiplies per (ci, co) instead of 36 -- 2.25x fewer MACs -- at the price of cheap +/-
+// transforms.  Unfused (transform kernels + batched GEMM) it would move 4x the activation bytes
+// through HBM and lose; here BOTH data transforms are lane-local register arithmetic around the same
+// LDS-halo / MFMA structure the direct kernels use, so HBM sees exactly the direct kernel's traffic:
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A          (Lavin & Gray, F(2x2,3x3))
+//
+//   * GEMM view per frequency f = (i,j) of the 4x4 transform domain:
+//         M_f[tile][co] = sum_ci V_f[tile][ci] * U_f[ci][co]
+//     M = 16 Winograd tiles (2x2 output pixels each) per wave, N = 48 output channels, K = Cin in
+//     chunks of 16.  v_mfma_f32_16x16x4_f32, the fragment mapping of the direct kernels: lane
+//     (li = l&15, kq = l>>4) supplies A[tile li][channels 4kq..4kq+3] and B[4kq..][co li], owns
+//     C[tiles 4kq+r][co li].
+//   * U = G g G^T is precomputed (host, float64 -> fp32) and packed like a 4x4-tap filter:
+//     [co-tile][chunk][f][quad][48][4] floats, so one (chunk, co-tile) slab is 48 KB contiguous and
+//     a lane's B fragment of (f, nt) is one ds_read_b128.
+//   * input transform in registers: a lane reads the 4x4 patch of ITS tile and ITS channel quad from
+//     the LDS halo (16 ds_read_b128), forms V = B^T d B with 128 adds and uses the 16 results
+//     directly as the A operands of the 16 frequencies.  Nothing transformed ever touches LDS.
+//   * all 16 frequencies of a (tile, co) accumulate in the SAME lane (192 accumulator registers per
+//     wave, one wave per SIMD owns the 512-entry file), so the output transform A^T M A is lane
+//     local too: 24 adds per 2x2 patch, then scale/shift (+residual) + activation and dword stores
+//     (16 lanes cover 64 contiguous bytes of a pixel, as in conv_c48.hip).
+//   * persistent blocks walk over (spatial tile, co-tile) items; a K step = one 16-channel chunk:
+//     halo chunk + U slab arrive by LDS-DMA in double-buffered stages, ONE barrier per step.
+//
+// Numerics: exact fp32 products, fp32 accumulation; the +/- transforms add a few ulp relative to
+// the direct sum (the filter transform is done in float64).  Not bit-identical to the direct
+// kernels -- the parity bar is the reference's (1e-3 px on key-points, arg-max indices exact).
+#include "conv_common.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_wino_t;
+
+namespace {
+constexpr int WN_CO = 48;                          // output channels per block (NT = 3)
+constexpr int WN_NT = 3;
+constexpr int WN_USLOTS = 16 * EGN_CKQ * WN_CO;    // float4 per (chunk, co-tile) slab of U: 3072 = 48 KB
+constexpr int WN_NTH = 256;
+constexpr int WN_UIT = WN_USLOTS / WN_NTH;         // 12 DMA instructions per lane and slab
+}  // namespace
+
+// Geometry of a block tile (64 Winograd tiles = 4 waves x 16) and the LDS image of its halo chunk.
+//
+// The halo lives in LDS as FOUR CHANNEL-QUAD PLANES  sH[quad][pixel slot]  (16 B per slot), not pixel
+// major: a patch read (one ds_read_b128 per lane) is served in 4 groups of 16 lanes, each group holding
+// all 16 tiles (li) of the wave with only two quad values, so it is conflict free exactly when the 16
+// tiles' pixel slots are distinct mod 16 (and the plane size is a multiple of 256 B).  Tiles step by TWO
+// pixels, so plain row-major slots collide; each geometry therefore skews its rows / images:
+//   <16,16,1>  tile li = (ty = li>>3, tx = li&7): slot = y*24 + ((y>>1)&1) + x.  The two tile rows of a
+//              wave are 2 pixel rows apart = 48 slots (= 0 mod 16) +- 1 from the skew: 2tx + {0,1}.
+//   <8,8,4>    wave = tile row, li = (image b = li>>2, tx = li&3): slot = b*112 + g(b) + y*10 + x with
+//              g = {0,1,8,9}: 2tx + g(b) covers 0..15.
+// (pixel-major slots measured 4-way conflicts: 16 instead of 4 LDS cycles per read, 16 % of a K step.)
+template <int TH, int TW, int TNB>
+struct WinoGeom;
+
+template <>
+struct WinoGeom<16, 16, 1> {
+  static constexpr int TH = 16, TW = 16, TNB = 1, HH = 18, HW = 18;
+  static constexpr int RP = 24, PLANE = 432;     // 18 rows x 24 slots; 6912 B = 27 x 256
+  static constexpr int ROFF = RP;                // slot step of one patch row
+  // DMA slot p of a plane -> halo pixel (b, hy, hx) or -1
+  static __device__ __forceinline__ int decode(int p) {
+    const int y = p / RP, x = p - y * RP - ((y >> 1) & 1);
+    return (y < HH && x >= 0 && x < HW) ? ((y << 8) | x) : -1;
+  }
+  // slot of the patch origin of tile li of wave w, for patch rows {0,1} (k = 0) / {2,3} (k = 1)
+  static __device__ __forceinline__ int patch_base(int w, int li, int k) {
+    const int tyl = li >> 3, tx = li & 7;
+    return (4 * w + 2 * tyl) * RP + 2 * tx + ((tyl + k) & 1);
+  }
+  // tile index (b << 16 | ty << 8 | tx) of MFMA result row m (0..15) of wave w
+  static __device__ __forceinline__ int out_tile(int w, int m) { return ((2 * w + (m >> 3)) << 8) | (m & 7); }
+};
+
+template <>
+struct WinoGeom<8, 8, 4> {
+  static constexpr int TH = 8, TW = 8, TNB = 4, HH = 10, HW = 10;
+  static constexpr int RP = 10, IMGP = 112, PLANE = 448;   // 7168 B = 28 x 256
+  static constexpr int ROFF = RP;
+  static __device__ __forceinline__ int skew(int b) { return (b & 1) + ((b & 2) << 2); }  // 0, 1, 8, 9
+  static __device__ __forceinline__ int decode(int p) {
+    const int b = p / IMGP, r = p - b * IMGP - skew(b);
+    const int y = r / RP, x = r - y * RP;
+    return (r >= 0 && r < HH * RP) ? ((b << 16) | (y << 8) | x) : -1;
+  }
+  static __device__ __forceinline__ int patch_base(int w, int li, int) {
+    const int b = li >> 2, tx = li & 3;
+    return b * IMGP + skew(b) + 2 * w * RP + 2 * tx;
+  }
+  static __device__ __forceinline__ int out_tile(int w, int m) { return ((m >> 2) << 16) | (w << 8) | (m & 3); }
+};
+
+template <int TH, int TW, int TNB>
+struct WinoDims {
+  using G = WinoGeom<TH, TW, TNB>;
+  static constexpr int SLOTS = EGN_CKQ * G::PLANE;
+  static constexpr int IT = (SLOTS + WN_NTH - 1) / WN_NTH;  // DMA instructions per lane and halo chunk
+  static constexpr int BUF = IT * WN_NTH;                   // every wave issues IT whole instructions
+  static_assert(G::PLANE % 16 == 0, "planes must start on a 256-byte boundary");
+  static_assert(TNB * (TH / 2) * (TW / 2) == 64, "4 waves x 16 Winograd tiles");
+};
+
+__device__ __forceinline__ void wino_dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "m0");
+}
+__device__ __forceinline__ unsigned wino_lds_addr(const void* p) {
+  return (unsigned)(__UINTPTR_TYPE__)(lds_ptr_wino_t) const_cast<void*>(p);
+}
+__device__ __forceinline__ float wino_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void wino_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+// ABL != 0 are timing ablations (wrong results by construction; cfg ids 47..50, tools/wino_probe.py only):
+//   bit 0 no DMA after the prologue, bit 1 no patch reads / input transform, bit 2 no residual loads /
+//   output stores, bit 3 no barrier / waitcnt at the step tops
+template <int TH, int TW, int TNB, int ABL = 0>
+__global__ __launch_bounds__(WN_NTH, 1) void conv_wino_kernel(ConvArgs a) {
+  using G = WinoGeom<TH, TW, TNB>;
+  using D = WinoDims<TH, TW, TNB>;
+  constexpr int IT = D::IT;
+  constexpr int NPIECE = IT + WN_UIT;  // DMA instructions per lane and K step
+  extern __shared__ float4 smem[];
+  float4* sU = smem;                  // [2][WN_USLOTS]   (f, quad, co) of one chunk and co-tile
+  float4* sH = smem + 2 * WN_USLOTS;  // [2][D::BUF]      quad planes of one halo chunk
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15;
+  const int kq = lane >> 4;
+
+  const int C = a.Cin;        // cs_in == Cin (planner)
+  const int Co = a.Cout;      // cs_out == Cout, multiple of 48
+  const int nct = Co / WN_CO;
+  const int nchunk = a.nchunk;
+
+  const unsigned long long xaddr = reinterpret_cast<unsigned long long>(a.x);
+  const unsigned long long uaddr = reinterpret_cast<unsigned long long>(a.w);
+  const u32x4 rxv = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu,
+                     (unsigned)((size_t)a.N * a.H * a.W * C * 4), 0x00020000u};
+  const u32x4 ruv = {(unsigned)uaddr, (unsigned)(uaddr >> 32) & 0xffffu,
+                     (unsigned)((size_t)nct * nchunk * WN_USLOTS * 16), 0x00020000u};
+  const unsigned out_bytes = (unsigned)((size_t)a.N * a.Ho * a.Wo * Co * 4);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, out_bytes, 0x00020000);
+
+  // halo slot e = it*256 + tid -> (quad plane, pixel slot) -> (image b, hy, hx); item independent
+  int hmeta[IT];  // b << 16 | hy << 8 | hx, -1 = pad slot;  the quad is e / PLANE
+  unsigned hq[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int e = it * WN_NTH + tid;
+    const int q = e / G::PLANE;
+    hmeta[it] = q < EGN_CKQ ? G::decode(e - q * G::PLANE) : -1;
+    hq[it] = (unsigned)q * 16u;
+  }
+
+  // this lane's patch origin (float4 index in a halo buffer) for patch rows {0,1} and {2,3}
+  const int pb01 = kq * G::PLANE + G::patch_base(wave, li, 0);
+  const int pb23 = kq * G::PLANE + G::patch_base(wave, li, 1);
+  // the 4 tiles whose results it owns (rows 4kq + r of the MFMA tile): b << 16 | ty << 8 | tx
+  int og[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) og[r] = G::out_tile(wave, 4 * kq + r);
+
+  const int tiles_xy = a.tiles_x * a.tiles_y;
+  const int ntile = tiles_xy * ((a.N + TNB - 1) / TNB);
+  const int nwork = ((ntile + 7) >> 3) * nct * 8;  // work index space, see WINO_ITEM
+
+// work index w -> (spatial tile, co-tile).  Blocks w, w+8, w+16 ... run on one XCD (block b -> XCD
+// b % 8): the co-tiles of ONE spatial tile are consecutive slots of one XCD, so the halo they all read
+// is fetched into that XCD's L2 once.
+#define WINO_ITEM(Wi, TILE_, CT_)            \
+  {                                          \
+    const int x_ = (Wi)&7, q_ = (Wi) >> 3;   \
+    TILE_ = (q_ / nct) * 8 + x_;             \
+    CT_ = q_ - (q_ / nct) * nct;             \
+  }
+// halo DMA byte offsets (chunk 0) of a spatial tile; out-of-image and pad slots get the OOB offset
+// and are written as zeros by the same DMA (= the convolution's zero padding)
+#define WINO_DOFF(TILE_, OUT)                                                                       \
+  {                                                                                                 \
+    const int tb_ = (TILE_) / tiles_xy;                                                             \
+    const int r_ = (TILE_)-tb_ * tiles_xy;                                                          \
+    const int ty_ = r_ / a.tiles_x, tx_ = r_ - ty_ * a.tiles_x;                                     \
+    const int n0_ = tb_ * TNB, iy0_ = ty_ * TH - 1, ix0_ = tx_ * TW - 1;                            \
+    _Pragma("unroll") for (int it = 0; it < IT; ++it) {                                             \
+      const int m_ = hmeta[it];                                                                     \
+      const int n_ = n0_ + (m_ >> 16), iy_ = iy0_ + ((m_ >> 8) & 255), ix_ = ix0_ + (m_ & 255);     \
+      const bool in_ = m_ >= 0 && (TILE_) < ntile && n_ < a.N && iy_ >= 0 && iy_ < a.H && ix_ >= 0 && ix_ < a.W; \
+      OUT[it] = in_ ? (unsigned)(((n_ * a.H + iy_) * a.W + ix_) * C) * 4u + hq[it] : EGN_OOB;       \
+    }                                                                                               \
+  }
+// DMA instruction K (0 .. NPIECE-1) of a K step: halo chunk CH of the tile with offsets OFF (K < IT),
+// then the U slab (CT, CH), into stage buffer P
+#define WINO_PIECE(K, P, OFF, CT, CH)                                                                \
+  {                                                                                                  \
+    if ((K) < IT) {                                                                                  \
+      wino_dma16(rxv, wino_lds_addr(sH + (P)*D::BUF + wave * 64) + (K)*WN_NTH * 16, OFF[(K) < IT ? (K) : 0], \
+                 (unsigned)(CH)*64u);                                                                \
+    } else {                                                                                         \
+      wino_dma16(ruv, wino_lds_addr(sU + (P)*WN_USLOTS + wave * 64) + ((K)-IT) * WN_NTH * 16, (unsigned)tid * 16u, \
+                 (unsigned)(((CT)*nchunk + (CH)) * WN_USLOTS) * 16u + ((K)-IT) * WN_NTH * 16);       \
+    }                                                                                                \
+  }
+#define WINO_ISSUE(P, OFF, CT, CH) \
+  { _Pragma("unroll") for (int k_ = 0; k_ < NPIECE; ++k_) WINO_PIECE(k_, P, OFF, CT, CH) }
+
+  int w = blockIdx.x;
+  int tile = 0, ct = 0;
+  WINO_ITEM(w, tile, ct)
+  unsigned doff[IT];
+  WINO_DOFF(tile, doff)
+  if (w < nwork) WINO_ISSUE(0, doff, ct, 0)
+  int par = 0;
+  bool first = true;
+
+  // activation: none or ReLU (all the 3x3 s1 layers of the network), branch-free as max(v, lo)
+  const float act_lo = (a.act & EGN_ACT_MASK) == EGN_ACT_RELU ? 0.f : -__builtin_inff();
+  const bool has_res = a.res != nullptr;
+  const unsigned rowpitch = (unsigned)(a.Wo * Co) * 4u, colpitch = (unsigned)Co * 4u;
+
+  for (; w < nwork; w += gridDim.x) {
+    // next item (its first stage is prefetched during this item's last K step) and this item's outputs
+    int tile_n = 0, ct_n = 0;
+    WINO_ITEM(w + (int)gridDim.x, tile_n, ct_n)
+    const bool more = (w + (int)gridDim.x) < nwork;
+    unsigned doff_n[IT];
+    WINO_DOFF(tile_n, doff_n)
+    unsigned voff[4];
+    {
+      const int tb_ = tile / tiles_xy;
+      const int r_ = tile - tb_ * tiles_xy;
+      const int ty_ = r_ / a.tiles_x, tx_ = r_ - ty_ * a.tiles_x;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = tb_ * TNB + (og[r] >> 16);
+        const int oy = ty_ * TH + 2 * ((og[r] >> 8) & 255), ox = tx_ * TW + 2 * (og[r] & 255);
+        voff[r] = (tile < ntile && n < a.N && oy < a.Ho && ox < a.Wo)
+                      ? (unsigned)(((n * a.Ho + oy) * a.Wo + ox) * Co + ct * WN_CO + li) * 4u
+                      : EGN_OOB;
+      }
+    }
+    float sc[WN_NT], sh[WN_NT];
+#pragma unroll
+    for (int nt = 0; nt < WN_NT; ++nt) {
+      sc[nt] = a.scale[ct * WN_CO + nt * 16 + li];
+      sh[nt] = a.shift[ct * WN_CO + nt * 16 + li];
+    }
+
+    f32x4 acc[16][WN_NT];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+      for (int nt = 0; nt < WN_NT; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rv[4][2][2][WN_NT];  // residual of this lane's outputs: [tile r][a][b][nt]
+
+    for (int c = 0; c < nchunk; ++c) {
+      const bool last = c + 1 == nchunk;
+      // stage `par` (halo chunk c + U slab) must have landed in every wave's share; the only younger
+      // vector-memory operations are the 48 stores of the previous item's epilogue (they may stay in flight)
+      asm volatile("" ::: "memory");
+      if constexpr (!(ABL & 8)) {
+        if (c == 0 && !first) __builtin_amdgcn_s_waitcnt(0xC070);  // vmcnt(48) expcnt(7) lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0x0070);                   // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+      }
+      asm volatile("" ::: "memory");
+      first = false;
+      // the next stage: (this item, chunk c+1) or (next item, chunk 0); its NPIECE DMA instructions are
+      // issued one by one between the frequency groups below (a burst of 19 at the top cost 14 % of a step)
+      const bool nx_issue = !(ABL & 1) && (!last || more);
+      const int nx_ct = last ? ct_n : ct, nx_ch = last ? 0 : c + 1;
+      unsigned nxo[IT];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) nxo[it] = last ? doff_n[it] : doff[it];
+#define WINO_NEXT(K)                                     \
+  {                                                      \
+    __builtin_amdgcn_sched_barrier(0x0106);              \
+    if (nx_issue) WINO_PIECE(K, par ^ 1, nxo, nx_ct, nx_ch) \
+    __builtin_amdgcn_sched_barrier(0x0106);              \
+  }
+      WINO_NEXT(0) WINO_NEXT(1) WINO_NEXT(2)
+      static_assert(NPIECE <= 19, "3 DMA pieces at the top + one per frequency");
+      if (last) {
+        // the vmcnt(48) above counts on program order DMA -> residual loads -> stores: the loads go
+        // after the LAST piece (end of this step); here only the offsets are prepared
+      }
+
+      // ---- input transform V = B^T d B of this lane's (tile, channel quad), row by row ----
+      const float4* hb01 = sH + par * D::BUF + pb01;
+      const float4* hb23 = sH + par * D::BUF + pb23;
+      f32x4 d[4][4], t[4][4], V[16];
+#define WINO_LOADROW(R)                                                                                   \
+  _Pragma("unroll") for (int cc = 0; cc < 4; ++cc) {                                                      \
+    if constexpr ((ABL & 2)) d[R][cc] = f32x4{(float)lane, (float)((R) + c), (float)cc, 1.f};              \
+    else d[R][cc] = *reinterpret_cast<const f32x4*>(&((R) < 2 ? hb01 : hb23)[(R)*G::ROFF + cc]);          \
+  }
+#define WINO_VROW(I)                          \
+  {                                           \
+    V[(I)*4 + 0] = t[I][0] - t[I][2];         \
+    V[(I)*4 + 1] = t[I][1] + t[I][2];         \
+    V[(I)*4 + 2] = t[I][2] - t[I][1];         \
+    V[(I)*4 + 3] = t[I][1] - t[I][3];         \
+  }
+      WINO_LOADROW(0) WINO_LOADROW(2)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) t[0][cc] = d[0][cc] - d[2][cc];
+      WINO_VROW(0)
+      WINO_LOADROW(1)
+      WINO_LOADROW(3)
+
+      // ---- 16 frequencies x 3 co sub-tiles x 4 k-steps ----
+      const float4* ub = sU + par * WN_USLOTS + kq * WN_CO + li;
+      f32x4 bf[2][WN_NT];
+#pragma unroll
+      for (int nt = 0; nt < WN_NT; ++nt) bf[0][nt] = *reinterpret_cast<const f32x4*>(&ub[nt * 16]);
+#pragma unroll
+      for (int f = 0; f < 16; ++f) {
+        if (f + 1 < 16) {
+#pragma unroll
+          for (int nt = 0; nt < WN_NT; ++nt)
+            bf[(f + 1) & 1][nt] = *reinterpret_cast<const f32x4*>(&ub[(f + 1) * EGN_CKQ * WN_CO + nt * 16]);
+        }
+        // the next frequency row's V: in source order here so that its adds land between the MFMAs
+        if (f == 0) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            t[1][cc] = d[1][cc] + d[2][cc];
+            t[2][cc] = d[2][cc] - d[1][cc];
+          }
+          WINO_VROW(1)
+        } else if (f == 4) {
+          WINO_VROW(2)
+        } else if (f == 8) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) t[3][cc] = d[1][cc] - d[3][cc];
+          WINO_VROW(3)
+        }
+        // k-step outermost: consecutive MFMAs hit different accumulators (40-cycle dependent latency
+        // vs 32-cycle issue -- one wave per SIMD has no partner to fill the bubble)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int nt = 0; nt < WN_NT; ++nt)
+            acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[f][s], bf[f & 1][nt][s], acc[f][nt], 0, 0, 0);
+        if (3 + f < NPIECE) WINO_NEXT(3 + f)
+      }
+#undef WINO_NEXT
+#undef WINO_LOADROW
+#undef WINO_VROW
+      if (last) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) doff[it] = doff_n[it];
+        // pin the program order DMA -> residual loads (the asm has no memory clobber)
+        asm volatile("" ::: "memory");
+        // residual values (without a residual: OOB offsets, zeros, same instruction stream)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned ro = (has_res && !(ABL & 4)) ? voff[r] : EGN_OOB;
+#pragma unroll
+          for (int pa = 0; pa < 2; ++pa)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+              for (int nt = 0; nt < WN_NT; ++nt)
+                rv[r][pa][pb][nt] = wino_load4(rr, ro, pa * rowpitch + pb * colpitch + nt * 64u);
+        }
+      }
+      par ^= 1;
+    }
+
+    // ---- output transform Y = A^T M A, epilogue, stores ----
+#pragma unroll
+    for (int nt = 0; nt < WN_NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float tt[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float m0 = acc[i * 4 + 0][nt][r], m1 = acc[i * 4 + 1][nt][r];
+          const float m2 = acc[i * 4 + 2][nt][r], m3 = acc[i * 4 + 3][nt][r];
+          tt[i][0] = m0 + m1 + m2;
+          tt[i][1] = m1 - m2 - m3;
+        }
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          const float y0 = tt[0][pb] + tt[1][pb] + tt[2][pb];
+          const float y1 = tt[1][pb] - tt[2][pb] - tt[3][pb];
+#pragma unroll
+          for (int pa = 0; pa < 2; ++pa) {
+            float v = (pa == 0 ? y0 : y1) * sc[nt] + sh[nt] + rv[r][pa][pb][nt];
+            v = fmaxf(v, act_lo);
+            wino_store4(ry, ((ABL & 4) && v != 12345.678f) ? EGN_OOB : voff[r], pa * rowpitch + pb * colpitch + nt * 64u, v);
+          }
+        }
+      }
+    tile = tile_n;
+    ct = ct_n;
+  }
+#undef WINO_ITEM
+#undef WINO_DOFF
+#undef WINO_PIECE
+#undef WINO_ISSUE
+}
+
+template <int TH, int TW, int TNB, int ABL = 0>
+static int wino_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
+  static bool raised[EGN_MAX_DEVICES];
+  static int cus = 0;
+  if (egn_first_use_on_device(raised)) {
+    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_kernel<TH, TW, TNB, ABL>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+  }
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+    cus &= ~7;  // whole XCD rounds
+    if (cus <= 0) cus = 8;
+  }
+  const int ntile = a.tiles_x * a.tiles_y * ((a.N + TNB - 1) / TNB);
+  const int nwork = ((ntile + 7) / 8) * 8 * (a.Cout / WN_CO);
+  const int grid = nwork < cus ? nwork : cus;
+  hipLaunchKernelGGL((conv_wino_kernel<TH, TW, TNB, ABL>), dim3(grid), dim3(WN_NTH), lds, stream, a);
+  return (int)hipGetLastError();
+}
+
+// variant 0: 16 x 16 pixel tile of one image; variant 1: four 8 x 8 images (the 8 x 8 maps)
+size_t egn_conv_wino_lds_bytes(int variant) {
+  const size_t halo = (variant & 15) == 1 ? WinoDims<8, 8, 4>::BUF : WinoDims<16, 16, 1>::BUF;
+  return (2 * (size_t)WN_USLOTS + 2 * halo) * 16;
+}
+int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t stream) {
+  const int act = a.act & EGN_ACT_MASK;
+  if ((act != EGN_ACT_NONE && act != EGN_ACT_RELU) || (a.act & EGN_ACT_RES_AFTER)) return EGN_E_BADARG;
+  switch (variant) {
+    case 1: return wino_launch<8, 8, 4>(a, lds, stream);
+    case 0x10: return wino_launch<16, 16, 1, 15>(a, lds, stream);
+    case 0x20: return wino_launch<16, 16, 1, 7>(a, lds, stream);
+    case 0x30: return wino_launch<16, 16, 1, 3>(a, lds, stream);
+    case 0x40: return wino_launch<16, 16, 1, 11>(a, lds, stream);
+    default: return wino_launch<16, 16, 1>(a, lds, stream);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Filter transform on the device: torch weight [Cout][Cin][3][3] -> U = G g G^T in the packed layout
+// above ([co-tile][chunk][f][quad][48][4]).  float64 arithmetic, one rounding to fp32.  dgrad = 1 packs
+// the data-gradient filter (in/out channels swapped, taps rotated by 180 degrees) like
+// egn_pack_conv_weight_f32.  One thread per (co, ci): 9 loads, 16 stores.
+__global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin,
+                                                               int dgrad, float* __restrict__ dst) {
+  const int n_out = dgrad ? Cin : Cout, n_in = dgrad ? Cout : Cin;
+  const int nchunk = n_in / EGN_CK;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_out * n_in; e += gridDim.x * blockDim.x) {
+    const int o = e / n_in, i = e - o * n_in;
+    double g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        g[a][b] = dgrad ? (double)w[((size_t)i * Cin + o) * 9 + (2 - a) * 3 + (2 - b)]
+                        : (double)w[((size_t)o * Cin + i) * 9 + a * 3 + b];
+    double t[4][3];  // G g
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      t[0][b] = g[0][b];
+      t[1][b] = 0.5 * (g[0][b] + g[1][b] + g[2][b]);
+      t[2][b] = 0.5 * (g[0][b] - g[1][b] + g[2][b]);
+      t[3][b] = g[2][b];
+    }
+    const int ct = o / WN_CO, col = o - ct * WN_CO;
+    const int chunk = i / EGN_CK, q = (i % EGN_CK) >> 2, r = i & 3;
+    float* base = dst + ((size_t)(ct * nchunk + chunk) * WN_USLOTS) * 4 + ((size_t)q * WN_CO + col) * 4 + r;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const double u0 = t[a][0], u1 = 0.5 * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5 * (t[a][0] - t[a][1] + t[a][2]),
+                   u3 = t[a][2];
+      const double u[4] = {u0, u1, u2, u3};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) base[(size_t)(a * 4 + b) * EGN_CKQ * WN_CO * 4] = (float)u[b];
+    }
+  }
+}
+
+extern "C" long egn_wino_weight_floats(int Cout, int Cin, int dgrad) {
+  const int n_out = dgrad ? Cin : Cout, n_in = dgrad ? Cout : Cin;
+  if (n_out <= 0 || n_in <= 0 || n_out % WN_CO || n_in % EGN_CK) return 0;
+  return (long)n_out * n_in * 16;
+}
+extern "C" int egn_wino_pack_weight_f32(const float* w, int Cout, int Cin, int dgrad, float* dst, void* stream) {
+  if (!w || !dst || egn_wino_weight_floats(Cout, Cin, dgrad) == 0) return EGN_E_BADARG;
+  const long total = (long)Cout * Cin;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(wino_pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, dgrad, dst);
+  return (int)hipGetLastError();
+}

@@ -52,6 +52,24 @@ def pack_conv_weight(w):
     return wp.reshape(-1)
 
 
+WINO_CFGS = (45, 46)     # conv_wino.hip tile configs (csrc/conv_plan.hip)
+WINO_CO = 48
+
+
+def pack_wino_weight(w):
+    """[Cout,Cin,3,3] -> the Winograd F(2x2,3x3) filter U = G g G^T (float64, rounded once to
+    fp32) in the layout conv_wino.hip stages through LDS:
+    flat fp32 [co-tile = Cout/48][chunk = Cin/16][f = 4i+j][quad][48][4]
+    (ci = chunk*16 + quad*4 + r), one 48 KB slab per (co-tile, chunk)."""
+    w = w.detach().to(torch.float64).cpu()
+    cout, cin, kh, kw = w.shape
+    assert (kh, kw) == (3, 3) and cout % WINO_CO == 0 and cin % CK == 0, w.shape
+    G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]], dtype=torch.float64)
+    u = torch.einsum('ia,ocab,jb->ocij', G, w, G).to(torch.float32)        # [Cout,Cin,4,4]
+    u = u.reshape(cout // WINO_CO, WINO_CO, cin // CK, CK // 4, 4, 16)     # ct, co, chunk, quad, r, f
+    return u.permute(0, 2, 5, 3, 1, 4).contiguous().reshape(-1)
+
+
 def fold_scale_shift(cout, bias=None, bn=None):
     """Per-channel (scale, shift) so that  bn(conv(x) + bias) == conv(x)*scale + shift,
     eval-mode BatchNorm (running stats).  Computed in float64, stored fp32,
@@ -166,7 +184,9 @@ class _Recorder(object):
                 dst.cs = cout_cs
                 dst.nbytes = x.n * ho * wo * cout_cs * 4
         scale, shift = fold_scale_shift(cout, bias, bn)
-        op = dict(x=x, w=self.weight(pack_conv_weight(weight)), scale=self.weight(scale),
+        # the filter is packed when the program is built: the layout depends on the tile
+        # configuration the tuner picks for the shape (direct vs Winograd kernels)
+        op = dict(x=x, w=None, w_src=weight, scale=self.weight(scale),
                   shift=self.weight(shift), res=res, y=dst, cin=cin, cout=cout, kh=kh, kw=kw,
                   stride=stride, pad=pad, act=act, out_nchw=int(out_nchw), ho=ho, wo=wo, tag=tag)
         self._touch(x, res, dst)
@@ -259,7 +279,14 @@ class _Recorder(object):
             active.append(b)
         return top
 
+    def pack_pending(self):
+        """Filters no tile configuration was chosen for get the direct layout."""
+        for kind, op in self.ops:
+            if kind == 'conv' and op.get('w') is None:
+                op['w'] = self.weight(pack_conv_weight(op['w_src']))
+
     def weights_blob(self, device):
+        self.pack_pending()
         blob = torch.zeros(max(self.blob_off, 256) // 4, dtype=torch.float32)
         off = 0
         for t in self.blobs:
@@ -277,6 +304,7 @@ class Program(object):
         self.device = device
         arena_bytes = rec.plan_arena()
         self.arena = torch.zeros(max(arena_bytes, 256) // 4, dtype=torch.float32, device=device)
+        self._choose_and_pack(rec, device)
         self.weights = rec.weights_blob(device)
         self.handle = C.c_void_p(L.egn_program_create(SLOT_USER0 + n_user_slots))
         if not self.handle:
@@ -290,6 +318,27 @@ class Program(object):
         for kind, op in rec.ops:
             self._emit(kind, op)
 
+    @staticmethod
+    def _conv_key(op):
+        x, y = op['x'], op['y']
+        cs_out = y.cs if not op['out_nchw'] else op['cout']
+        return (x.n, x.h, x.w, op['cin'], x.cs, op['cout'], cs_out, op['kh'], op['kw'], op['stride'],
+                op['pad'], op['res'] is not None, bool(op['out_nchw']))
+
+    def _choose_and_pack(self, rec, device):
+        """Tile configuration per conv (measured table / autotune) and the filter in the layout
+        that configuration's kernel stages through LDS."""
+        from . import tuner
+        L = self.lib
+        for kind, op in rec.ops:
+            if kind != 'conv' or op.get('w') is not None:
+                continue
+            if 'cfg' not in op:
+                plain_act = (op['act'] & 0xf) in (ACT_NONE, ACT_RELU) and not (op['act'] & ACT_RES_AFTER)
+                op['cfg'] = tuner.choose(device, self._conv_key(op), allow_wino=plain_act)
+            wino = op['cfg'] > 0 and L.egn_conv_config_kind(op['cfg']) == 1
+            op['w'] = rec.weight(pack_wino_weight(op['w_src']) if wino else pack_conv_weight(op['w_src']))
+
     def _emit(self, kind, op):
         L, h = self.lib, self.handle
         flops, nbytes = 0.0, 0.0
@@ -302,11 +351,6 @@ class Program(object):
             x, y = op['x'], op['y']
             res = op['res'].ref() if op['res'] is not None else NULL_REF
             cs_out = y.cs if not op['out_nchw'] else op['cout']
-            if 'cfg' not in op:
-                from . import tuner
-                op['cfg'] = tuner.choose(self.device, (
-                    x.n, x.h, x.w, op['cin'], x.cs, op['cout'], cs_out, op['kh'], op['kw'], op['stride'],
-                    op['pad'], op['res'] is not None, bool(op['out_nchw'])))
             _lib.check(L.egn_program_add_conv2d(
                 h, x.ref(), op['w'], op['scale'], op['shift'], res, y.ref(),
                 x.n, x.h, x.w, op['cin'], x.cs, op['cout'], cs_out, op['kh'], op['kw'],

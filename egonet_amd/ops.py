@@ -54,9 +54,22 @@ def fill_coord_ramps(y, c0):
 class PackedConv(object):
     """Device-resident packed weights + folded scale/shift of one conv layer."""
 
-    def __init__(self, weight, bias=None, bn=None, device='cuda'):
+    def __init__(self, weight, bias=None, bn=None, device='cuda', wino=False):
+        """``wino``: pack for the fused Winograd kernels (config kind 1) ON THE DEVICE
+        (egn_wino_pack_weight_f32) instead of the direct layout."""
         self.cout, self.cin, self.kh, self.kw = weight.shape
-        self.w = pack_conv_weight(weight).to(device)
+        if wino:
+            L = _lib.lib()
+            nfl = L.egn_wino_weight_floats(self.cout, self.cin, 0)
+            if nfl == 0 or (self.kh, self.kw) != (3, 3):
+                raise ValueError('no Winograd packing for a %s filter' % (tuple(weight.shape),))
+            wd = weight.detach().to(device=device, dtype=torch.float32).contiguous()
+            self.w = torch.empty(nfl, dtype=torch.float32, device=device)
+            with torch.cuda.device(self.w.device):
+                _lib.check(L.egn_wino_pack_weight_f32(_lib.ptr(wd), self.cout, self.cin, 0, _lib.ptr(self.w),
+                                                      _lib.current_stream(self.w.device)), 'wino_pack')
+        else:
+            self.w = pack_conv_weight(weight).to(device)
         s, b = fold_scale_shift(self.cout, bias, bn)
         self.scale, self.shift = s.to(device), b.to(device)
 

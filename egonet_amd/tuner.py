@@ -81,7 +81,9 @@ def tune(device, args):
     g = torch.Generator(device='cpu').manual_seed(1)
     with torch.cuda.device(device):
         x = torch.randn(n * h * wd * cs_in, device=device)
-        w = torch.randn(nchunk * kh * kw * 4 * coutp * 4, device=device) * 0.05
+        # one buffer serves both packings (random data: only the timing matters); the Winograd
+        # kernels read 16 floats per (co, ci)
+        w = torch.randn(max(nchunk * kh * kw * 4 * coutp * 4, cout * cin * 16), device=device) * 0.05
         sc = torch.ones(coutp, device=device)
         sh = torch.zeros(coutp, device=device)
         ny = n * ho * wo * (cout if out_nchw else cs_out)
@@ -90,6 +92,8 @@ def tune(device, args):
         stream = _lib.current_stream(device)
         times = {}
         for cfg in range(1, L.egn_conv_num_configs() + 1):
+            if L.egn_conv_config_kind(cfg) < 0:      # timing-ablation builds
+                continue
             out = (C.c_int * 12)()
             if L.egn_conv_plan_query(n, h, wd, cin, cs_in, cout, cs_out, kh, kw, stride, pad,
                                      int(out_nchw), cfg, out) != 0:
@@ -104,18 +108,53 @@ def tune(device, args):
     return min(times, key=times.get), times
 
 
-def choose(device, args):
+def _pick(entry, allow_wino):
+    """Fastest measured configuration of a table entry; without ``allow_wino`` the fastest
+    DIRECT one (callers that hand the kernel a direct-packed filter: the training tape,
+    activations the Winograd epilogue does not implement)."""
+    cfg = int(entry['cfg'])
+    if allow_wino or cfg <= 0 or _lib.lib().egn_conv_config_kind(cfg) == 0:
+        return cfg
+    L = _lib.lib()
+    direct = {int(k): v for k, v in entry.get('ms', {}).items() if L.egn_conv_config_kind(int(k)) == 0}
+    return min(direct, key=direct.get) if direct else 0
+
+
+def _forced_wino(args):
+    """EGONET_AMD_WINO=1: the Winograd configuration for every shape one plans for (parity tests pin
+    both kernel families on the same fixtures); returns 0 if none does."""
+    n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, has_res, out_nchw = args
+    L = _lib.lib()
+    out = (C.c_int * 12)()
+    for cfg in range(L.egn_conv_num_configs(), 0, -1):
+        if L.egn_conv_config_kind(cfg) == 1 and L.egn_conv_plan_query(
+                n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, int(out_nchw), cfg, out) == 0:
+            return cfg
+    return 0
+
+
+def choose(device, args, allow_wino=False):
+    """``allow_wino``: the caller packs the filter for whatever configuration comes back
+    (egn_conv_config_kind).  EGONET_AMD_WINO=0 never returns a Winograd configuration, =1 always
+    does where one plans; default: whichever measured fastest."""
+    mode = os.environ.get('EGONET_AMD_WINO', '')
+    if mode == '0':
+        allow_wino = False
+    elif mode == '1' and allow_wino:
+        cfg = _forced_wino(args)
+        if cfg:
+            return cfg
     key = shape_key(*args)
     tab = _load()
     if key in tab:
-        return int(tab[key]['cfg'])
+        return _pick(tab[key], allow_wino)
     if key in _tuned_here:
-        return _tuned_here[key]['cfg']
+        return _pick(_tuned_here[key], allow_wino)
     if not autotune_enabled():
         return 0
     cfg, times = tune(device, args)
     _tuned_here[key] = {'cfg': cfg, 'ms': {str(k): round(v, 5) for k, v in times.items()}}
-    return cfg
+    return _pick(_tuned_here[key], allow_wino)
 
 
 def tuned_in_process():

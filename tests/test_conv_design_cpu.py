@@ -110,7 +110,7 @@ def test_filter_resident_configs_plan_only_the_48_channel_3x3_layers():
     48-channel halo buffers (2 x 36 864 B) in LDS, refused for every other layer.  43 = four
     waves that copy the whole filter into registers."""
     L = _lib.lib()
-    assert L.egn_conv_num_configs() == 44
+    assert L.egn_conv_num_configs() >= 44
     for cfg, waves in ((41, 4), (42, 8), (43, 4)):
         plan = _plan((64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0), cfg=cfg)
         cfg_id, wm, wn, mt, nt, th, tw, tnb, tps, lds = plan[:10]
@@ -144,3 +144,49 @@ def test_tall_tile_filter_resident_config():
     out = (C.c_int * 12)()
     assert L.egn_conv_plan_query(64, 64, 64, 48, 48, 96, 96, 3, 3, 1, 1, 0, 44, out) != 0
     assert _plan((3, 19, 13, 48, 48, 48, 48, 3, 3, 1, 1, 0), cfg=44)[5:8] == [16, 16, 1]
+
+
+def test_winograd_configs_plan_and_kinds():
+    """Configs 45 / 46 (csrc/conv_wino.hip): fused Winograd F(2x2,3x3).  Fixed tiles (16 x 16 of one
+    image / four 8 x 8 images), two U slabs (2 x 49 152 B) + two quad-plane halo buffers in LDS."""
+    L = _lib.lib()
+    assert [L.egn_conv_config_kind(c) for c in (0, 1, 44, 45, 46, 47, 999)] == [-1, 0, 0, 1, 1, -1, -1]
+    for cfg, shape, tile in ((45, (64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0), [16, 16, 1]),
+                             (45, (64, 16, 16, 192, 192, 192, 192, 3, 3, 1, 1, 0), [16, 16, 1]),
+                             (46, (64, 8, 8, 384, 384, 384, 384, 3, 3, 1, 1, 0), [8, 8, 4])):
+        plan = _plan(shape, cfg=cfg)
+        assert plan[0] == cfg and plan[5:8] == tile
+        assert plan[9] == 2 * 49152 + 2 * 1792 * 16 and plan[9] <= 160 * 1024 - 512
+        assert plan[11] == shape[5] // 48                       # co-tiles
+    out = (C.c_int * 12)()
+    for bad in ((64, 64, 64, 48, 48, 48, 48, 3, 3, 2, 1, 0),          # stride 2
+                (64, 64, 64, 48, 48, 48, 48, 1, 1, 1, 0, 0),          # 1x1
+                (64, 64, 64, 35, 36, 48, 48, 3, 3, 1, 1, 0),          # padded / odd input channels
+                (64, 64, 64, 48, 48, 64, 64, 3, 3, 1, 1, 0),          # Cout % 48
+                (64, 63, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0),          # odd map
+                (64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 1)):         # NCHW output
+        assert L.egn_conv_plan_query(*bad, 45, out) != 0
+    assert L.egn_conv_plan_query(64, 16, 16, 192, 192, 192, 192, 3, 3, 1, 1, 0, 46, out) != 0   # 46: 8x8 maps only
+    name = C.create_string_buffer(96)
+    assert L.egn_conv_config_name(45, name, 96) == 0 and name.value == b'void conv_wino_kernel<16, 16, 1, 0>(ConvArgs)'
+    assert L.egn_wino_weight_floats(96, 48, 0) == 96 * 48 * 16 and L.egn_wino_weight_floats(40, 48, 0) == 0
+
+
+def test_winograd_halo_layout_is_bank_conflict_free():
+    """The quad-plane LDS image with skewed rows / images: all 16 lanes of every ds_read_b128 lane
+    group of a patch read hit distinct 16-byte columns (the pixel-major image of the direct kernels
+    would put 4 of them on one)."""
+    import wino_emulator
+    assert wino_emulator.worst_bank_conflict(16, 16, 1) == 1
+    assert wino_emulator.worst_bank_conflict(8, 8, 4) == 1
+
+
+def test_winograd_kernel_design_vs_torch():
+    """Lane-level emulation of conv_wino.hip (tests/wino_emulator.py) on the product code's filter
+    packing: work-item map, halo slots incl. zero padding, fragment mapping, both transforms and the
+    epilogue addressing reproduce torch's conv2d (+scale/shift, residual, ReLU); every output is
+    written exactly once."""
+    import wino_emulator
+    assert wino_emulator.conv_case(1, 16, 16, 16, 48, 16, 16, 1) < 2e-5
+    assert wino_emulator.conv_case(1, 24, 8, 32, 96, 16, 16, 1, seed=1) < 2e-5     # partial tiles, 2 co-tiles
+    assert wino_emulator.conv_case(5, 8, 8, 16, 48, 8, 8, 4, seed=2) < 2e-5        # partial image batch

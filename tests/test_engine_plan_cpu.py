@@ -80,7 +80,8 @@ def test_lifter_program_and_weight_blob():
     assert [(c['cin'], c['cout']) for c in convs] == [(66, 1024)] + [(1024, 1024)] * 4 + [(1024, 96)]
     assert convs[2]['act'] == (engine.ACT_RELU | engine.ACT_RES_AFTER) and convs[2]['res'] is not None
     blob = rec.weights_blob('cpu')
-    # first packed weight: [nchunk=5][1][4][1024][4], chunk 0 / quad 0 / co 3 = w1.weight[3, 0:4]
-    w = blob[:5 * 4 * 1024 * 4].view(5, 1, 4, 1024, 4)
+    # w1's packed weight: [nchunk=5][1][4][1024][4], chunk 0 / quad 0 / co 3 = w1.weight[3, 0:4]
+    o = convs[0]['w'].off // 4
+    w = blob[o:o + 5 * 4 * 1024 * 4].view(5, 1, 4, 1024, 4)
     assert torch.equal(w[0, 0, 0, 3], net.w1.weight[3, 0:4].detach())
     assert float(w[4, 0, 0, :, 2:].abs().sum()) == 0.0      # input channels 66, 67 are padding

@@ -42,7 +42,8 @@ def _conv_case(n, h, w, cin, cout, k, s, p, act=1, use_res=False, nchw=False, cf
         ref = f(ref)
         if res is not None and (act & 0x10):
             ref = res + ref
-    pc = ops.PackedConv(wt, b, bn)
+    from egonet_amd import _lib
+    pc = ops.PackedConv(wt, b, bn, wino=(cfg > 0 and _lib.lib().egn_conv_config_kind(cfg) == 1))
     xd = ops.nchw_to_nhwc(x.cuda())
     rd = ops.nchw_to_nhwc(res.cuda()) if res is not None else None
     y = ops.conv2d_nhwc(xd, pc, cin, s, p, act, rd, out_nchw=nchw, cfg=cfg)
@@ -105,6 +106,62 @@ def test_conv_every_tile_config(cfg):
         assert err < 2e-4, (cfg, err)
     else:
         assert (cfg - 1) % 10 < 6      # only the >= 128-row tiles overflow
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,res,act', [
+    (2, 64, 64, 48, 48, True, 1),      # the HRNet shape classes at small batch
+    (2, 32, 32, 96, 96, True, 1),
+    (2, 16, 16, 192, 192, False, 1),
+    (5, 8, 8, 384, 384, True, 1),      # 8 x 8 maps: partial image batch for the 4-image tiles
+    (1, 16, 16, 16, 48, False, 0),     # one tile, one chunk, every halo side is padding, no activation
+    (3, 24, 40, 32, 96, True, 1),      # partial tiles in x and y (24 = 16 + 8, 40 = 32 + 8)
+    (70, 32, 32, 48, 48, True, 1),     # more work items than one round of persistent blocks
+    (9, 6, 4, 64, 144, False, 1),      # maps smaller than a tile, 3 co-tiles
+])
+def test_conv_winograd_kernels(n, h, w, cin, cout, res, act):
+    """Configs 45 / 46 (csrc/conv_wino.hip): fused Winograd F(2x2,3x3); the filter transform runs on
+    the device (egn_wino_pack_weight_f32).  Same oracle and tolerance as the direct kernels."""
+    import ctypes as C
+    from egonet_amd import _lib
+    L = _lib.lib()
+    assert L.egn_conv_config_kind(45) == 1 and L.egn_conv_config_kind(46) == 1 and L.egn_conv_config_kind(44) == 0
+    assert L.egn_conv_config_kind(47) == -1                # timing ablation: never selectable
+    out = (C.c_int * 12)()
+    for cfg in (45, 46):
+        rc = L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, cfg, out)
+        if cfg == 46 and (h > 8 or w > 8):
+            assert rc != 0
+            continue
+        assert rc == 0
+        err = _conv_case(n, h, w, cin, cout, 3, 1, 1, act=act, use_res=res, cfg=cfg, seed=n + h + cin)
+        assert err < 2e-4, (cfg, err)
+    # what the planner must refuse: stride 2, 1x1, padded channel strides, Cout not a multiple of 48
+    assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 48, 48, 3, 3, 2, 1, 0, 45, out) != 0
+    assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 48, 48, 1, 1, 1, 0, 0, 45, out) != 0
+    assert L.egn_conv_plan_query(2, 16, 16, 35, 36, 48, 48, 3, 3, 1, 1, 0, 45, out) != 0
+    assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 64, 64, 3, 3, 1, 1, 0, 45, out) != 0
+    assert L.egn_wino_weight_floats(64, 48, 0) == 0 and L.egn_wino_weight_floats(48, 64, 1) == 0
+
+
+def test_winograd_filter_pack_device_vs_host():
+    """egn_wino_pack_weight_f32 == engine.pack_wino_weight (the float64 host transform the inference
+    programs use), forward and data-gradient filters."""
+    from egonet_amd import _lib, engine
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    for cout, cin in ((48, 48), (96, 32), (144, 192)):
+        wt = torch.randn(cout, cin, 3, 3, generator=g)
+        for dgrad in (0, 1):
+            if L.egn_wino_weight_floats(cout, cin, dgrad) == 0:
+                continue
+            dst = torch.empty(L.egn_wino_weight_floats(cout, cin, dgrad), device='cuda')
+            _lib.check(L.egn_wino_pack_weight_f32(_lib.ptr(wt.cuda()), cout, cin, dgrad, _lib.ptr(dst),
+                                                  _lib.current_stream()))
+            src = wt.flip(2, 3).permute(1, 0, 2, 3).contiguous() if dgrad else wt
+            want = engine.pack_wino_weight(src)
+            assert dst.numel() == want.numel()
+            d = (dst.cpu() - want).abs().max().item()
+            assert d <= 2e-7 * wt.abs().max().item(), (cout, cin, dgrad, d)
 
 
 @pytest.mark.parametrize('n,h,w,res,act', [
