@@ -42,11 +42,14 @@ SIGNATURES = {
     'egn_fuse_sum_relu_f32': (_i, [_p, _i, _i, _i, _i, _i, _i, C.POINTER(_p), C.POINTER(_i), _i, _p]),
     'egn_nchw_to_nhwc_f32': (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
     'egn_nhwc_to_nchw_f32': (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),
+    'egn_pixel_shuffle_nhwc_to_nchw_f32': (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     'egn_fill_coord_ramps_f32': (_i, [_p, _i, _i, _i, _i, _i, _p]),
     'egn_decode_heatmaps_f32': (_i, [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     'egn_keypoints_to_screen_f64': (_i, [_p, _i, _i, _d, _d, _p, _p, _i, _i, _p, _p, _p, _p, _i, _p]),
     'egn_unnormalize_f64': (_i, [_p, _i, _i, _i, _p, _p, _p, _p]),
     'egn_pose_solve_f64': (_i, [_p, _i, _p, _d, _d, _i, _p, _p, _p]),
+    'egn_keypoints_to_screen_host_f64': (_i, [_p, _i, _i, _d, _d, _p, _p, _i, _i, _p]),
+    'egn_pose_solve_host_f64': (_i, [_p, _i, _p, _d, _d, _i, _p, _p]),
     'egn_kitti_eval_image': (_i, [C.c_char_p, C.c_char_p, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i),
                                   C.POINTER(_d), C.POINTER(_d)]),
     'egn_crop_warp_normalize_u8': (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p]),
@@ -84,6 +87,7 @@ SIGNATURES = {
     'egn_program_add_fuse': (_i, [_p, Ref, _i, _i, _i, _i, _i, _i, C.POINTER(Ref), C.POINTER(_i), _i]),
     'egn_program_add_nchw_to_nhwc': (_i, [_p, Ref, Ref, _i, _i, _i, _i, _i]),
     'egn_program_add_nhwc_to_nchw': (_i, [_p, Ref, Ref, _i, _i, _i, _i, _i]),
+    'egn_program_add_pixel_shuffle': (_i, [_p, Ref, Ref, _i, _i, _i, _i, _i, _i]),
     'egn_program_add_ramps': (_i, [_p, Ref, _i, _i, _i, _i, _i]),
     'egn_program_add_decode': (_i, [_p, Ref, _i, _i, _i, _i, _i, Ref, Ref, Ref]),
     'egn_program_fork': (_i, [_p]),
@@ -94,6 +98,7 @@ SIGNATURES = {
     'egn_program_run_timed': (_i, [_p, _p, C.POINTER(C.c_float), _i]),
     'egn_program_capture': (_i, [_p, _p]),
     'egn_program_replay': (_i, [_p, _p]),
+    'egn_launch_count': (C.c_long, []),
     'egn_program_op_info': (_i, [_p, _i, C.POINTER(_i), C.POINTER(_d), C.POINTER(_d), C.c_char_p, _i]),
 }
 

@@ -61,10 +61,17 @@ def crop_instances(model, annot_dict, images=None):
     """-> (instances [n,3,h,w] CUDA, records) like egonet.py:105-155.  ``images``:
     optional {path: [H,W,3] uint8 RGB}; otherwise the files are read with PIL."""
     width, height = model.resolution
+    if model.xy_dict is not None and model.xy_dict.get('flag'):
+        # the reference concatenates the x/y ramps to the crop (egonet.py:88-93); the device
+        # front end produces the 3 image channels only
+        raise NotImplementedError('add_xy: the GPU crop front end writes 3-channel crops; set pth_trans to use '
+                                  'the host route (common/crop_cv2.py) for 5-channel inputs')
     records = model.make_records(annot_dict)
     dev = next(model.parameters()).device
     norm = (model.cfgs.get('dataset', {}) or {}).get('pth_transform') or {}
-    mean, std = norm.get('mean', IMAGENET_MEAN)[:3], norm.get('std', IMAGENET_STD)[:3]
+    mean, std = list(norm.get('mean', IMAGENET_MEAN)), list(norm.get('std', IMAGENET_STD))
+    if len(mean) != 3 or len(std) != 3:
+        raise ValueError('pth_transform mean/std must have 3 entries (RGB), got %d / %d' % (len(mean), len(std)))
     by_path = {}
     for i, rec in enumerate(records):
         by_path.setdefault(rec['path'], []).append(i)

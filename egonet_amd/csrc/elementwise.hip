@@ -142,6 +142,34 @@ extern "C" int egn_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int 
   return (int)hipGetLastError();
 }
 
+// nn.PixelShuffle(up) fused with the NHWC -> NCHW hand-over (hrnet.py:373-383, 598-600):
+//   y[n, j, h*up + a, w*up + b] = x[n, h, w, j*up*up + a*up + b]
+// one thread per output element; consecutive threads walk a row of y (coalesced stores), the
+// up*up*C floats of an input pixel stay in L1/L2 between them
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            int N, int C, int H, int W, int cs, int up) {
+  const int Ho = H * up, Wo = W * up;
+  const size_t total = (size_t)N * C * Ho * Wo;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(e % Wo);
+    const int oy = (int)((e / Wo) % Ho);
+    const int j = (int)((e / ((size_t)Wo * Ho)) % C);
+    const int n = (int)(e / ((size_t)Wo * Ho * C));
+    const int h = oy / up, a = oy - h * up, w = ox / up, b = ox - w * up;
+    y[e] = x[(((size_t)n * H + h) * W + w) * cs + (j * up + a) * up + b];
+  }
+}
+
+extern "C" int egn_pixel_shuffle_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int H, int W, int cs,
+                                                  int up, void* stream) {
+  if (up < 1 || C < 1 || cs < C * up * up) return EGN_E_BADARG;
+  const size_t total = (size_t)N * C * H * W * up * up;
+  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N,
+                     C, H, W, cs, up);
+  return (int)hipGetLastError();
+}
+
 extern "C" int egn_fill_coord_ramps_f32(float* y, int N, int H, int W, int cs, int c0, void* stream) {
   if (c0 < 0 || c0 + 2 > cs) return EGN_E_BADARG;
   const size_t total = (size_t)N * H * W;

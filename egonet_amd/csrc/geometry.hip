@@ -89,3 +89,32 @@ extern "C" int egn_pose_solve_f64(const double* pred3d, int n, const double* kpt
                      kpt_x, fx, cx, alpha_mode, euler, alpha);
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Host twins (plain loops over HOST pointers, the same pose_math.h): the reference's CPU plumbing --
+// EgoNet.get_keypoints(is_cuda=False) / get_6d_rep on a CPU model (egonet.py:424-467, 279-295;
+// BASELINE config 1) -- needs the glue without a GPU.  Not a fallback of the device path: CUDA
+// tensors never come here.
+extern "C" int egn_keypoints_to_screen_host_f64(const float* local, int n, int K, double mul_x, double mul_y,
+                                                const double* center, const double* scale, int crop_w,
+                                                int crop_h, double* screen) {
+  if (n < 0 || K <= 0 || (n > 0 && (!local || !center || !scale || !screen))) return EGN_E_BADARG;
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < K; ++k) {
+      const size_t e = (size_t)i * K + k;
+      const double u = (double)(float)((double)local[2 * e] * mul_x);
+      const double v = (double)(float)((double)local[2 * e + 1] * mul_y);
+      egn_crop_to_screen(center[2 * i], center[2 * i + 1], scale[2 * i], crop_w, crop_h, u, v, &screen[2 * e],
+                         &screen[2 * e + 1]);
+    }
+  return 0;
+}
+
+extern "C" int egn_pose_solve_host_f64(const double* pred3d, int n, const double* kpt_x, double fx, double cx,
+                                       int alpha_mode, double* euler, double* alpha) {
+  if (n < 0 || (alpha_mode != 0 && alpha_mode != 1) || (alpha_mode == 0 && !kpt_x)) return EGN_E_BADARG;
+  if (n > 0 && (!pred3d || !euler || !alpha)) return EGN_E_BADARG;
+  for (int i = 0; i < n; ++i)
+    alpha[i] = egn_pose_solve_one(pred3d + (size_t)96 * i, kpt_x ? kpt_x[i] : 0.0, fx, cx, alpha_mode, euler + 3 * i);
+  return 0;
+}

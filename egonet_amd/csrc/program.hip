@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <string>
+#include <atomic>
 #include <vector>
 
 #include "egn_internal.h"
@@ -72,7 +73,7 @@ extern "C" int egn_conv_plan_query(int N, int H, int W, int Cin, int cs_in, int 
 // programs
 // ---------------------------------------------------------------------------
 enum OpKind { OP_CONV = 1, OP_FUSE = 2, OP_NCHW2NHWC = 3, OP_NHWC2NCHW = 4, OP_RAMPS = 5, OP_DECODE = 6,
-              OP_FORK = 7, OP_JOIN = 8 };
+              OP_FORK = 7, OP_JOIN = 8, OP_PIXSHUF = 9 };
 constexpr int kMaxLanes = 4;  // concurrent launch lanes (HRNet has at most 4 branches)
 
 struct Op {
@@ -205,6 +206,11 @@ extern "C" int egn_program_add_nhwc_to_nchw(egn_program* p, egn_ref x, egn_ref y
   if (cs < C) return EGN_E_BADARG;
   return add_simple(p, OP_NHWC2NCHW, x, y, N, C, H, W, cs, 0);
 }
+extern "C" int egn_program_add_pixel_shuffle(egn_program* p, egn_ref x, egn_ref y, int N, int C, int H, int W,
+                                             int cs, int up) {
+  if (up < 1 || cs < C * up * up) return EGN_E_BADARG;
+  return add_simple(p, OP_PIXSHUF, x, y, N, C, H, W, cs, up);
+}
 extern "C" int egn_program_add_ramps(egn_program* p, egn_ref y, int N, int H, int W, int cs, int c0) {
   egn_ref none = {-1, 0};
   return add_simple(p, OP_RAMPS, y, none, N, H, W, cs, c0, 0);
@@ -270,7 +276,13 @@ extern "C" int egn_program_op_info(const egn_program* p, int i, int* kind, doubl
   return 0;
 }
 
+// kernel launches issued through programs since the library was loaded (egn_launch_count): lets a
+// caller PROVE that a forward ran on this library's kernels and not on some other route
+static std::atomic<long> g_launches{0};
+extern "C" long egn_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
+
 static int launch_op(egn_program* p, Op& op, hipStream_t s) {
+  g_launches.fetch_add(1, std::memory_order_relaxed);
   switch (op.kind) {
     case OP_CONV: {
       ConvArgs a = op.conv;
@@ -298,6 +310,9 @@ static int launch_op(egn_program* p, Op& op, hipStream_t s) {
     case OP_NHWC2NCHW:
       return egn_nhwc_to_nchw_f32((const float*)resolve(p, op.r[0]), (float*)resolve(p, op.r[1]), op.i[0],
                                   op.i[1], op.i[2], op.i[3], op.i[4], s);
+    case OP_PIXSHUF:
+      return egn_pixel_shuffle_nhwc_to_nchw_f32((const float*)resolve(p, op.r[0]), (float*)resolve(p, op.r[1]),
+                                                op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], s);
     case OP_RAMPS:
       return egn_fill_coord_ramps_f32((float*)resolve(p, op.r[0]), op.i[0], op.i[1], op.i[2], op.i[3],
                                       op.i[4], s);
@@ -406,5 +421,8 @@ extern "C" int egn_program_capture(egn_program* p, void* stream) {
 
 extern "C" int egn_program_replay(egn_program* p, void* stream) {
   if (!p || !p->exec) return EGN_E_STATE;
+  long nk = 0;
+  for (const Op& op : p->ops) nk += (op.kind != OP_FORK && op.kind != OP_JOIN);
+  g_launches.fetch_add(nk, std::memory_order_relaxed);
   return (int)hipGraphLaunch(p->exec, (hipStream_t)stream);
 }

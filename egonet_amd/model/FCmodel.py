@@ -63,7 +63,14 @@ class FCModel(nn.Module):
         self._engine = None
 
     def _hip_ok(self, x):
-        return x.is_cuda and not self.training and not torch.is_grad_enabled()
+        # eval mode + CUDA input: always the HIP program, whatever the autograd mode
+        # (the reference evaluates with grad enabled, libs/trainer/trainer.py:421)
+        return x.is_cuda and not self.training
+
+    def train(self, mode=True):
+        if mode:                 # the weights are about to change: drop programs and packed blobs
+            self._engine = None
+        return super().train(mode)
 
     def _hip_engine(self):
         from egonet_amd import engine

@@ -135,22 +135,27 @@ class EgoNet(nn.Module):
         return {k: [] for k in ('center', 'scale', 'rotation', 'bbox_resize', 'kpts_2d_pred',
                                 'label', 'score')}
 
+    @torch.no_grad()
     def get_keypoints(self, instances, records, is_cuda=True):
         """Reference egonet.py:424-467 (coordinates head): fills
-        ``records[i]['kpts']`` and returns the per-image dictionary."""
+        ``records[i]['kpts']`` and returns the per-image dictionary.
+        ``is_cuda=False`` is the reference's CPU plumbing (BASELINE config 1): HC runs through
+        torch on the CPU (where the model lives) and the crop->screen affine through the host twin
+        of the device kernel (same pose_math.h arithmetic)."""
         if is_cuda:
             instances = instances.cuda()
         if any(float(r.get('rotation', 0.)) != 0. for r in records):
             raise NotImplementedError('rotated crops are not produced by the inference path')
+        width, height = self.resolution
+        centers = np.ascontiguousarray(np.stack([np.asarray(r['center'], dtype=np.float64) for r in records]))
+        scales = np.ascontiguousarray(np.stack([np.asarray(r['scale'], dtype=np.float64) for r in records]))
+        out = self.HC(instances.float())
+        local = out[1].contiguous()
+        n, J = local.shape[:2]
         if instances.is_cuda:
-            width, height = self.resolution
-            out = self.HC(instances)
-            local = out[1].contiguous()
-            n, J = local.shape[:2]
             dev = local.device
             screen = torch.empty(n, 2 * J, dtype=torch.float64, device=dev)
-            c_d = _dev_f64(np.stack([np.asarray(r['center'], dtype=np.float64) for r in records]), dev)
-            s_d = _dev_f64(np.stack([np.asarray(r['scale'], dtype=np.float64) for r in records]), dev)
+            c_d, s_d = _dev_f64(centers, dev), _dev_f64(scales, dev)
             with torch.cuda.device(dev):
                 _lib.check(_lib.lib().egn_keypoints_to_screen_f64(
                     _lib.ptr(local), n, J, float(width), float(height), _lib.ptr(c_d), _lib.ptr(s_d),
@@ -158,8 +163,11 @@ class EgoNet(nn.Module):
                     _lib.current_stream(dev)), 'keypoints_to_screen')
             screen = screen.cpu().numpy().reshape(n, J, 2)
         else:
-            raise ValueError('get_keypoints needs a GPU (the reference rejects CPU inference too, '
-                             'tools/inference.py:230-231)')
+            loc = np.ascontiguousarray(local.numpy(), dtype=np.float32)
+            screen = np.empty((n, J, 2), dtype=np.float64)
+            _lib.check(_lib.lib().egn_keypoints_to_screen_host_f64(
+                loc.ctypes.data, n, J, float(width), float(height), centers.ctypes.data, scales.ctypes.data,
+                int(width), int(height), screen.ctypes.data), 'keypoints_to_screen_host')
         ret = {}
         for i, record in enumerate(records):
             record['kpts'] = screen[i]
@@ -197,9 +205,17 @@ class EgoNet(nn.Module):
 
     def _pose(self, pred3d, kpt_x, K, amode):
         dev = next(self.parameters()).device
-        if dev.type != 'cuda':
-            raise ValueError('pose solve runs on the GPU; move the model with .cuda()')
         n = len(pred3d)
+        if dev.type != 'cuda':       # CPU model (BASELINE config 1): the host twin, same arithmetic
+            p = np.ascontiguousarray(np.asarray(pred3d, dtype=np.float64).reshape(n, -1))
+            euler = np.empty((n, 3), dtype=np.float64)
+            alpha = np.empty(n, dtype=np.float64)
+            kx = None if kpt_x is None else np.ascontiguousarray(kpt_x, dtype=np.float64)
+            fx, cx = (float(K[0, 0]), float(K[0, 2])) if K is not None else (1.0, 0.0)
+            _lib.check(_lib.lib().egn_pose_solve_host_f64(
+                p.ctypes.data, n, None if kx is None else kx.ctypes.data, fx, cx, amode,
+                euler.ctypes.data, alpha.ctypes.data), 'pose_solve_host')
+            return euler, alpha
         p = _dev_f64(pred3d.reshape(n, -1), dev)
         euler = torch.empty(n, 3, dtype=torch.float64, device=dev)
         alpha = torch.empty(n, dtype=torch.float64, device=dev)

@@ -242,13 +242,22 @@ class PoseHighResolutionNet(nn.Module):
 
     # -- execution ---------------------------------------------------------
     def forward(self, x):
-        if x.is_cuda and not self.training and not torch.is_grad_enabled() \
-                and self.head_type in ('heatmap', 'coordinates') and not self.pixel_shuffle:
+        """Eval mode + CUDA input: ALWAYS the HIP program, whatever the autograd mode -- the
+        reference's validation loop calls ``model.eval(); model(data)`` with grad enabled
+        (libs/trainer/trainer.py:421) and ``EgoNet.get_keypoints`` has no ``no_grad`` of its own
+        (libs/model/egonet.py:434).  The outputs are plain tensors (inference: no autograd
+        graph).  There is no torch/MIOpen route for an eval-mode CUDA tensor.
+        Training mode: the module graph under torch autograd (the reference's API allows
+        ``model(data)`` + ``loss.backward()``); the native training step of this package
+        (egonet_amd.train_hrnet) does not go through here.  CPU tensors: torch on the CPU."""
+        if x.is_cuda and not self.training:
             return self._hip_engine().forward(x)
-        if x.is_cuda and not self.training and not torch.is_grad_enabled():
-            raise NotImplementedError('egonet_amd: no HIP path for head_type=%r pixel_shuffle=%r'
-                                      % (self.head_type, self.pixel_shuffle))
         return self._torch_forward(x)
+
+    def train(self, mode=True):
+        if mode:                 # the weights are about to change: drop programs and packed blobs
+            self._engine = None
+        return super().train(mode)
 
     def _hip_engine(self):
         from egonet_amd import engine

@@ -38,6 +38,7 @@ import os
 import torch
 
 from . import _lib, tuner
+from .engine import invalidate
 from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID
 from .engine import Buf, HRNetEngine, _round_up
 
@@ -588,7 +589,7 @@ class HRNetTrainStep(object):
             if update:
                 self.flat.adam_step(self.lr, self.betas, self.eps, st)
             self.packs.finalize()     # first step: the set of filters is known now
-            m._engine = None          # the inference engine caches folded weights
+            invalidate(m)             # the inference engine caches folded weights (raw-pointer writes)
             if self.debug_hook is not None:
                 self.last_tape = tape
         return self.loss_dev

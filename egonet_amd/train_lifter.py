@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import _lib, tuner
-from .engine import _round_up
+from .engine import _round_up, invalidate
 from .train_hrnet import FlatParams
 
 
@@ -143,9 +143,9 @@ class LifterTrainStep(object):
         """One zero_grad/forward/loss/backward/Adam iteration.  Returns the loss
         (Python float is NOT forced: a 1-element float64 device tensor)."""
         L, dev = self.L, self.dev
-        B = x.shape[0]
-        if B % 4:
-            raise ValueError('batch size must be a multiple of 4 (row stride of the transposed operands)')
+        B = x.shape[0]              # any size: the reference's DataLoader has no drop_last (trainer.py:113-125)
+        if B < 2:
+            raise ValueError('BatchNorm1d needs more than one sample per batch in training mode')
         x = x.contiguous().float()
         target = target.contiguous().float()
         ws = self._buf('colws', L.egn_colreduce_ws_bytes(1024 + 16) // 4)
@@ -243,4 +243,7 @@ class LifterTrainStep(object):
                 self.grad_sync(self.flat.grad)
             if update:
                 self.flat.adam_step(self.lr, self.betas, self.eps, st)
+            # weights and BatchNorm buffers were written through raw pointers: eval-mode forwards
+            # between steps (eval_during, EgoNet.L after fine-tuning) must re-fold them
+            invalidate(self.model)
         return self.loss_dev

@@ -8,6 +8,10 @@ metric callbacks, snapshots.  What is replaced: the five lines of its hot loop
 (trainer.py:183-209, ``zero_grad / forward / loss / backward / step``) -- one call
 of ``HRNetTrainStep.step`` / ``LifterTrainStep.step`` (HIP launches only).
 
+``evaluate`` (trainer.py:395-513) is the reference's validation loop: ``model.eval()`` and
+``model(data)`` with autograd enabled -- which here runs the HIP inference program (the modules
+ignore the autograd mode in eval mode) -- then the caller's loss / evaluator objects.
+
 ``loss_func`` and ``optim`` are accepted like in the reference; they are read, not
 executed: the loss weights come from ``loss_func.comp_dict`` when it has one
 (JointsCompositeLoss, function.py:61-93) else from
@@ -18,6 +22,7 @@ dumps of the reference are not reproduced.
 import os
 import time
 
+import numpy as np
 import torch
 
 from . import parallel
@@ -100,13 +105,87 @@ def make_step(model, cfgs, loss_func=None, optim=None):
     raise TypeError('no native training step for %s' % type(inner).__name__)
 
 
+class _Acc(object):
+    """The reference's AverageMeter for the optional training metric (utils.py:149-182)."""
+
+    def __init__(self):
+        self.sum, self.count, self.others = 0.0, 0, None
+
+    def update(self, val, n=1, others=None):
+        self.sum += float(val) * n
+        self.count += n
+        self.others = others
+
+    @property
+    def avg(self):
+        return self.sum / self.count if self.count else 0.0
+
+
+def evaluate(eval_dataset, model, loss_func, cfgs, logger, evaluator, save=False, save_path=None,
+             collate_fn=None, epoch=None, sample_num=20):
+    """trainer.py:395-513.  ``model.eval()`` + ``model(data)`` per batch with autograd ENABLED, like
+    the reference: for CUDA batches that is the HIP inference program (hrnet.py / FCmodel.py
+    ``forward``).  ``loss_func`` (the caller's criterion, optional) and ``evaluator``
+    (``update(prediction, ground_truth=, meta_data=)`` / ``report(logger)``) are called like the
+    reference calls them; 3D plotting (``vis_epoch``) is outside the hot path and skipped.
+    Returns the mean validation loss (None without ``loss_func``)."""
+    ts = cfgs['testing_settings']
+    unnorm = bool(ts.get('unnormalize', False))
+    stats = eval_dataset.statistics if unnorm else None
+    if ts.get('apply_dropout', False):
+        raise NotImplementedError('testing_settings.apply_dropout: the eval-mode HIP program has no dropout')
+    model.eval()
+    loader = get_loader(eval_dataset, cfgs, 'testing', collate_fn)
+    use_cuda = cfgs.get('use_gpu', True) and torch.cuda.is_available()
+    loss_sum, seen = 0.0, 0
+    preds, gts = [], []
+    for batch_idx, (data, target, weights, meta) in enumerate(loader):
+        if use_cuda:
+            data, target = data.cuda(), target.cuda()
+            weights = weights.cuda() if torch.is_tensor(weights) else weights
+        prediction = model(data)
+        if loss_func is not None:
+            with torch.no_grad():
+                loss = loss_func(prediction, target, weights, meta)
+            loss_sum += float(loss.item()) * data.size(0)
+            seen += data.size(0)
+        if unnorm:
+            target = eval_dataset.unnormalize(target.data.cpu().numpy(), stats['mean_out'], stats['std_out'])
+            prediction = eval_dataset.unnormalize(prediction.data.cpu().numpy(), stats['mean_out'], stats['std_out'])
+        if evaluator is not None:
+            evaluator.update(prediction, ground_truth=target, meta_data=meta)
+        if save:
+            preds.append(prediction if isinstance(prediction, np.ndarray) else
+                         (prediction[0] if isinstance(prediction, tuple) else prediction).data.cpu().numpy())
+            gts.append(target if isinstance(target, np.ndarray) else target.data.cpu().numpy())
+    if save:
+        np.save(save_path, np.array({'pred': np.concatenate(preds, axis=0), 'error': [],
+                                     'gt': np.concatenate(gts, axis=0)}, dtype=object))
+    if evaluator is not None:
+        evaluator.report(logger)
+    mean_loss = loss_sum / seen if seen else None
+    if mean_loss is not None:
+        logger.info('Validation%s: loss %.6f over %d samples' % (
+            '' if epoch is None else ' (epoch %d)' % epoch, mean_loss, seen))
+    return mean_loss
+
+
 def train(train_dataset, model, loss_func, optim, sche, cfgs, logger, metric_func=None, stats=None,
-          valid_dataset=None, collate_fn=None, save_debug=False, evaluate_fn=None):
-    """trainer.py:127-263.  ``evaluate_fn(valid_dataset, model, epoch)`` (optional) stands in for the
-    reference's ``evaluate`` call during training (``eval_during``)."""
+          valid_dataset=None, collate_fn=None, save_debug=False, evaluate_fn=None, evaluator=None):
+    """trainer.py:127-263.  Validation during training (``eval_during``): ``evaluate_fn(valid_dataset,
+    model, epoch)`` if given, else this module's ``evaluate`` with ``evaluator`` (the reference builds
+    its ``Evaluator`` from libs/metric, which is outside this package: pass one in)."""
     ts = cfgs['training_settings']
     total_epochs, report_every = ts['total_epochs'], ts['report_every']
-    eval_during = ts.get('eval_during', False) and valid_dataset is not None and evaluate_fn is not None
+    eval_during = bool(ts.get('eval_during', False)) and valid_dataset is not None
+    if eval_during and evaluate_fn is None and evaluator is None:
+        logger.warning('training_settings.eval_during is set but neither evaluate_fn nor evaluator was given: '
+                       'no validation during training')
+        eval_during = False
+    if eval_during and evaluate_fn is None:
+        def evaluate_fn(ds, mdl, ep):
+            return evaluate(ds, mdl, loss_func if callable(loss_func) else None, cfgs, logger, evaluator,
+                            collate_fn=collate_fn, epoch=ep)
     eval_every = ts.get('eval_every', 0)
     eval_start = ts.get('eval_start_epoch', 0)
     step = make_step(model, cfgs, loss_func, optim)
@@ -122,7 +201,8 @@ def train(train_dataset, model, loss_func, optim, sche, cfgs, logger, metric_fun
         if optim is not None:
             step.lr = optim.param_groups[0]['lr']
         loader = get_loader(train_dataset, cfgs, 'training', collate_fn)
-        total_batches, seen, loss_sum, t_epoch = len(loader), 0, 0.0, time.time()
+        total_batches, t_epoch = len(loader), time.time()
+        acc = _Acc()
         for batch_idx, (data, target, weights, meta) in enumerate(loader):
             data = data.to(dev, non_blocking=True)
             target = target.to(dev, non_blocking=True)
@@ -133,17 +213,20 @@ def train(train_dataset, model, loss_func, optim, sche, cfgs, logger, metric_fun
             else:
                 loss = step.step(data, target)
                 prediction = None
-            if batch_idx % report_every == 0:               # the only host sync of the loop
+            # the optional metric runs on EVERY batch and accumulates, like the reference
+            # (trainer.py:200-205); its decode is on the device, its result is a host number
+            if metric_func is not None and prediction is not None:
+                avg_acc, cnt, others = metric_func(prediction, meta, cfgs)
+                acc.update(avg_acc, n=cnt, others=others)
+            if batch_idx % report_every == 0:               # loss read-back only here
                 lv = float(loss.item())
-                seen += data.size(0)
-                loss_sum += lv
                 logger.info('Epoch: [%d][%d/%d]  loss %.6f  lr %.2e  %.1f samples/s' % (
                     epoch, batch_idx, total_batches, lv, step.lr,
                     (batch_idx + 1) * data.size(0) / max(time.time() - t_epoch, 1e-9)))
+                if acc.count:
+                    logger.info('          metric %.6f (running mean over %d)' % (acc.avg, acc.count))
                 x_buffer.append(total_batches * (epoch - 1) + batch_idx)
                 y_buffer.append(lv)
-                if metric_func is not None and prediction is not None:
-                    metric_func(prediction, meta, cfgs)
             if eval_during and epoch > eval_start and batch_idx and eval_every and batch_idx % eval_every == 0:
                 evaluate_fn(valid_dataset, model, epoch)
                 model.train()

@@ -114,6 +114,11 @@ int egn_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int H, int W,
                          int cs, void* stream);
 int egn_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int H, int W,
                          int cs, void* stream);
+/* nn.PixelShuffle(up) of the heat-map upsampler (hrnet.py:373-383, 598-600) fused with
+ * the NHWC -> NCHW hand-over: y[n,j,h*up+a,w*up+b] = x[n,h,w,(j*up+a)*up+b];
+ * x [N,H,W,cs] with cs >= C*up*up, y [N,C,H*up,W*up] */
+int egn_pixel_shuffle_nhwc_to_nchw_f32(const float* x, float* y, int N, int C,
+                                       int H, int W, int cs, int up, void* stream);
 /* write the two coordinate ramps linspace(0,1) (hrnet.py:461-467) into
  * channels [c0, c0+1] of an NHWC tensor */
 int egn_fill_coord_ramps_f32(float* y, int N, int H, int W, int cs, int c0,
@@ -166,6 +171,18 @@ int egn_unnormalize_f64(const float* y, int n, int D, int ld,
 int egn_pose_solve_f64(const double* pred3d, int n, const double* kpt_x,
                        double fx, double cx, int alpha_mode,
                        double* euler, double* alpha, void* stream);
+/* Host twins of egn_keypoints_to_screen_f64 (without the lifter-input part) and
+ * egn_pose_solve_f64: the same arithmetic as plain loops over HOST pointers, no
+ * stream.  They serve the reference's CPU plumbing -- EgoNet.get_keypoints(
+ * is_cuda=False), get_6d_rep on a CPU model (egonet.py:424-467, 279-295;
+ * BASELINE config 1) -- and are never used for CUDA tensors. */
+int egn_keypoints_to_screen_host_f64(const float* local, int n, int K,
+                                     double mul_x, double mul_y,
+                                     const double* center, const double* scale,
+                                     int crop_w, int crop_h, double* screen);
+int egn_pose_solve_host_f64(const double* pred3d, int n, const double* kpt_x,
+                            double fx, double cx, int alpha_mode,
+                            double* euler, double* alpha);
 
 /* ------------------------------------------------------------------------
  * KITTI 2D-detection AP + Average Orientation Similarity, the IMAGE-metric path
@@ -359,6 +376,8 @@ int egn_program_add_nchw_to_nhwc(egn_program* p, egn_ref x, egn_ref y, int N,
                                  int C, int H, int W, int cs);
 int egn_program_add_nhwc_to_nchw(egn_program* p, egn_ref x, egn_ref y, int N,
                                  int C, int H, int W, int cs);
+int egn_program_add_pixel_shuffle(egn_program* p, egn_ref x, egn_ref y, int N,
+                                  int C, int H, int W, int cs, int up);
 int egn_program_add_ramps(egn_program* p, egn_ref y, int N, int H, int W,
                           int cs, int c0);
 int egn_program_add_decode(egn_program* p, egn_ref hm, int N, int K, int H,
@@ -384,6 +403,10 @@ int egn_program_run_timed(egn_program* p, void* stream, float* ms, int n_ms);
 /* capture the op sequence into a hipGraph (bindings frozen) / replay it */
 int egn_program_capture(egn_program* p, void* stream);
 int egn_program_replay(egn_program* p, void* stream);
+/* number of kernel launches issued through egn_program_run / _run_timed / _replay
+ * since the library was loaded (process wide, all devices).  Test hook: a caller
+ * can prove that a forward went through this library's kernels. */
+long egn_launch_count(void);
 /* per-op metadata for reports */
 int egn_program_op_info(const egn_program* p, int i, int* kind, double* flops,
                         double* bytes, char* tag, int tag_len);

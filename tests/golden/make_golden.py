@@ -17,6 +17,8 @@ stored in full (tiny nets) or regenerated from ``egonet_amd.synth`` (per-key
 seeded, construction-order independent) for the full-size W48 / lifter nets.
 
 Usage:  python tests/golden/make_golden.py            (from the repo root)
+        --w48-pipeline only the full-size W48 end-to-end fixture (section 7b)
+        --heads        only the pixel-shuffle / angle-regression head fixtures (section 3b)
         --train-only   stop after the training-side fixtures (sections 0 .. 0e)
         --cr-only      stop after the cross-ratio / metric fixtures (0d, 0e)
 The generation is deterministic: re-running leaves the committed files byte-identical.
@@ -55,6 +57,62 @@ def _install_stubs():
     import matplotlib
     matplotlib.use('Agg')
 
+def w48_pipeline(save, crc, sd_crc):
+    """---- 7b: BASELINE config 5 at full size: the reference's EgoNet (HRNet-W48 coordinates
+    head, demo.yml topology) on 16 crops of 4 frames, CPU: get_keypoints -> lift_2d_to_3d ->
+    gather_lifting_results('proj', get_str=True) (tools/inference.py:135-199 minus file I/O).
+    Weights: egonet_amd.synth (regenerated on the test side, CRC checked)."""
+    from egonet_amd import configs, synth
+    import libs.common.img_proc as ref_ip
+    import libs.model.egonet as ref_ego
+    cfg = configs.w48_config('coordinates')
+    ego = ref_ego.EgoNet(cfg, pre_trained=False).eval()
+    hc_sd = synth.synth_state_dict(ego.HC.state_dict(), seed=1)
+    l_sd = synth.synth_state_dict(ego.L.state_dict(), seed=2)
+    ego.HC.load_state_dict(hc_sd)
+    ego.L.load_state_dict(l_sd)
+    ego.LS = synth.synth_lifter_stats(66, 96, seed=1)
+    n, per = 16, 4
+    boxes = synth.synth_boxes(n, seed=11)
+    crops = synth.synth_crops(n, 3, 256, 256, seed=12)
+    K = np.array([[707.0493, 0., 604.0814], [0., 707.0493, 180.5066], [0., 0., 1.]])
+    rng = np.random.RandomState(9)
+    records, raws = [], {}
+    for i, b in enumerate(boxes):
+        ret = ref_ip.modify_bbox(b, 1.0)
+        path = 'frame%02d.png' % (i // per)
+        records.append({'path': path, 'center': ret['c'], 'scale': ret['s'], 'bbox': b,
+                        'bbox_resize': ret['bbox'], 'rotation': 0., 'label': 0, 'score': float(rng.uniform(0.3, 1))})
+        raws.setdefault(path, []).append(
+            {'class': 'Car', 'truncation': float(rng.randint(0, 3)) / 2, 'occlusion': float(rng.randint(0, 3)),
+             'alpha': float(rng.uniform(-3.1, 3.1)), 'bbox': [float(v) for v in b],
+             'dimensions': [float(v) for v in rng.uniform(1.2, 4.5, 3)],
+             'locations': [float(v) for v in rng.uniform(-20, 50, 3)], 'rot_y': float(rng.uniform(-3.1, 3.1)),
+             'score': records[-1]['score']})
+    with torch.no_grad():
+        rec = ego.get_keypoints(crops, records, is_cuda=False)
+        rec = ego.lift_2d_to_3d(rec, cuda=False)
+    kp2d, kp3d, eul, trn, alp, lines = [], [], [], [], [], {}
+    for path in rec:
+        r = rec[path]
+        r['K'] = K
+        r['raw_txt_format'] = raws[path]
+        r = ego.gather_lifting_results(r, None, None, get_str=True, alpha_mode='proj')
+        kp2d.append(np.concatenate(r['kpts_2d_pred']))
+        kp3d.append(r['kpts_3d_pred'])
+        eul.append(r['euler_angles'])
+        trn.append(r['translation'])
+        alp.append(r['alphas'])
+        lines[path] = r['pred_str']
+    save('egonet_w48_pipeline.npz', crops_crc=np.array(crc(crops.numpy())), boxes=boxes, K=K,
+         centers=np.stack([r['center'] for r in records]), scales=np.stack([r['scale'] for r in records]),
+         scores=np.array([r['score'] for r in records]),
+         kpts_2d=np.concatenate(kp2d), kpts_3d=np.concatenate(kp3d), euler=np.concatenate(eul),
+         translation=np.concatenate(trn), alpha_proj=np.concatenate(alp),
+         raw_txt=np.array(json.dumps(raws)), pred_str=np.array(json.dumps(lines)),
+         hc_crc=np.array(sd_crc(hc_sd)), l_crc=np.array(sd_crc(l_sd)),
+         **{'ls/' + k: v for k, v in ego.LS.items()})
+
 
 def main():
     _install_stubs()
@@ -84,6 +142,33 @@ def main():
         for k, v in sd.items():
             c = zlib.crc32(np.ascontiguousarray(v.numpy()).tobytes(), c)
         return c
+
+    if '--w48-pipeline' in sys.argv:
+        w48_pipeline(save, crc, sd_crc)
+        return
+
+    def head_variants():
+        """---- 3b: the remaining head variants of the reference (hrnet.py:373-422, 598-611): the
+        pixel-shuffle upsampler behind the heat-map head and the 'angleregression' head (needs a
+        64 x 64 trunk map: 256 x 256 input).  Tiny topology-complete nets, weights from synth."""
+        cfg_ps = configs.tiny_config('heatmap')
+        cfg_ps['heatmapModel']['pixel_shuffle'] = True
+        cfg_ps['heatmapModel']['heatmap_size'] = [32, 32]            # upsampling factor 32 / 64 * 4 = 2
+        cfg_an = configs.tiny_config('angleregression', input_size=(256, 256))
+        for tag, cfg, n in (('tiny_pixshuf', cfg_ps, 2), ('tiny_angle', cfg_an, 3)):
+            net = ref_hrnet.get_pose_net(cfg, is_train=False).eval()
+            sd = synth.synth_state_dict(net.state_dict(), seed=3)
+            net.load_state_dict(sd)
+            iw, ih = cfg['heatmapModel']['input_size']
+            x = synth.synth_crops(n, 3, ih, iw, seed=5)
+            with torch.no_grad():
+                out = net(x)
+            save('hrnet_%s.npz' % tag, cfg=np.array(json.dumps(cfg)), n=np.array(n), x_crc=np.array(crc(x.numpy())),
+                 sd_crc=np.array(sd_crc(sd)), out=out.numpy(), keys=np.array(json.dumps(list(sd))))
+
+    if '--heads' in sys.argv:
+        head_variants()
+        return
 
     # ---- 0: two training iterations of the reference HRNet (train mode) with the
     #         reference's JointsCompositeLoss ('mse', 'l1', weights 1.0 / 0.1) and
@@ -299,6 +384,8 @@ def main():
             arrs.update(maps=out.numpy())
         save('hrnet_%s.npz' % tag, **arrs)
 
+    head_variants()
+
     # ---- 4: full W48, weights regenerated from synth ----------------------
     x = synth.synth_crops(4, 3, 256, 256, seed=11)
     w48 = {}
@@ -436,6 +523,8 @@ def main():
          alpha_proj=np.concatenate(a_proj), alpha_trans=np.concatenate(a_trans),
          hc_crc=np.array(sd_crc(hc_sd)), l_crc=np.array(sd_crc(l_sd)),
          **{'ls/' + k: v for k, v in ego.LS.items()})
+
+    w48_pipeline(save, crc, sd_crc)
 
     # ---- 8: pose solve on well-posed cuboids (noisy rotated templates) -----
     from scipy.spatial.transform import Rotation

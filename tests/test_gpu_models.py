@@ -46,10 +46,14 @@ def test_hrnet_tiny_vs_reference_outputs(name):
     assert np.array_equal(maps.reshape(maps.shape[0], maps.shape[1], -1).argmax(axis=2), idx_ref)
 
 
+@pytest.mark.parametrize('wino', ['1', '0'])
 @pytest.mark.parametrize('head', ['coordinates', 'heatmap'])
-def test_hrnet_w48_vs_reference_outputs(head):
-    """The headline model: HRNet-W48 @256x256, 4 crops, both heads + decode."""
+def test_hrnet_w48_vs_reference_outputs(head, wino, monkeypatch):
+    """The headline model: HRNet-W48 @256x256, 4 crops, both heads + decode -- once with the fused
+    Winograd kernels on every 3x3 s1 layer they plan for (EGONET_AMD_WINO=1, csrc/conv_wino.hip),
+    once with the direct kernels only (=0): both kernel families meet the reference's bar."""
     from egonet_amd.common import img_proc
+    monkeypatch.setenv('EGONET_AMD_WINO', wino)
     g = golden('hrnet_w48_outputs.npz')
     cfg = configs.w48_config(head)
     net, sd = _model(cfg, 1)
@@ -174,6 +178,162 @@ def test_egonet_pipeline_vs_reference_outputs():
     np.testing.assert_allclose(res['kpts_3d'], kp3d, rtol=0, atol=1e-5)
     al = np.concatenate([rec[p]['alphas'] for p in rec])
     np.testing.assert_allclose(np.cos(res['alpha']), np.cos(al), atol=1e-6)
+
+
+@pytest.mark.parametrize('tag', ['tiny_pixshuf', 'tiny_angle'])
+def test_hrnet_other_heads_vs_reference_outputs(tag):
+    """Pixel-shuffle upsampler behind the heat-map head and the 'angleregression' head (reference
+    hrnet.py:373-422, 598-611) as HIP programs: final_layer -> 1x1 conv + BN + ReLU -> PixelShuffle
+    fused with the NCHW hand-over; 1x1 conv -> 4 strided BasicBlocks -> (AvgPool2d(4) + Linear + BN1d +
+    ReLU as one 4x4 valid conv) -> Linear.  Against the reference's outputs, launch counter checked."""
+    from egonet_amd import _lib
+    g = golden('hrnet_%s.npz' % tag)
+    cfg = fixture_cfg(g)
+    net, sd = _model(cfg, 3)
+    require_same_rng(sd_crc(sd), g['sd_crc'], 'weights')
+    iw, ih = cfg['heatmapModel']['input_size']
+    x = synth.synth_crops(int(g['n']), 3, ih, iw, seed=5).cuda()
+    c0 = _lib.lib().egn_launch_count()
+    out = net(x)                                            # eval mode, grad on: the HIP program
+    assert _lib.lib().egn_launch_count() - c0 > 40
+    assert tuple(out.shape) == g['out'].shape
+    np.testing.assert_allclose(out.cpu().numpy(), g['out'], rtol=0, atol=2e-4)
+    if tag == 'tiny_pixshuf':
+        idx_ref = g['out'].reshape(out.shape[0], out.shape[1], -1).argmax(axis=2)
+        assert np.array_equal(out.cpu().numpy().reshape(out.shape[0], out.shape[1], -1).argmax(axis=2), idx_ref)
+
+
+def test_egonet_w48_pipeline_vs_reference_outputs(tmp_path):
+    """BASELINE config 5 at full size on one GPU: HRNet-W48 (coordinates head) -> x256 -> crop affine
+    -> lifter -> pose solve -> KITTI result lines for 16 crops of 4 frames, against the REFERENCE's
+    own CPU run (tests/golden/egonet_w48_pipeline.npz, tools/inference.py:135-199 minus file I/O).
+    get_keypoints is called the way the reference calls it -- eval mode, autograd enabled
+    (libs/model/egonet.py:434) -- and must run the HIP program (launch counter)."""
+    from egonet_amd import _lib
+    from egonet_amd.model.egonet import EgoNet
+    import json
+    g = golden('egonet_w48_pipeline.npz')
+    cfg = configs.w48_config('coordinates')
+    ego = EgoNet(cfg, pre_trained=False)
+    hc_sd = synth.synth_state_dict(ego.HC.state_dict(), seed=1)
+    l_sd = synth.synth_state_dict(ego.L.state_dict(), seed=2)
+    require_same_rng(sd_crc(hc_sd), g['hc_crc'], 'HC weights')
+    ego.HC.load_state_dict(hc_sd)
+    ego.L.load_state_dict(l_sd)
+    ego.LS = {k[3:]: g[k] for k in g.files if k.startswith('ls/')}
+    ego = ego.eval().cuda()
+    crops = synth.synth_crops(16, 3, 256, 256, seed=12)
+    require_same_rng(arr_crc(crops.numpy()), g['crops_crc'], 'crops')
+    boxes, scores = g['boxes'], g['scores']
+    paths = ['frame%02d.png' % i for i in range(4)]
+    annot = {'path': paths, 'boxes': [boxes[4 * i:4 * i + 4] for i in range(4)],
+             'scores': [scores[4 * i:4 * i + 4] for i in range(4)]}
+    records = ego.make_records(annot)
+    L = _lib.lib()
+    assert torch.is_grad_enabled()
+    before = L.egn_launch_count()
+    rec = ego.get_keypoints(crops, records)                 # no torch.no_grad() around it
+    nops = sum(1 for m in ego.HC._hip_engine().program(crops.cuda()).meta if m['kind'] not in ('fork', 'join'))
+    assert L.egn_launch_count() - before >= nops > 300
+    rec = ego.lift_2d_to_3d(rec)
+    kp2d = np.concatenate([np.concatenate(rec[p]['kpts_2d_pred']) for p in paths])
+    kp3d = np.concatenate([rec[p]['kpts_3d_pred'] for p in paths])
+    np.testing.assert_allclose(kp2d, g['kpts_2d'], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(kp3d, g['kpts_3d'], rtol=0, atol=1e-3)
+    raws = json.loads(str(g['raw_txt']))
+    for p in paths:
+        rec[p]['K'] = g['K']
+        rec[p]['raw_txt_format'] = raws[p]
+    rec = ego.post_process(rec, alpha_mode='proj', save_dict={'flag': True, 'save_dir': str(tmp_path)})
+    al = np.concatenate([rec[p]['alphas'] for p in paths])
+    eu = np.concatenate([rec[p]['euler_angles'] for p in paths])
+    # AOS sees a prediction only through (1 + cos(delta alpha)) / 2 (evaluate_object_3d_offline.cpp:547-548)
+    np.testing.assert_allclose((1 + np.cos(al - g['alpha_proj'])) / 2, 1.0, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(np.cos(eu), np.cos(g['euler']), atol=2e-5)
+    np.testing.assert_allclose(np.sin(eu), np.sin(g['euler']), atol=2e-5)
+    # result lines (and the files post_process wrote): every field the reference copies from the
+    # detection is byte-equal; alpha and rotation_y are printed with 6 decimals and follow the fp32
+    # network output, so they agree to the key-point tolerance (format parity with the reference's
+    # own angles is byte-exact: tests/test_format_cpu.py)
+    want = json.loads(str(g['pred_str']))
+    for p in paths:
+        got_lines, want_lines = rec[p]['pred_str'].strip().split('\n'), want[p].strip().split('\n')
+        assert len(got_lines) == len(want_lines) == 4
+        with open(str(tmp_path / (p[:-4] + '.txt'))) as f:
+            assert f.read() == rec[p]['pred_str']
+        for la, lb in zip(got_lines, want_lines):
+            a, b = la.split(), lb.split()
+            assert len(a) == len(b) == 16
+            for i, (ta, tb) in enumerate(zip(a, b)):
+                if i in (3, 14):                            # alpha, rotation_y
+                    d = abs(float(ta) - float(tb))
+                    assert min(d, abs(d - 2 * np.pi)) < 5e-4, (i, ta, tb)
+                else:
+                    assert ta == tb, (i, ta, tb)
+    # the batched device pipeline gives the same numbers
+    res = ego.infer_crops(crops.cuda(), g['centers'], g['scales'], K=g['K'])
+    np.testing.assert_allclose(res['kpts_2d'], g['kpts_2d'], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(res['kpts_3d'], g['kpts_3d'], rtol=0, atol=1e-3)
+    np.testing.assert_allclose((1 + np.cos(res['alpha'] - g['alpha_proj'])) / 2, 1.0, rtol=0, atol=1e-6)
+
+
+def test_eval_mode_cuda_forward_always_runs_the_hip_program():
+    """There is no torch/MIOpen route for an eval-mode CUDA tensor: with autograd ENABLED (the
+    reference's validation loop, libs/trainer/trainer.py:421) HC and L still run the native program --
+    the library's launch counter advances by the program's kernel count -- and return plain
+    tensors.  CPU tensors run torch on the CPU (the reference's CPU path)."""
+    from egonet_amd import _lib
+    L = _lib.lib()
+    cfg = configs.tiny_config('coordinates')
+    net, sd = _model(cfg, 3)
+    x = synth.synth_crops(2, 3, 64, 64, seed=5).cuda()
+    with torch.no_grad():
+        want = [t.clone() for t in net(x)]
+    nops = sum(1 for m in net._hip_engine().program(x).meta if m['kind'] not in ('fork', 'join'))
+    assert torch.is_grad_enabled() and not net.training
+    c0 = L.egn_launch_count()
+    got = net(x)                                            # grad mode on
+    assert L.egn_launch_count() - c0 == nops
+    assert all(not t.requires_grad and t.grad_fn is None for t in got)
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    lif = hip_fc.get_fc_model(1, cfg, 10, 12)
+    lif.load_state_dict(synth.synth_state_dict(lif.state_dict(), seed=4))
+    lif = lif.eval().cuda()
+    c0 = L.egn_launch_count()
+    y = lif(torch.randn(9, 10).cuda())                      # grad mode on
+    assert L.egn_launch_count() - c0 == 6 + 1 and not y.requires_grad      # input relayout + six fused GEMMs
+    c0 = L.egn_launch_count()
+    net.cpu()(x.cpu())
+    assert L.egn_launch_count() == c0                       # CPU tensors never touch the library
+
+
+def test_engine_notices_every_weight_and_buffer_change():
+    """The packed blob folds ALL parameters and BatchNorm buffers.  A change that leaves the FIRST
+    parameter alone -- torch-autograd fine-tuning with freeze_layers: ['conv1', ...]
+    (KITTI_train_IGRs_Ped.yml), a BatchNorm running-stat update -- must still rebuild it, and
+    .train() drops the programs."""
+    cfg = configs.tiny_config('coordinates')
+    net, sd = _model(cfg, 3)
+    x = synth.synth_crops(2, 3, 64, 64, seed=5).cuda()
+    y0 = net(x)[0].clone()
+    eng = net._engine
+    assert eng is not None and len(eng.programs) == 1
+    with torch.no_grad():                                   # what an optimizer step / BN update does
+        net.stage3[0].branches[1][0].conv1.weight.mul_(1.5)
+        net.stage2[0].branches[0][0].bn1.running_mean.add_(0.3)
+    y1 = net(x)[0].clone()
+    assert float((y1 - y0).abs().max()) > 1e-4
+    fresh, _ = _model(cfg, 3)
+    fresh.load_state_dict(net.state_dict())
+    np.testing.assert_array_equal(fresh(x)[0].cpu().numpy(), y1.cpu().numpy())
+    net.train()
+    assert net._engine is None                              # SURVEY 8(b): dropped on .train()
+    net.eval()
+    np.testing.assert_array_equal(net(x)[0].cpu().numpy(), y1.cpu().numpy())
+    # ... and an nn.DataParallel-style shallow replica shares the programs but not the staleness
+    import copy
+    rep = copy.copy(net)
+    np.testing.assert_array_equal(rep(x)[0].cpu().numpy(), y1.cpu().numpy())
 
 
 def test_program_timing_and_graph_replay():

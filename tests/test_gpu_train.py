@@ -83,7 +83,9 @@ def test_lifter_gradients_full_size_vs_oracle():
 
 def test_graphed_lifter_step_equals_eager_steps():
     """The whole iteration captured as one hipGraph (egonet_amd/graph.py): replays give
-    bit-identical parameters to eager steps -- the Adam step counter lives on the device."""
+    bit-identical parameters to eager steps -- the Adam step counter lives on the device -- and
+    the warm-up iterations of the capture leave no trace (weights, moments, step counter,
+    BatchNorm buffers are restored: the first replay is iteration 1)."""
     from egonet_amd.graph import GraphedStep
     cfg = configs.tiny_config()
     cfg['FCModel']['dropout'] = 0.0
@@ -97,14 +99,19 @@ def test_graphed_lifter_step_equals_eager_steps():
         net = net.cuda().train()
         tr = LifterTrainStep(net, lr=1e-3)
         if graphed:
-            g = GraphedStep(tr, xs[0], ys[0], warmup=2)          # 2 real iterations on batch 0
+            before = {k: v.clone() for k, v in net.state_dict().items()}
+            side = tr.wgrad_stream
+            g = GraphedStep(tr, xs[0], ys[0], warmup=2)          # 2 warm-up iterations on batch 0, undone
+            assert tr.flat.t == 0 and float(tr.flat.m.abs().max()) == 0.0
+            for k, v in net.state_dict().items():
+                assert torch.equal(v, before[k]), k
             losses = [float(g(xs[i], ys[i]).item()) for i in range(1, 6)]
+            g.close()
+            assert tr.wgrad_stream is side                       # handed back for eager steps
         else:
-            for _ in range(2):
-                tr.step(xs[0], ys[0])
             losses = [float(tr.step(xs[i], ys[i]).item()) for i in range(1, 6)]
         nets.append((net, losses, tr.flat.t))
-    assert nets[0][2] == nets[1][2] == 7
+    assert nets[0][2] == nets[1][2] == 5
     np.testing.assert_allclose(nets[0][1], nets[1][1], rtol=1e-12)     # the loss sum uses atomics: order varies
     for (k, a), (_, b) in zip(nets[0][0].state_dict().items(), nets[1][0].state_dict().items()):
         assert torch.equal(a, b), k
@@ -122,3 +129,80 @@ def test_lifter_training_reduces_loss_with_dropout():
     for _ in range(60):
         last = float(tr.step(x, y).item())
     assert np.isfinite(last) and last < 0.5 * first
+
+
+def test_graphed_step_follows_the_lr_schedule():
+    """MultiStepLR changes trainer.lr between iterations (egonet_amd/trainer.py): the replayed graph
+    reads the learning rate from device memory, refreshed by GraphedStep.__call__."""
+    from egonet_amd.graph import GraphedStep
+    cfg = configs.tiny_config()
+    cfg['FCModel']['dropout'] = 0.0
+    gen = torch.Generator().manual_seed(2)
+    xs = torch.randn(4, 32, 10, generator=gen).cuda()
+    ys = torch.randn(4, 32, 12, generator=gen).cuda()
+    sds = []
+    for graphed in (False, True):
+        net = FCmodel.get_fc_model(1, cfg, 10, 12)
+        net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=4))
+        net = net.cuda().train()
+        tr = LifterTrainStep(net, lr=1e-3)
+        step = GraphedStep(tr, xs[0], ys[0]) if graphed else tr.step
+        for i in range(4):
+            if i == 2:
+                tr.lr = 2.5e-4          # scheduler milestone
+            step(xs[i], ys[i])
+        sds.append({k: v.clone() for k, v in net.state_dict().items()})
+    for k in sds[0]:
+        assert torch.equal(sds[0][k], sds[1][k]), k
+
+
+@pytest.mark.parametrize('batch', [30, 4097, 7])      # (2-sample BatchNorm is too ill-conditioned to compare)
+def test_lifter_step_ragged_batch_sizes(batch):
+    """The reference's DataLoader has no drop_last (trainer.py:113-125): the tail batch of an epoch
+    has any size.  Loss and gradients against the CPU oracle."""
+    cfg = configs.tiny_config()
+    cfg['FCModel']['dropout'] = 0.0
+    net = FCmodel.get_fc_model(1, cfg, 10, 12)
+    sd = synth.synth_state_dict(net.state_dict(), seed=5)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(batch)
+    x, y = torch.randn(batch, 10, generator=g), torch.randn(batch, 12, generator=g)
+    orc = LifterTrainOracle(sd, lr=1e-3)
+    want_loss = orc.step(x, y)
+    want = orc.grads()
+    net = net.cuda().train()
+    tr = LifterTrainStep(net, lr=1e-3)
+    loss = tr.step(x.cuda(), y.cuda(), update=False)
+    assert abs(float(loss.item()) - want_loss) < 2e-5 * max(1.0, want_loss)
+    named = dict(net.named_parameters())
+    for k, gw in want.items():
+        if _is_dead_bias(k):
+            continue
+        scale = float(gw.abs().max())
+        np.testing.assert_allclose(named[k].grad.cpu().numpy(), gw.numpy(), rtol=0, atol=3e-4 * scale + 1e-7,
+                                   err_msg=k)
+    with pytest.raises(ValueError):
+        tr.step(x[:1].cuda(), y[:1].cuda())          # BatchNorm1d cannot train on one sample (torch raises too)
+
+
+def test_lifter_inference_after_native_training_uses_the_updated_weights():
+    """Eval-mode forwards between native steps (eval_during, EgoNet.L after fine-tuning) must see the
+    weights and BatchNorm statistics the HIP kernels wrote through raw pointers."""
+    cfg = configs.tiny_config()
+    cfg['FCModel']['dropout'] = 0.0
+    net = FCmodel.get_fc_model(1, cfg, 10, 12)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=6))
+    net = net.cuda()
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(32, 10, generator=g).cuda(), torch.randn(32, 12, generator=g).cuda()
+    y0 = net.eval()(x).clone()
+    tr = LifterTrainStep(net.train(), lr=1e-2)
+    for _ in range(3):
+        tr.step(x, y)
+        y1 = net.eval()(x).clone()                   # eval between steps, grad mode on
+        net.train()
+    assert float((y1 - y0).abs().max()) > 1e-3
+    fresh = FCmodel.get_fc_model(1, cfg, 10, 12)
+    fresh.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    want = fresh.eval()(x.cpu())                     # torch on the CPU with the trained weights
+    np.testing.assert_allclose(y1.cpu().numpy(), want.detach().numpy(), atol=2e-5)

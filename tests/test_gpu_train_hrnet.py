@@ -158,13 +158,15 @@ def test_graphed_hrnet_step_equals_eager_steps():
         net, _ = _tiny_model(cfg, seed=9)
         tr = HRNetTrainStep(net, lr=1e-3)
         if graphed:
-            g = GraphedStep(tr, xs[0], tg[0], jt[0], warmup=1)
+            before = {k: v.clone() for k, v in net.state_dict().items()}
+            g = GraphedStep(tr, xs[0], tg[0], jt[0], warmup=1)       # the warm-up iteration is undone
+            for k, v in net.state_dict().items():
+                assert torch.equal(v, before[k]), k
             losses = [float(g(xs[i], tg[i], jt[i]).item()) for i in range(1, 4)]
         else:
-            tr.step(xs[0], tg[0], jt[0])
             losses = [float(tr.step(xs[i], tg[i], jt[i]).item()) for i in range(1, 4)]
         out.append((net, losses, tr.flat.t))
-    assert out[0][2] == out[1][2] == 4
+    assert out[0][2] == out[1][2] == 3
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-12)       # the loss sum uses atomics: order varies
     for (k, a), (_, b) in zip(out[0][0].state_dict().items(), out[1][0].state_dict().items()):
         assert torch.equal(a, b), k

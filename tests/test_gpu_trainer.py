@@ -42,8 +42,9 @@ class _LiftSet(torch.utils.data.Dataset):
 
     def __init__(self, n=512):
         g = torch.Generator().manual_seed(0)
+        w = torch.randn(10, 12, generator=g) * 0.5          # drawn first: the same map for every n
         self.x = torch.randn(n, 10, generator=g)
-        self.y = self.x @ torch.randn(10, 12, generator=g) * 0.5
+        self.y = self.x @ w
 
     def get_input_output_size(self):
         return 10, 12
@@ -109,14 +110,16 @@ def test_train_runs_the_hc_loop_with_metric_callback_and_snapshot(tmp_path):
     optim, sche = trainer.prepare_optim(net, cfg)
     seen = []
 
-    def metric(prediction, meta, cfgs):
+    def metric(prediction, meta, cfgs):              # (avg_acc, cnt, others) like get_distance_src
         maps, coords = prediction
         seen.append((tuple(maps.shape), tuple(coords.shape), tuple(meta['transformed_joints'].shape)))
+        return 0.25 * len(seen), len(maps), None
 
     lg, h = _logger()
     rec = trainer.train(_CropSet(), net, None, optim, sche, cfg, lg, metric_func=metric)
     assert len(rec['loss']) == 4 and all(np.isfinite(rec['loss']))
-    assert seen[0] == ((4, 5, 16, 16), (4, 5, 2), (4, 5, 3)) and len(seen) == 4
+    assert seen[0] == ((4, 5, 16, 16), (4, 5, 2), (4, 5, 3)) and len(seen) == 4     # every batch
+    assert any('metric 0.375000 (running mean over 8)' in l for l in h.lines)         # epoch 1: (0.25*4 + 0.5*4) / 8
     assert not torch.equal(net.conv1.weight.detach(), before)
     snap = torch.load(str(tmp_path / 'test_2.pth'))
     assert list(snap) == list(net.state_dict()) and int(snap['bn1.num_batches_tracked']) == 4
@@ -138,3 +141,66 @@ def test_train_runs_the_hc_loop_with_metric_callback_and_snapshot(tmp_path):
     cfg2['heatmapModel']['loss_spec_list'] = ['sl1', 'l1', 'None']
     with pytest.raises(NotImplementedError):
         trainer.make_step(net, cfg2)
+
+
+def test_train_cascade_with_a_ragged_tail_batch():
+    """len(dataset) % batch_size is anything with the reference's DataLoader (no drop_last,
+    trainer.py:113-125): 333 = 5 x 64 + 13."""
+    cfg = _train_cfg(configs.tiny_config(), epochs=2, batch=64)
+    cfg['FCModel']['dropout'] = 0.0
+    lg, h = _logger()
+    out = trainer.train_cascade(_LiftSet(333), None, cfg, lg)
+    (idx, losses), = out['record']
+    assert len(losses) == 2 * 3 and all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert int(out['cascade'][0].state_dict()['batch_norm1.num_batches_tracked']) == 12
+
+
+class _Evaluator(object):
+    def __init__(self):
+        self.n, self.err = 0, 0.0
+
+    def update(self, prediction, ground_truth=None, meta_data=None):
+        p = prediction if isinstance(prediction, np.ndarray) else prediction.detach().cpu().numpy()
+        g = ground_truth if isinstance(ground_truth, np.ndarray) else ground_truth.cpu().numpy()
+        self.n += len(p)
+        self.err += float(np.abs(p - g).sum())
+
+    def report(self, logger):
+        logger.info('MAE %.6f over %d' % (self.err / max(self.n, 1) / 12, self.n))
+
+
+def test_evaluate_runs_the_hip_program_like_the_reference_loop():
+    """trainer.evaluate (reference trainer.py:395-513): model.eval() and model(data) with autograd on --
+    the HIP program (launch counter), the caller's criterion and evaluator; and eval_during inside
+    train() uses it between native steps with the weights of that moment."""
+    from egonet_amd import _lib
+    L = _lib.lib()
+    cfg = _train_cfg(configs.tiny_config(), epochs=1, batch=64)
+    cfg['FCModel']['dropout'] = 0.0
+    cfg['testing_settings'] = {'batch_size': 100, 'num_threads': 0, 'shuffle': False, 'unnormalize': False,
+                               'apply_dropout': False}
+    net = FCmodel.get_fc_model(1, cfg, 10, 12)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=3))
+    net = net.cuda().train()
+    ds = _LiftSet(250)
+    lg, h = _logger()
+    ev = _Evaluator()
+    crit = torch.nn.MSELoss()
+    c0 = L.egn_launch_count()
+    loss = trainer.evaluate(ds, net, lambda p, t, w, m: crit(p, t), cfg, lg, ev)
+    assert L.egn_launch_count() - c0 == 3 * 7 and not net.training          # 3 batches x (relayout + 6 GEMMs)
+    assert ev.n == 250 and any(l.startswith('MAE') for l in h.lines)
+    want = float(crit(net.cpu().eval()(ds.x), ds.y))                         # torch on the CPU, same weights
+    assert abs(loss - want) < 1e-5 * max(1.0, want)
+    # eval_during: validation between native steps sees the updated weights
+    net = net.cuda()
+    cfg['training_settings'].update(eval_during=True, eval_every=2, eval_start_epoch=0, total_epochs=2)
+    optim, sche = trainer.prepare_optim(net, cfg)
+    lg, h = _logger()
+    trainer.train(_LiftSet(512), net, lambda p, t, w, m: crit(p, t), optim, sche, cfg, lg, valid_dataset=ds,
+                  evaluator=_Evaluator())
+    vals = [float(l.split('loss ')[1].split()[0]) for l in h.lines if l.startswith('Validation')]
+    assert len(vals) == 6 and vals[-1] < vals[0]                             # batches 2, 4, 6 of both epochs
+    lg, h = _logger()
+    trainer.train(_LiftSet(128), net, None, optim, sche, cfg, lg, valid_dataset=ds)      # nothing to evaluate with
+    assert any('no validation during training' in l for l in h.lines)

@@ -72,3 +72,28 @@ def test_lifter_mirror_cpu_and_training_mode():
     y.sum().backward()
     assert net.w1.weight.grad is not None
     assert len(FCmodel.get_cascade()) == 0
+
+
+def test_pixel_shuffle_and_angle_heads_match_the_reference_on_cpu():
+    """The remaining head variants (reference hrnet.py:373-422, 598-611): same state_dict keys in the
+    same order, and the module's CPU forward reproduces the reference's outputs
+    (tests/golden/hrnet_tiny_pixshuf.npz, hrnet_tiny_angle.npz)."""
+    import json
+    import numpy as np
+    from conftest import golden, fixture_cfg, sd_crc, require_same_rng
+    from egonet_amd import synth
+    from egonet_amd.model.heatmapModel import hrnet
+    for tag, shape in (('tiny_pixshuf', (2, 5, 32, 32)), ('tiny_angle', (3, 2))):
+        g = golden('hrnet_%s.npz' % tag)
+        cfg = fixture_cfg(g)
+        net = hrnet.get_pose_net(cfg, is_train=False).eval()
+        assert list(net.state_dict()) == json.loads(str(g['keys']))
+        sd = synth.synth_state_dict(net.state_dict(), seed=3)
+        require_same_rng(sd_crc(sd), g['sd_crc'], 'weights')
+        net.load_state_dict(sd)
+        iw, ih = cfg['heatmapModel']['input_size']
+        x = synth.synth_crops(int(g['n']), 3, ih, iw, seed=5)
+        with torch.no_grad():
+            out = net(x)
+        assert tuple(out.shape) == shape == g['out'].shape
+        np.testing.assert_allclose(out.numpy(), g['out'], rtol=0, atol=1e-5)
