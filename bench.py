@@ -12,6 +12,16 @@ soft-argmax", extended by the lift so that the number is the headline metric
 crops/s "heatmap+decode+lift").  Crops shard across ranks with no data-path
 collective (weak scaling, B per GPU fixed).
 
+The same run then measures the two TRAINING configurations of BASELINE.json, each with its
+own warm-up + timed steps bracketed by barrier + synchronize (max over ranks), and adds them to
+the same JSON line (``--no-train`` skips them):
+  train_hc      configs[3]: HRNet-W48 forward + backward + Adam, 32 crops/GPU, native HIP step,
+                RCCL all-reduce of the flat gradient when N > 1 (whole-job crops/s)
+  train_lifter  configs[2]: FC lifter forward + backward + Adam, batch 4096 (N = 1 only)
+each with ms/step, algorithmic TFLOP/s, the dominant conv/GEMM kernel's roofline fraction
+(hipEvents around every launch in one extra single-stream step) and the CPU training oracle's
+rate on a bounded sample.
+
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
   roofline      the dominant kernel (by time; keyed by the kernel SYMBOL that
                 rocprofv3 prints) of the backbone, measured live with hipEvents
@@ -50,6 +60,9 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-seconds', type=float, default=15.0)
     p.add_argument('--profile-json', default='', help='write the per-op timing table here')
+    p.add_argument('--no-train', action='store_true', help='skip the training blocks (configs 3 and 4)')
+    p.add_argument('--train-batch', type=int, default=32, help='crops per GPU of the train_hc block')
+    p.add_argument('--lifter-batch', type=int, default=4096)
     return p.parse_args()
 
 
@@ -162,6 +175,150 @@ def cpu_baseline(cfg, hc_sd, l_sd, stats, head, seconds):
                       % (reps, b, head, best_t, avail, dt)}
 
 
+GFLOP_FWD_PER_CROP = 42.035      # HRNet-W48 coordinates head, forward, 2*MAC
+
+
+def _timed(step, steps, warmup, dev, dist):
+    """warmup untimed + `steps` timed calls, barrier + synchronize on both sides, max over ranks."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt / steps, out
+
+
+def _dominant(timing):
+    """(symbol, launches, avg_us, tflops, share of the timed launches) of the kernel symbol with the
+    largest total time among the hipEvent-bracketed conv / GEMM launches of one step."""
+    torch.cuda.synchronize()
+    by = {}
+    for cfg, flops, e0, e1 in timing:
+        a = by.setdefault(_symbol(cfg) or 'cfg%d' % cfg, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += e0.elapsed_time(e1)
+        a[2] += flops
+    total = sum(a[1] for a in by.values())
+    name, (n, ms, fl) = max(by.items(), key=lambda kv: kv[1][1])
+    tf = fl / (ms * 1e-3) / 1e12
+    return {'bound': 'mfma', 'kernel': name, 'achieved': tf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': tf / PEAK_FP32_MFMA_TFLOPS, 'launches': n, 'avg_us': ms * 1e3 / n,
+            'share_of_conv_time': ms / total if total else 0.0, 'conv_ms_per_step': total,
+            'traffic': None}
+
+
+def train_hc_block(args, world, rank, dev, dist):
+    """BASELINE configs[3]: train_IGRs HRNet-W48 fwd + bwd + Adam (libs/trainer/trainer.py:183-209)."""
+    from egonet_amd import configs, parallel, synth
+    from egonet_amd.model.heatmapModel import hrnet
+    from egonet_amd.train_hrnet import HRNetTrainStep
+    B = args.train_batch
+    cfg = configs.w48_config('coordinates')
+    net = hrnet.get_pose_net(cfg, is_train=False)
+    sd = synth.synth_state_dict(net.state_dict(), seed=1)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    if dist:
+        parallel.broadcast_module(net, src=0)
+    tr = HRNetTrainStep(net, lr=1e-3, grad_sync=parallel.FlatGradSync(32.0) if dist else None)
+    g = torch.Generator().manual_seed(100 + rank)
+    x = synth.synth_crops(B, 3, 256, 256, seed=50 + rank).to(dev)
+    tgt = torch.rand(B, 33, 64, 64, generator=g).to(dev)
+    jt = (torch.rand(B, 33, 2, generator=g) * 256).to(dev)
+    sec, loss = _timed(lambda: tr.step(x, tgt, jt), args.steps, max(args.warmup, 2), dev, dist)
+    out = None
+    if rank == 0:
+        # one extra step on ONE stream with hipEvents around every forward / data-gradient conv
+        side, tr.wgrad_stream = tr.wgrad_stream, None
+        tr.timing = []
+        tr.step(x, tgt, jt)
+        roof = _dominant(tr.timing)
+        tr.timing, tr.wgrad_stream = None, side
+        crops = B * world
+        out = {'metric': 'hc_train_crops_per_sec', 'value': crops / sec, 'unit': 'crops/s', 'n_gpus': world,
+               'steps': args.steps, 'warmup': max(args.warmup, 2), 'ms_per_step': sec * 1e3, 'scaling': 'weak',
+               'dtype': 'f32', 'data': 'synthetic', 'loss': float(loss.item()),
+               'algorithmic_tflops_per_gpu': 3 * GFLOP_FWD_PER_CROP * B / sec / 1e3,
+               'frac_of_fp32_peak': 3 * GFLOP_FWD_PER_CROP * B / sec / 1e3 / PEAK_FP32_MFMA_TFLOPS,
+               'roofline': roof,
+               'config': {'workload': 'configs[3]: train_IGRs HRNet-W48 256x256 fwd+bwd+Adam, composite loss '
+                                      '(mse + 0.1 l1), batch=%d crops/GPU' % B, 'global_batch': crops,
+                          'parallelism': 'dp%d, one flat-gradient all-reduce per step (RCCL)' % world
+                          if world > 1 else 'dp1'}}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.hrnet_train_oracle import HRNetTrainOracle
+            nb = 2
+            torch.set_num_threads(min(16, os.cpu_count() or 1))
+            orc = HRNetTrainOracle(sd, cfg, lr=1e-3)
+            t0 = time.time()
+            orc.step(x[:nb].cpu(), tgt[:nb].cpu(), jt[:nb].cpu())
+            dt = time.time() - t0
+            out['cpu_baseline'] = {'value': nb / dt, 'unit': 'crops/s', 'cores': torch.get_num_threads(),
+                                   'kind': 'port', 'sample': '1 iteration of a %d-crop batch (torch autograd fp32 '
+                                   'training oracle), %.1f s' % (nb, dt)}
+    del tr, net
+    torch.cuda.empty_cache()
+    return out
+
+
+def train_lifter_block(args, dev):
+    """BASELINE configs[2]: train_lifting FCModel fwd + bwd + Adam, batch 4096, one GPU."""
+    from egonet_amd import configs, synth
+    from egonet_amd.model import FCmodel
+    from egonet_amd.train_lifter import LifterTrainStep
+    B = args.lifter_batch
+    cfg = configs.w48_config()
+    net = FCmodel.get_fc_model(1, cfg, 66, 96)               # dropout 0.5 as shipped
+    sd = synth.synth_state_dict(net.state_dict(), seed=2)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(0)
+    x, y = torch.randn(B, 66, generator=g), torch.randn(B, 96, generator=g)
+    net = net.to(dev).train()
+    tr = LifterTrainStep(net, lr=1e-3)
+    xd, yd = x.to(dev), y.to(dev)
+    steps = max(args.steps, 50)
+    sec, loss = _timed(lambda: tr.step(xd, yd), steps, max(args.warmup, 5), dev, None)
+    side, tr.wgrad_stream = tr.wgrad_stream, None
+    tr.timing = []
+    tr.step(xd, yd)
+    roof = _dominant(tr.timing)
+    tr.timing, tr.wgrad_stream = None, side
+    lin = [m for m in net.modules() if isinstance(m, torch.nn.Linear)]
+    fl = sum(2.0 * B * m.in_features * m.out_features * (2 if i == 0 else 3) for i, m in enumerate(lin))
+    out = {'metric': 'lifter_train_sets_per_sec', 'value': B / sec, 'unit': 'sets/s', 'n_gpus': 1, 'steps': steps,
+           'warmup': max(args.warmup, 5), 'ms_per_step': sec * 1e3, 'dtype': 'f32', 'data': 'synthetic',
+           'loss': float(loss.item()), 'gemm_gflop_per_step': fl / 1e9, 'algorithmic_tflops': fl / sec / 1e12,
+           'frac_of_fp32_peak': fl / sec / 1e12 / PEAK_FP32_MFMA_TFLOPS, 'roofline': roof,
+           'config': {'workload': 'configs[2]: train_lifting FCModel(66->96, 1024 x 2 blocks) fwd+bwd+Adam, '
+                                  'batch=%d, dropout 0.5' % B}}
+    if not args.no_cpu_baseline:
+        from oracle.lifter_train_oracle import LifterTrainOracle
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        orc = LifterTrainOracle(sd, lr=1e-3)
+        orc.step(x, y)
+        t0 = time.time()
+        for _ in range(3):
+            orc.step(x, y)
+        dt = (time.time() - t0) / 3
+        out['cpu_baseline'] = {'value': B / dt, 'unit': 'sets/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                               'sample': '3 iterations of one %d-set batch (torch autograd fp32 training oracle, '
+                                         'dropout off)' % B}
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -271,6 +428,16 @@ def main():
                            'symbols': syms}, f, indent=1)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(cfg, hc_sd, l_sd, ego.LS, args.head, args.cpu_seconds)
+    # ---- the training configurations, same run, their own timed regions ----
+    if not args.no_train:
+        del ego, crops
+        torch.cuda.empty_cache()
+        hc_block = train_hc_block(args, world, rank, dev, dist)
+        if rank == 0:
+            result['train_hc'] = hc_block
+            if world == 1:
+                result['train_lifter'] = train_lifter_block(args, dev)
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if dist:
         dist.barrier()

@@ -221,9 +221,17 @@ class _Tape(object):
     def _conv_launch(self, x, wp, shift, y, n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, act):
         key = (n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, False, False)
         cfg = tuner.choose(self.dev, key)
+        tm = self.o.timing
+        if tm is not None:         # bench.py: hipEvents around every forward / data-gradient conv launch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.dev))
         _lib.check(self.L.egn_conv2d_f32(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(self.o.ones), _lib.ptr(shift), None,
                                          _lib.ptr(y), n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, act,
                                          0, cfg, self.st), 'conv')
+        if tm is not None:
+            e1.record(torch.cuda.current_stream(self.dev))
+            ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+            tm.append((cfg, 2.0 * n * ho * wo * cout * cin * kh * kw, e0, e1))
 
     def _wgrad(self, x, xd, dy, cs_out, weight, stride, pad):
         cout, cin, kh, kw = weight.shape
@@ -493,6 +501,7 @@ class HRNetTrainStep(object):
         self.packs = PackedFilters(self.dev)
         self.last_maps = self.last_coords = None
         self.debug_hook = None        # tests/train_debug.py: per-layer checks of the BatchNorm backward
+        self.timing = None            # bench.py: a list collects (cfg, flops, start, end) per conv launch
 
     def wgrad_ws(self, nbytes):
         if self._wgrad_ws is None or self._wgrad_ws.numel() * 4 < nbytes:

@@ -70,6 +70,7 @@ class LifterTrainStep(object):
         self.wgrad_stream = torch.cuda.Stream(device=self.dev) \
             if os.environ.get('EGONET_AMD_WGRAD_STREAM', '1') != '0' else None
         self._side_used = False
+        self.timing = None            # bench.py: a list collects (cfg, flops, start, end) per GEMM launch
 
     # -- helpers -----------------------------------------------------------
     def _buf(self, name, *shape):
@@ -106,8 +107,15 @@ class LifterTrainStep(object):
         nchw = 1 if cout % 4 else 0
         key = (rows, 1, 1, k, ld_a, cout, cout, 1, 1, 1, 0, False, bool(nchw))
         cfg = tuner.choose(self.dev, key)
+        tm = self.timing
+        if tm is not None:         # bench.py: hipEvents around every forward / data-gradient GEMM launch
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.dev))
         _lib.check(L.egn_conv2d_f32(_lib.ptr(a), _lib.ptr(wp), _lib.ptr(sc), _lib.ptr(sh), None, _lib.ptr(out),
                                     rows, 1, 1, k, ld_a, cout, cout, 1, 1, 1, 0, 0, nchw, cfg, self._st()), 'gemm')
+        if tm is not None:
+            e1.record(torch.cuda.current_stream(self.dev))
+            tm.append((cfg, 2.0 * rows * k * cout, e0, e1))
         return out
 
     def _wgrad(self, a, ld_a, inf, dz, ld_dz, outf, rows, grad_w):
