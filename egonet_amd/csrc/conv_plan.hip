@@ -75,6 +75,11 @@ static const ConvConfig kConfigs[] = {
     {48, 4, 1, 1, 3, 6, 0x20, 5},  // no DMA / no input transform / no epilogue memory ops / no barriers
     {49, 4, 1, 1, 3, 6, 0x30, 5},
     {50, 4, 1, 1, 3, 6, 0x40, 5},
+    {51, 8, 1, 1, 3, 4, 2, 5},     // the 8-wave Winograd kernel (two per SIMD, frequency halves): 16 x 16 tile
+    {52, 8, 1, 1, 3, 4, 3, 5},     // ... four 8 x 8 images
+    {53, 8, 1, 1, 3, 4, 0x12, 5},  // timing ablations of 51
+    {54, 8, 1, 1, 3, 4, 0x22, 5},
+    {55, 8, 1, 1, 3, 4, 0x32, 5},
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -104,7 +109,8 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (cfg < 1 || cfg > kNumConfigs || !buf || len < 8) return EGN_E_BADARG;
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 5)
-    snprintf(buf, len, "void conv_wino_kernel<%s, %d>(ConvArgs)", (c.bi & 15) == 1 ? "8, 8, 4" : "16, 16, 1", c.bi >> 4);
+    snprintf(buf, len, "void conv_wino%s_kernel<%s, %d>(ConvArgs)", (c.bi & 2) ? "8" : "", (c.bi & 1) ? "8, 8, 4" : "16, 16, 1",
+             c.bi >> 4);
   else if (c.dma == 4 && c.bi == 2)
     snprintf(buf, len, "conv_c48t_kernel(ConvArgs)");
   else if (c.dma == 4 && c.bi == 1)
@@ -151,9 +157,9 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % EGN_CK || a.cs_in != a.Cin ||
         a.Cout % 48 || a.cs_out != a.Cout || a.out_nchw || (a.Ho & 1) || (a.Wo & 1))
       return false;
-    if ((cf.bi & 15) == 1) { a.TH = 8; a.TW = 8; a.TNB = 4; }
+    if (cf.bi & 1) { a.TH = 8; a.TW = 8; a.TNB = 4; }
     else { a.TH = 16; a.TW = 16; a.TNB = 1; }
-    if ((cf.bi & 15) == 1 && (a.Ho > 8 || a.Wo > 8)) return false;   // the batched variant is for the 8 x 8 maps
+    if ((cf.bi & 1) && (a.Ho > 8 || a.Wo > 8)) return false;   // the batched variant is for the 8 x 8 maps
     a.HH = a.TH + 2; a.HW = a.TW + 2;
     a.npix = a.TNB * a.HH * a.HW; a.npixp = (a.npix + 15) & ~15; a.tps = 16;
     a.tiles_x = (a.Wo + a.TW - 1) / a.TW;

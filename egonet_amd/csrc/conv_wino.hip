@@ -419,6 +419,325 @@ __global__ __launch_bounds__(WN_NTH, 1) void conv_wino_kernel(ConvArgs a) {
 #undef WINO_ISSUE
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv_wino8_kernel -- the same algorithm with EIGHT waves (two per SIMD).
+//
+// What the 4-wave kernel loses (ablations, profiles/r2_wino_ablation.txt): with one wave per SIMD every
+// DMA issue (~19 per K step), every ds_read wait and the input transform stall the matrix pipe, because
+// nothing else can issue MFMAs on that SIMD -- 55..65 us where the MFMA + B-read loop alone takes 40.
+// 192 accumulator registers per wave forbid a second wave.  So the 16 frequencies of an m-tile are
+// split between TWO waves on the same tile: wave (mt, fh) owns frequency rows {2fh, 2fh+1} -- 8
+// frequencies, 96 accumulators, ~230 registers -> 2 waves per SIMD, and one wave's DMA / transform /
+// waits hide under its partner's MFMAs.  Per K step a wave reads 3 patch rows (12 ds_read_b128),
+// forms its two rows of V (8 of the 16 values), reads 24 B fragments, issues 96 MFMAs and 9-10 DMAs.
+// The output transform needs all four frequency rows: Y0 = t0 + t1 + t2, Y1 = t1 - t2 - t3 with
+// t_i = (row i of M) A.  Wave fh = 0 keeps t0 + t1 (its share of Y0) and SENDS t1 (Y1's); wave
+// fh = 1 keeps -t2 - t3 and sends t2 -- 24 floats per lane through LDS, in the U stage buffer the
+// last K step has just consumed (8 waves x 6 KB = exactly its 48 KB), between two barriers; then
+// each wave finishes and stores the output rows a = fh of its tile.  Per item: nchunk + 2 barriers.
+template <int TH, int TW, int TNB, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvArgs a) {
+  using G = WinoGeom<TH, TW, TNB>;
+  constexpr int NTH = 512;
+  constexpr int SLOTS = EGN_CKQ * G::PLANE;                 // multiple of 64: whole waves
+  constexpr int IT = (SLOTS + NTH - 1) / NTH;               // halo DMA instructions (the last one partial)
+  constexpr int BUF = SLOTS;
+  constexpr int UIT = WN_USLOTS / NTH;                      // 6
+  constexpr int NPIECE = IT + UIT;                          // 10
+  static_assert(SLOTS % 64 == 0 && WN_USLOTS % NTH == 0, "whole-wave DMA pieces");
+  extern __shared__ float4 smem[];
+  float4* sU = smem;                  // [2][WN_USLOTS]
+  float4* sH = smem + 2 * WN_USLOTS;  // [2][BUF]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = wave & 3;   // m-tile (16 Winograd tiles)
+  const int fh = wave >> 2;  // frequency rows {2fh, 2fh+1}
+  const int li = lane & 15;
+  const int kq = lane >> 4;
+
+  const int C = a.Cin, Co = a.Cout;
+  const int nct = Co / WN_CO;
+  const int nchunk = a.nchunk;
+
+  const unsigned long long xaddr = reinterpret_cast<unsigned long long>(a.x);
+  const unsigned long long uaddr = reinterpret_cast<unsigned long long>(a.w);
+  const u32x4 rxv = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu,
+                     (unsigned)((size_t)a.N * a.H * a.W * C * 4), 0x00020000u};
+  const u32x4 ruv = {(unsigned)uaddr, (unsigned)(uaddr >> 32) & 0xffffu,
+                     (unsigned)((size_t)nct * nchunk * WN_USLOTS * 16), 0x00020000u};
+  const unsigned out_bytes = (unsigned)((size_t)a.N * a.Ho * a.Wo * Co * 4);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, out_bytes, 0x00020000);
+
+  int hmeta[IT];
+  unsigned hq[IT];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int e = it * NTH + tid;
+    const int q = e / G::PLANE;
+    hmeta[it] = (e < SLOTS && q < EGN_CKQ) ? G::decode(e - q * G::PLANE) : -1;
+    hq[it] = (unsigned)q * 16u;
+  }
+  // patch rows fh, fh+1, fh+2 of this lane's tile: float4 index of column 0 in a halo buffer
+  int prow[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int r = fh + k;
+    prow[k] = kq * G::PLANE + G::patch_base(mt, li, r >> 1) + r * G::ROFF;
+  }
+  int og[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) og[r] = G::out_tile(mt, 4 * kq + r);
+
+  const int tiles_xy = a.tiles_x * a.tiles_y;
+  const int ntile = tiles_xy * ((a.N + TNB - 1) / TNB);
+  const int nwork = ((ntile + 7) >> 3) * nct * 8;
+
+#define W8_ITEM(Wi, TILE_, CT_)              \
+  {                                          \
+    const int x_ = (Wi)&7, q_ = (Wi) >> 3;   \
+    TILE_ = (q_ / nct) * 8 + x_;             \
+    CT_ = q_ - (q_ / nct) * nct;             \
+  }
+#define W8_DOFF(TILE_, OUT)                                                                         \
+  {                                                                                                 \
+    const int tb_ = (TILE_) / tiles_xy;                                                             \
+    const int r_ = (TILE_)-tb_ * tiles_xy;                                                          \
+    const int ty_ = r_ / a.tiles_x, tx_ = r_ - ty_ * a.tiles_x;                                     \
+    const int n0_ = tb_ * TNB, iy0_ = ty_ * TH - 1, ix0_ = tx_ * TW - 1;                            \
+    _Pragma("unroll") for (int it = 0; it < IT; ++it) {                                             \
+      const int m_ = hmeta[it];                                                                     \
+      const int n_ = n0_ + (m_ >> 16), iy_ = iy0_ + ((m_ >> 8) & 255), ix_ = ix0_ + (m_ & 255);     \
+      const bool in_ = m_ >= 0 && (TILE_) < ntile && n_ < a.N && iy_ >= 0 && iy_ < a.H && ix_ >= 0 && ix_ < a.W; \
+      OUT[it] = in_ ? (unsigned)(((n_ * a.H + iy_) * a.W + ix_) * C) * 4u + hq[it] : EGN_OOB;       \
+    }                                                                                               \
+  }
+// DMA instruction K (0 .. NPIECE-1) of a K step; a wave beyond the end of the halo image skips its
+// share of the last halo piece (wave-uniform)
+#define W8_PIECE(K, P, OFF, CT, CH)                                                                  \
+  {                                                                                                  \
+    if ((K) < IT) {                                                                                  \
+      if ((K)*NTH + wave * 64 < SLOTS)                                                               \
+        wino_dma16(rxv, wino_lds_addr(sH + (P)*BUF + wave * 64) + (K)*NTH * 16, OFF[(K) < IT ? (K) : 0], \
+                   (unsigned)(CH)*64u);                                                              \
+    } else {                                                                                         \
+      wino_dma16(ruv, wino_lds_addr(sU + (P)*WN_USLOTS + wave * 64) + ((K)-IT) * NTH * 16, (unsigned)tid * 16u, \
+                 (unsigned)(((CT)*nchunk + (CH)) * WN_USLOTS) * 16u + ((K)-IT) * NTH * 16);          \
+    }                                                                                                \
+  }
+
+  int w = blockIdx.x;
+  int tile = 0, ct = 0;
+  W8_ITEM(w, tile, ct)
+  unsigned doff[IT];
+  W8_DOFF(tile, doff)
+  if (w < nwork) {
+#pragma unroll
+    for (int k_ = 0; k_ < NPIECE; ++k_) W8_PIECE(k_, 0, doff, ct, 0)
+  }
+  int par = 0;
+  bool first = true;
+
+  const float act_lo = (a.act & EGN_ACT_MASK) == EGN_ACT_RELU ? 0.f : -__builtin_inff();
+  const bool has_res = a.res != nullptr;
+  const unsigned rowpitch = (unsigned)(a.Wo * Co) * 4u, colpitch = (unsigned)Co * 4u;
+
+  for (; w < nwork; w += gridDim.x) {
+    int tile_n = 0, ct_n = 0;
+    W8_ITEM(w + (int)gridDim.x, tile_n, ct_n)
+    const bool more = (w + (int)gridDim.x) < nwork;
+    unsigned doff_n[IT];
+    W8_DOFF(tile_n, doff_n)
+    unsigned voff[4];   // this wave's output rows: a = fh of each of its 4 tiles
+    {
+      const int tb_ = tile / tiles_xy;
+      const int r_ = tile - tb_ * tiles_xy;
+      const int ty_ = r_ / a.tiles_x, tx_ = r_ - ty_ * a.tiles_x;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = tb_ * TNB + (og[r] >> 16);
+        const int oy = ty_ * TH + 2 * ((og[r] >> 8) & 255) + fh, ox = tx_ * TW + 2 * (og[r] & 255);
+        voff[r] = (tile < ntile && n < a.N && oy < a.Ho && ox < a.Wo)
+                      ? (unsigned)(((n * a.Ho + oy) * a.Wo + ox) * Co + ct * WN_CO + li) * 4u
+                      : EGN_OOB;
+      }
+    }
+    float sc[WN_NT], sh[WN_NT];
+#pragma unroll
+    for (int nt = 0; nt < WN_NT; ++nt) {
+      sc[nt] = a.scale[ct * WN_CO + nt * 16 + li];
+      sh[nt] = a.shift[ct * WN_CO + nt * 16 + li];
+    }
+
+    f32x4 acc[8][WN_NT];
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+      for (int nt = 0; nt < WN_NT; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rv[4][2][WN_NT];  // residual of this lane's outputs: [tile r][b][nt]
+
+    for (int c = 0; c < nchunk; ++c) {
+      const bool last = c + 1 == nchunk;
+      asm volatile("" ::: "memory");
+      if constexpr (!(ABL & 8)) {
+        if (c == 0 && !first) __builtin_amdgcn_s_waitcnt(0x4078);  // vmcnt(24): all but the last item's stores
+        else __builtin_amdgcn_s_waitcnt(0x0070);                   // vmcnt(0)
+        __builtin_amdgcn_s_barrier();
+      }
+      asm volatile("" ::: "memory");
+      first = false;
+      const bool nx_issue = !(ABL & 1) && (!last || more);
+      const int nx_ct = last ? ct_n : ct, nx_ch = last ? 0 : c + 1;
+      unsigned nxo[IT];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) nxo[it] = last ? doff_n[it] : doff[it];
+#define W8_NEXT(K)                                        \
+  {                                                       \
+    __builtin_amdgcn_sched_barrier(0x0106);               \
+    if (nx_issue) W8_PIECE(K, par ^ 1, nxo, nx_ct, nx_ch) \
+    __builtin_amdgcn_sched_barrier(0x0106);               \
+  }
+      // ---- this wave's two rows of V = B^T d B ----
+      const float4* hb = sH + par * BUF;
+      f32x4 d[3][4], V[8];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          if constexpr ((ABL & 2)) d[k][cc] = f32x4{(float)lane, (float)(k + c), (float)cc, 1.f};
+          else d[k][cc] = *reinterpret_cast<const f32x4*>(&hb[prow[k] + cc]);
+        }
+      W8_NEXT(0) W8_NEXT(1)
+      static_assert(NPIECE <= 10, "2 DMA pieces at the top + one per frequency");
+      {
+        f32x4 ta[4], tb[4];
+        // fh = 0: rows (d0, d1, d2): T0 = d0 - d2, T1 = d1 + d2;  fh = 1: rows (d1, d2, d3): T2 = d2 - d1, T3 = d1 - d3
+        if (fh == 0) {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            ta[cc] = d[0][cc] - d[2][cc];
+            tb[cc] = d[1][cc] + d[2][cc];
+          }
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < 4; ++cc) {
+            ta[cc] = d[1][cc] - d[0][cc];
+            tb[cc] = d[0][cc] - d[2][cc];
+          }
+        }
+        V[0] = ta[0] - ta[2]; V[1] = ta[1] + ta[2]; V[2] = ta[2] - ta[1]; V[3] = ta[1] - ta[3];
+        V[4] = tb[0] - tb[2]; V[5] = tb[1] + tb[2]; V[6] = tb[2] - tb[1]; V[7] = tb[1] - tb[3];
+      }
+
+      // ---- 8 frequencies x 3 co sub-tiles x 4 k-steps ----
+      const float4* ub = sU + par * WN_USLOTS + (fh * 8 * EGN_CKQ + kq) * WN_CO + li;
+      f32x4 bf[2][WN_NT];
+#pragma unroll
+      for (int nt = 0; nt < WN_NT; ++nt) bf[0][nt] = *reinterpret_cast<const f32x4*>(&ub[nt * 16]);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        if (f + 1 < 8) {
+#pragma unroll
+          for (int nt = 0; nt < WN_NT; ++nt)
+            bf[(f + 1) & 1][nt] = *reinterpret_cast<const f32x4*>(&ub[(f + 1) * EGN_CKQ * WN_CO + nt * 16]);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int nt = 0; nt < WN_NT; ++nt)
+            acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[f][s], bf[f & 1][nt][s], acc[f][nt], 0, 0, 0);
+        if (2 + f < NPIECE) W8_NEXT(2 + f)
+      }
+#undef W8_NEXT
+      if (last) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) doff[it] = doff_n[it];
+        asm volatile("" ::: "memory");  // program order DMA -> residual loads (the vmcnt(24) above counts on it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned ro = (has_res && !(ABL & 4)) ? voff[r] : EGN_OOB;
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int nt = 0; nt < WN_NT; ++nt) rv[r][pb][nt] = wino_load4(rr, ro, pb * colpitch + nt * 64u);
+        }
+      }
+      par ^= 1;
+    }
+
+    // ---- output transform: this wave's frequency rows, then the exchange with the partner wave ----
+    float keep[WN_NT][4][2], send[WN_NT][4][2];
+#pragma unroll
+    for (int nt = 0; nt < WN_NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          float t0, t1;  // t of the wave's first / second frequency row, column pb of A
+          if (pb == 0) {
+            t0 = acc[0][nt][r] + acc[1][nt][r] + acc[2][nt][r];
+            t1 = acc[4][nt][r] + acc[5][nt][r] + acc[6][nt][r];
+          } else {
+            t0 = acc[1][nt][r] - acc[2][nt][r] - acc[3][nt][r];
+            t1 = acc[5][nt][r] - acc[6][nt][r] - acc[7][nt][r];
+          }
+          // fh = 0: rows 0, 1: keep t0 + t1 (Y0), send t1 (Y1);  fh = 1: rows 2, 3: keep -t2 - t3 (Y1), send t2 (Y0)
+          keep[nt][r][pb] = fh == 0 ? t0 + t1 : -t0 - t1;
+          send[nt][r][pb] = fh == 0 ? t1 : t0;
+        }
+    {
+      // the U buffer of the last K step (par ^ 1 after the toggle) is free once every wave is past its
+      // MFMAs: barrier, write, barrier, read the partner's
+      float4* xch = sU + (par ^ 1) * WN_USLOTS;
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int k4 = 0; k4 < 6; ++k4) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int idx = k4 * 4 + e;  // (nt*4 + r)*2 + pb
+          v[e] = send[idx >> 3][(idx >> 1) & 3][idx & 1];
+        }
+        *reinterpret_cast<f32x4*>(&xch[(wave * 6 + k4) * 64 + lane]) = v;
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int k4 = 0; k4 < 6; ++k4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&xch[((wave ^ 4) * 6 + k4) * 64 + lane]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int idx = k4 * 4 + e;
+          keep[idx >> 3][(idx >> 1) & 3][idx & 1] += v[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < WN_NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          float v = keep[nt][r][pb] * sc[nt] + sh[nt] + rv[r][pb][nt];
+          v = fmaxf(v, act_lo);
+          wino_store4(ry, ((ABL & 4) && v != 12345.678f) ? EGN_OOB : voff[r], pb * colpitch + nt * 64u, v);
+        }
+    tile = tile_n;
+    ct = ct_n;
+  }
+#undef W8_ITEM
+#undef W8_DOFF
+#undef W8_PIECE
+}
+
 template <int TH, int TW, int TNB, int ABL = 0>
 static int wino_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
   static bool raised[EGN_MAX_DEVICES];
@@ -443,9 +762,36 @@ static int wino_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-// variant 0: 16 x 16 pixel tile of one image; variant 1: four 8 x 8 images (the 8 x 8 maps)
+template <int TH, int TW, int TNB, int ABL = 0>
+static int wino8_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
+  static bool raised[EGN_MAX_DEVICES];
+  static int cus = 0;
+  if (egn_first_use_on_device(raised)) {
+    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<TH, TW, TNB, ABL>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+  }
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+      cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+    cus &= ~7;
+    if (cus <= 0) cus = 8;
+  }
+  const int ntile = a.tiles_x * a.tiles_y * ((a.N + TNB - 1) / TNB);
+  const int nwork = ((ntile + 7) / 8) * 8 * (a.Cout / WN_CO);
+  const int grid = nwork < cus ? nwork : cus;
+  hipLaunchKernelGGL((conv_wino8_kernel<TH, TW, TNB, ABL>), dim3(grid), dim3(512), lds, stream, a);
+  return (int)hipGetLastError();
+}
+
+// variant 0: 16 x 16 pixel tile of one image; variant 1: four 8 x 8 images (the 8 x 8 maps);
+// variants 2 / 3: the same two geometries on the 8-wave kernel
 size_t egn_conv_wino_lds_bytes(int variant) {
-  const size_t halo = (variant & 15) == 1 ? WinoDims<8, 8, 4>::BUF : WinoDims<16, 16, 1>::BUF;
+  const int v = variant & 15;
+  size_t halo = (v & 1) ? WinoDims<8, 8, 4>::BUF : WinoDims<16, 16, 1>::BUF;
+  if (v >= 2) halo = (v & 1) ? EGN_CKQ * WinoGeom<8, 8, 4>::PLANE : EGN_CKQ * WinoGeom<16, 16, 1>::PLANE;
   return (2 * (size_t)WN_USLOTS + 2 * halo) * 16;
 }
 int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t stream) {
@@ -453,6 +799,11 @@ int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t
   if ((act != EGN_ACT_NONE && act != EGN_ACT_RELU) || (a.act & EGN_ACT_RES_AFTER)) return EGN_E_BADARG;
   switch (variant) {
     case 1: return wino_launch<8, 8, 4>(a, lds, stream);
+    case 2: return wino8_launch<16, 16, 1>(a, lds, stream);
+    case 3: return wino8_launch<8, 8, 4>(a, lds, stream);
+    case 0x12: return wino8_launch<16, 16, 1, 15>(a, lds, stream);
+    case 0x22: return wino8_launch<16, 16, 1, 7>(a, lds, stream);
+    case 0x32: return wino8_launch<16, 16, 1, 3>(a, lds, stream);
     case 0x10: return wino_launch<16, 16, 1, 15>(a, lds, stream);
     case 0x20: return wino_launch<16, 16, 1, 7>(a, lds, stream);
     case 0x30: return wino_launch<16, 16, 1, 3>(a, lds, stream);
