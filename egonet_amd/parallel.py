@@ -108,16 +108,82 @@ class GradBuckets(object):
                 off += n
 
 
+class _SyncSession(object):
+    """One backward pass of ``FlatGradSync.begin``: tracks which slices of the flat gradient are
+    final and launches their all-reduce while the rest of the backward still runs."""
+
+    def __init__(self, sync, flat_params, main_stream, side_stream):
+        self.sync, self.flat = sync, flat_params
+        self.grad = flat_params.grad
+        self.world = dist.get_world_size(sync.group)
+        self.main, self.side = main_stream, side_stream
+        self.cuda = self.grad.is_cuda
+        self.slices = sync.slices(self.grad.numel())
+        # number of parameters overlapping each slice that still wait for their gradient
+        self.spans = {}
+        self.waiting = [0] * len(self.slices)
+        for p, off in zip(flat_params.params, flat_params.offsets):
+            hit = [i for i, (lo, hi) in enumerate(self.slices) if off < hi and off + p.numel() > lo]
+            self.spans[id(p)] = hit
+            for i in hit:
+                self.waiting[i] += 1
+        self.launched = [False] * len(self.slices)
+        self.works = []
+        if self.cuda and sync.comm_stream is None:
+            sync.comm_stream = torch.cuda.Stream(device=self.grad.device)
+
+    def _launch(self, i):
+        lo, hi = self.slices[i]
+        self.launched[i] = True
+        if not self.cuda:
+            self.works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.sync.group,
+                                              async_op=True))
+            return
+        comm = self.sync.comm_stream
+        # the slice is final once everything issued so far on the backward's streams has run
+        for st in (self.main, self.side):
+            if st is not None:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                comm.wait_event(ev)
+        with torch.cuda.stream(comm):
+            self.works.append(dist.all_reduce(self.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.sync.group,
+                                              async_op=True))
+
+    def done(self, params):
+        """The kernels that write the gradients of ``params`` have been issued."""
+        for p in params:
+            for i in self.spans.pop(id(p), ()):
+                self.waiting[i] -= 1
+                if self.waiting[i] == 0 and not self.launched[i]:
+                    self._launch(i)
+
+    def finish(self):
+        """Launch what is left (parameters the backward never reported), wait, take the mean."""
+        for i in range(len(self.slices)):
+            if not self.launched[i]:
+                self._launch(i)
+        for w in self.works:
+            w.wait()                    # CUDA: the current (main) stream waits for the collective
+        self.grad.div_(self.world)
+
+
 class FlatGradSync(object):
     """Gradient all-reduce (mean) over ONE flat gradient buffer, in place, in
     slices of ``bucket_mb`` -- the ``grad_sync`` hook of the native training steps
     (egonet_amd.train_hrnet.FlatParams keeps every gradient in one allocation,
     so nothing is packed or copied).
 
-    The slices are issued back to front: the native backward fills the flat
-    buffer from its END (last layers first), so with ``async_op`` the early
-    collectives overlap what is still being reduced.  Replaces the per-step
-    parameter broadcast + output gather of ``torch.nn.DataParallel``
+    Two ways to use it:
+      * ``sync(flat_grad)`` after the backward: every slice, back to front, then the mean;
+      * ``sess = sync.begin(flat_params, main_stream, side_stream)`` before the backward,
+        ``sess.done([params...])`` whenever the kernels writing those gradients have been issued,
+        ``sess.finish()`` at the end: a slice is all-reduced ON A COMMUNICATION STREAM as soon as
+        every parameter in it is final -- the native backward fills the buffer from its end (last
+        layers first), so the collectives of the late layers run under the MFMA work of the early
+        ones and only the first layers' slice is exposed.  The order in which slices become final
+        is a property of the model, identical on every rank, so the collectives match up.
+    Replaces the per-step parameter broadcast + output gather of ``torch.nn.DataParallel``
     (tools/train_IGRs.py:59) by the one exchange step data parallelism needs.
     xGMI is point to point: 32 MB slices keep every ring step well above the
     latency floor without serialising the whole 256 MB HRNet gradient.
@@ -126,6 +192,14 @@ class FlatGradSync(object):
     def __init__(self, bucket_mb=32.0, group=None):
         self.group = group
         self.bucket = max(1, int(bucket_mb * 2 ** 20) // 4)
+        self.comm_stream = None
+
+    def active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def begin(self, flat_params, main_stream=None, side_stream=None):
+        """-> session (see the class docstring), or None when there is nothing to reduce."""
+        return _SyncSession(self, flat_params, main_stream, side_stream) if self.active() else None
 
     def slices(self, numel):
         out, hi = [], numel
@@ -147,6 +221,17 @@ class FlatGradSync(object):
         for work in pending:
             work.wait()
         flat.div_(world)
+
+
+def broadcast_buffers(module, src=0, group=None):
+    """BatchNorm running statistics follow rank ``src``: what ``torch.nn.DataParallel`` does implicitly
+    (only the replica on device 0 shares its buffers with the module the caller keeps,
+    tools/train_IGRs.py:59).  During training every rank updates its own running statistics from its
+    shard (they are not read in training mode); call this before evaluating or saving on other ranks."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    for t in module.buffers():
+        dist.broadcast(t.data, src=src, group=group)
 
 
 def broadcast_module(module, src=0, group=None):

@@ -363,6 +363,7 @@ class _Tape(object):
                     self._wgrad(x, xd, dy, z.cs, weight, stride, pad)
                 if id(x) not in self.no_grad:
                     self._accum(x, self._dgrad(dy, ho, wo, z.cs, weight, stride, pad, x))
+            backward.params = [weight] + ([bias] if bias is not None else [])     # gradients final after it
             self.back.append(backward)
             return z
 
@@ -411,6 +412,7 @@ class _Tape(object):
                 self._wgrad(x, xd, dz, z.cs, weight, stride, pad)
             if id(x) not in self.no_grad:
                 self._accum(x, self._dgrad(dz, ho, wo, z.cs, weight, stride, pad, x))
+        backward.params = [weight, bn.weight, bn.bias]
         self.back.append(backward)
         return y
 
@@ -590,10 +592,18 @@ class HRNetTrainStep(object):
             _lib.check(L.egn_mse_f32(_lib.ptr(tape.data[id(aug)]), _lib.ptr(tg), n * aug.h * aug.w, J, aug.cs, aug.cs,
                                      0.5 * self.w_hm, 0, _lib.ptr(da), _lib.ptr(self.loss_dev), st), 'mse')
             tape._accum(aug, da)
+            # the gradient all-reduce of a slice of the flat buffer starts (on a communication
+            # stream) as soon as every parameter in it has its gradient kernels issued
+            sess = self.grad_sync.begin(self.flat, torch.cuda.current_stream(self.dev), self.wgrad_stream) \
+                if hasattr(self.grad_sync, 'begin') else None
             for fn in reversed(tape.back):
                 fn()
+                if sess is not None:
+                    sess.done(getattr(fn, 'params', ()))
             tape.join_side()
-            if self.grad_sync is not None:
+            if sess is not None:
+                sess.finish()
+            elif self.grad_sync is not None:
                 self.grad_sync(self.flat.grad)
             if update:
                 self.flat.adam_step(self.lr, self.betas, self.eps, st)

@@ -212,8 +212,12 @@ class LifterTrainStep(object):
 
             # ---- backward ----
             g = self.grads
+            sess = self.grad_sync.begin(self.flat, torch.cuda.current_stream(dev), self.wgrad_stream) \
+                if hasattr(self.grad_sync, 'begin') else None
             self._wgrad(feat, nf, nf, dpred, no, no, B, g[id(self.final.weight)])
             _lib.check(L.egn_colsum_f32(_lib.ptr(dpred), B, no, no, _lib.ptr(g[id(self.final.bias)]), _lib.ptr(ws), st))
+            if sess is not None:
+                sess.done([self.final.weight, self.final.bias])
             dy = self._buf('dy_top', B, nf)
             self._gemm(dpred, B, no, no, self.final.weight, nf, nf, 1, dy, tagk='do')
 
@@ -235,6 +239,8 @@ class LifterTrainStep(object):
                                                u.outf, st), 'bn_bwd_dz')
                 self._wgrad(a_in, ld_in, u.inf, dz, u.outf, u.outf, B, g[id(u.fc.weight)])
                 _lib.check(L.egn_colsum_f32(_lib.ptr(dz), B, u.outf, u.outf, _lib.ptr(g[id(u.fc.bias)]), _lib.ptr(ws), st))
+                if sess is not None:
+                    sess.done([u.fc.weight, u.fc.bias, u.bn.weight, u.bn.bias])
                 if ui == 0:
                     break
                 da = self._buf('da%d' % (ui % 2), B, u.inf)
@@ -247,7 +253,9 @@ class LifterTrainStep(object):
                     d_block_out = nxt
 
             self._join_side()
-            if self.grad_sync is not None:
+            if sess is not None:
+                sess.finish()
+            elif self.grad_sync is not None:
                 self.grad_sync(self.flat.grad)
             if update:
                 self.flat.adam_step(self.lr, self.betas, self.eps, st)

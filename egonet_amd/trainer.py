@@ -228,9 +228,11 @@ def train(train_dataset, model, loss_func, optim, sche, cfgs, logger, metric_fun
                 x_buffer.append(total_batches * (epoch - 1) + batch_idx)
                 y_buffer.append(lv)
             if eval_during and epoch > eval_start and batch_idx and eval_every and batch_idx % eval_every == 0:
+                parallel.broadcast_buffers(model, src=0)    # running statistics follow rank 0 (DataParallel semantics)
                 evaluate_fn(valid_dataset, model, epoch)
                 model.train()
         if epoch in ts.get('snapshot_epochs', []):
+            parallel.broadcast_buffers(model, src=0)
             out_dir = cfgs.get('dirs', {}).get('output', '.')
             path = os.path.join(out_dir, '%s_%d.pth' % (cfgs.get('exp_type', 'model'), epoch))
             logger.info('=> Snapshot model to {}'.format(path))

@@ -150,7 +150,13 @@ def test_winograd_configs_plan_and_kinds():
     """Configs 45 / 46 (csrc/conv_wino.hip): fused Winograd F(2x2,3x3).  Fixed tiles (16 x 16 of one
     image / four 8 x 8 images), two U slabs (2 x 49 152 B) + two quad-plane halo buffers in LDS."""
     L = _lib.lib()
-    assert [L.egn_conv_config_kind(c) for c in (0, 1, 44, 45, 46, 47, 999)] == [-1, 0, 0, 1, 1, -1, -1]
+    assert [L.egn_conv_config_kind(c) for c in (0, 1, 44, 45, 46, 47, 51, 52, 53, 999)] == \
+        [-1, 0, 0, 1, 1, -1, 1, 1, -1, -1]
+    # the 8-wave variants: exact-size halo planes (no padding to whole 512-thread pieces)
+    p8 = _plan((64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0), cfg=51)
+    assert p8[0] == 51 and p8[1] == 8 and p8[5:8] == [16, 16, 1] and p8[9] == 2 * 49152 + 2 * 4 * 432 * 16
+    p8 = _plan((64, 8, 8, 384, 384, 384, 384, 3, 3, 1, 1, 0), cfg=52)
+    assert p8[5:8] == [8, 8, 4] and p8[9] == 2 * 49152 + 2 * 4 * 448 * 16 and p8[11] == 8
     for cfg, shape, tile in ((45, (64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0), [16, 16, 1]),
                              (45, (64, 16, 16, 192, 192, 192, 192, 3, 3, 1, 1, 0), [16, 16, 1]),
                              (46, (64, 8, 8, 384, 384, 384, 384, 3, 3, 1, 1, 0), [8, 8, 4])):

@@ -74,9 +74,10 @@ def test_gloo_world2_gradient_allreduce_and_gather():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert np.array_equal(idx.ravel(), np.arange(7))
-    # both ranks hold identical reduced gradients by construction; check they are
-    # finite and that the reduction is the mean of two different local gradients
     assert np.isfinite(grads).all() and np.abs(grads).sum() > 0
+    # (train-mode BatchNorm uses per-rank batch statistics -- DataParallel semantics -- so this run is
+    # not comparable to one process on the concatenated batch; the eval-mode equality is
+    # test_gloo_world2_sync_session_equals_single_process_gradient)
 
 
 def _flat_worker(rank, world, port, q):
@@ -110,7 +111,98 @@ def test_gloo_world2_flat_gradient_sync():
     np.testing.assert_allclose(flat, np.arange(1037, dtype=np.float32) * 1.5)
 
 
+def _session_worker(rank, world, port, q):
+    """Data parallel == single process on the concatenated batch: the lifter with
+    BatchNorm in EVAL mode (no cross-sample coupling), its parameters as views of one flat buffer
+    (FlatParams, as in the native steps), gradients reduced by a FlatGradSync SESSION -- slices go
+    out as soon as the parameters inside them are reported final, in backward order."""
+    from egonet_amd.train_hrnet import FlatParams
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    cfg = configs.tiny_config()
+    net = FCmodel.get_fc_model(1, cfg, 10, 12)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=3))
+    net.eval()                                          # running statistics: samples do not interact
+    flat = FlatParams(net.parameters())
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(9, 10, generator=g), torch.randn(9, 12, generator=g)       # 9 -> ragged 5 + 4
+    lo, hi = parallel.shard_range(9, world, rank)
+    # local SUM loss scaled so that the all-reduced MEAN of the rank gradients is the gradient of the
+    # global mean loss
+    loss = ((net.w2(net.get_representation(x[lo:hi])) - y[lo:hi]) ** 2).sum() / (9 * 12) * world
+    sync = parallel.FlatGradSync(bucket_mb=4 * 3000 / 2 ** 20)                     # 3000-float slices
+    sess = sync.begin(flat)
+    assert sess is not None and len(sess.slices) > 3
+    loss.backward()                                     # accumulates into the flat views
+    order = list(reversed(flat.params))                 # the order a backward pass finalises them
+    launched = []
+    for p in order:
+        sess.done([p])
+        launched.append(sum(sess.launched))
+    # progressively (a large weight completes several slices at once), not all at the end
+    assert launched == sorted(launched) and launched[-1] == len(sess.slices)
+    assert len(set(launched)) >= 4 and launched[len(launched) // 2] > 0
+    sess.finish()
+    if rank == 0:
+        ref = FCmodel.get_fc_model(1, cfg, 10, 12)
+        ref.load_state_dict(synth.synth_state_dict(ref.state_dict(), seed=3))
+        ref.eval()
+        full = ((ref.w2(ref.get_representation(x)) - y) ** 2).mean()
+        full.backward()
+        want = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+        got = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        q.put((got.numpy(), want.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_sync_session_equals_single_process_gradient():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_session_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, want = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.abs(want).max() > 1e-3
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max())
+
+
+def _buffers_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    cfg = configs.tiny_config()
+    net = FCmodel.get_fc_model(1, cfg, 10, 12)
+    for b in net.buffers():
+        b.fill_(rank + 1)
+    w0 = net.w1.weight.detach().clone()
+    parallel.broadcast_buffers(net, src=0)
+    ok = all(float(b.float().min()) == 1.0 == float(b.float().max()) for b in net.buffers()) \
+        and torch.equal(net.w1.weight, w0)                      # parameters untouched
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_broadcast_buffers_follows_rank0():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_buffers_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}
+
+
 def test_flat_gradient_sync_is_a_noop_without_a_process_group():
     flat = torch.ones(10)
     parallel.FlatGradSync()(flat)
     assert torch.equal(flat, torch.ones(10))
+    assert parallel.FlatGradSync().begin(None) is None

@@ -55,6 +55,29 @@ def test_frames_to_result_files_to_aos(tmp_path, monkeypatch):
         assert (got['alpha'], got['rot_y']) != (want['alpha'], want['rot_y'])   # replaced by the predictions
         assert got['score'] == 1.0
     ev = out['eval']['car']
-    # the boxes are the labels' own: every evaluated car is found, nothing else is a false positive
-    assert all(0.0 < v <= 100.0 for v in ev['AP']) and all(0.0 <= v <= 100.0 for v in ev['AOS'])
-    assert ev['AOS'][0] <= ev['AP'][0] + 1e-9                                   # orientation similarity <= 1
+    # exact values: the independent Python restatement of the evaluator (oracle/kitti_eval_oracle.py, the
+    # checker) on the files this run wrote gives the same doubles as the C++ evaluator
+    from oracle import kitti_eval_oracle as orc
+    frames = []
+    for idx in sorted(labels):
+        det = (out_dir / 'data' / ('%06d.txt' % idx)).read_text().split('\n')
+        frames.append(orc.parse_frame(labels[idx], [l for l in det if l.strip()]))
+    res, aos_valid = orc.evaluate(frames)
+    assert aos_valid and set(res) == {'car'}
+    prec, aos = res['car']
+    want_ap = [sum(prec[l][::4]) / 11 * 100 for l in range(3)]
+    want_aos = [sum(aos[l][::4]) / 11 * 100 for l in range(3)]
+    assert ev['AP'] == want_ap and ev['AOS'] == want_aos
+    # the boxes are the labels' own: every evaluated car is found, nothing else is a false positive.
+    # Three detections with equal scores give three thresholds, i.e. precision 1 at recall samples
+    # 0..2 only; of the 11 summary points (every 4th sample) just the first is non-zero.
+    assert all(abs(v - 100.0 / 11) < 1e-12 for v in ev['AP'])
+    # ... and AOS there is the mean orientation similarity (1 + cos(alpha_pred - alpha_gt)) / 2 of the
+    # three cars (evaluate_object_3d_offline.cpp:547-548)
+    sims = []
+    for idx in (0, 2):
+        det = [kfmt.parse_label_line(l) for l in (out_dir / 'data' / ('%06d.txt' % idx)).read_text().split('\n') if l.strip()]
+        gts = [kfmt.parse_label_line(l) for l in labels[idx] if l.startswith('Car')]
+        sims += [(1 + math.cos(d['alpha'] - g['alpha'])) / 2 for d, g in zip(det, gts)]
+    assert len(sims) == 3
+    assert abs(ev['AOS'][0] - 100.0 / 11 * sum(sims) / 3) < 1e-9

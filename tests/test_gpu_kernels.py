@@ -119,17 +119,18 @@ def test_conv_every_tile_config(cfg):
     (9, 6, 4, 64, 144, False, 1),      # maps smaller than a tile, 3 co-tiles
 ])
 def test_conv_winograd_kernels(n, h, w, cin, cout, res, act):
-    """Configs 45 / 46 (csrc/conv_wino.hip): fused Winograd F(2x2,3x3); the filter transform runs on
-    the device (egn_wino_pack_weight_f32).  Same oracle and tolerance as the direct kernels."""
+    """Configs 45 / 46 (4 waves) and 51 / 52 (8 waves, frequency halves + partial exchange) of
+    csrc/conv_wino.hip: fused Winograd F(2x2,3x3); the filter transform runs on the device
+    (egn_wino_pack_weight_f32).  Same oracle and tolerance as the direct kernels."""
     import ctypes as C
     from egonet_amd import _lib
     L = _lib.lib()
-    assert L.egn_conv_config_kind(45) == 1 and L.egn_conv_config_kind(46) == 1 and L.egn_conv_config_kind(44) == 0
-    assert L.egn_conv_config_kind(47) == -1                # timing ablation: never selectable
+    assert [L.egn_conv_config_kind(c) for c in (44, 45, 46, 51, 52)] == [0, 1, 1, 1, 1]
+    assert L.egn_conv_config_kind(47) == -1 and L.egn_conv_config_kind(53) == -1     # timing ablations: never selectable
     out = (C.c_int * 12)()
-    for cfg in (45, 46):
+    for cfg in (45, 46, 51, 52):
         rc = L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, cfg, out)
-        if cfg == 46 and (h > 8 or w > 8):
+        if cfg in (46, 52) and (h > 8 or w > 8):
             assert rc != 0
             continue
         assert rc == 0

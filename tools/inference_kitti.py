@@ -7,6 +7,12 @@ GPU crops -> HRNet key-points -> lifter -> pose solve -> KITTI result files ->
         [--calib <dir>] --out <result dir> [--ckpt <dir with HC.pth L.pth LS.npy> | --synthetic]
         [--gt <label dir>] [--classes Car] [--conf-thres 0] [--alpha-mode proj|trans] [--frames-per-step 8]
 
+Multi-GPU (BASELINE config 5's 8-GPU form): launch one process per GPU with
+``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...``;
+the frames are sharded contiguously by rank (egonet_amd.parallel.shard_range), every rank holds a
+full weight copy and writes the result files of its own frames -- no collective on the data path;
+rank 0 waits at a barrier, fills in the empty files and runs the evaluator.
+
 Boxes come from KITTI lines (ground-truth labels = the reference's ``use_gt_box``, or a 2D/3D
 detector's result files = ``use_pred_box``).  Every frame is uploaded once as uint8; all its
 boxes are cropped in one launch (csrc/crop.hip).  Result files go to ``<out>/data/%06d.txt``
@@ -88,8 +94,21 @@ def main(argv=None):
     classes = {c.strip().lower() for c in a.classes.split(',')}
     data_dir = os.path.join(a.out, 'data')
     os.makedirs(data_dir, exist_ok=True)
+    # one process per GPU: contiguous shard of the frame list per rank, no data-path collective
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        from egonet_amd.parallel import shard_range
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
+        dist.init_process_group('nccl')
     ego = build_model(a)
     names = sorted(f for f in os.listdir(a.images) if f.lower().endswith(('.png', '.jpg', '.jpeg')))
+    all_names = names
+    if world > 1:
+        lo_r, hi_r = shard_range(len(names), world, rank)
+        names = names[lo_r:hi_r]
     n_inst, t0 = 0, time.perf_counter()
     for lo in range(0, len(names), a.frames_per_step):
         annot = {'path': [], 'boxes': [], 'raw_txt_format': [], 'K': []}
@@ -112,13 +131,25 @@ def main(argv=None):
         n_inst += sum(len(b) for b in annot['boxes'])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if dist is not None:
+        cnt = torch.tensor([float(n_inst), dt], dtype=torch.float64, device='cuda')
+        tmax = cnt[1:].clone()
+        dist.all_reduce(cnt[:1])                         # instances of the whole job
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)      # slowest rank (also the barrier before the evaluator)
+        n_inst, dt = int(cnt[0].item()), float(tmax.item())
+        if rank != 0:
+            dist.destroy_process_group()
+            return None
+    names = all_names
     written = set(os.listdir(data_dir))
     for name in names:                                   # frames without predictions: empty result files
         stem = os.path.splitext(name)[0] + '.txt'
         if stem not in written:
             open(os.path.join(data_dir, stem), 'w').close()
-    out = {'frames': len(names), 'instances': n_inst, 'seconds': round(dt, 3),
+    out = {'frames': len(names), 'instances': n_inst, 'seconds': round(dt, 3), 'n_gpus': world,
            'instances_per_s': round(n_inst / dt, 1) if dt > 0 else None, 'result_dir': data_dir}
+    if dist is not None:
+        dist.destroy_process_group()
     if a.gt:
         res = evaluate.evaluate_aos(a.gt, a.out)
         out['eval'] = {k: {'AP': v['AP'], 'AOS': v['AOS']} for k, v in res.items() if isinstance(v, dict)}
