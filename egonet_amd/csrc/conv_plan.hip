@@ -7,8 +7,10 @@
 //   ids 11..30  "dma":    buffer_load ... lds straight into a double-buffered
 //               LDS stage, 1 barrier per stage, register double-buffered
 //               fragments                                   (conv_dma.hip)
-//   ids 31..40  "pers":   the dma pipeline in persistent blocks that walk over
-//               several tiles                               (conv_pers.hip)
+//   ids 31..40  retired: a persistent variant of the dma pipeline that no shape ever selected
+//               (removed in round 2; the ids stay reserved so measured tables keep their meaning)
+//   ids 41..44  filter-resident persistent kernels for the 48 -> 48 3x3 layers (conv_c48.hip)
+//   ids 45..55  fused Winograd F(2x2,3x3) kernels for every 3x3 stride-1 layer (conv_wino.hip)
 // The engine's tuner times the candidates on the real shape; cfg 0 = cost model.
 #include <stdio.h>
 
@@ -16,7 +18,6 @@
 
 int egn_conv_launch_staged(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
 int egn_conv_launch_dma(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
-int egn_conv_launch_pers(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
 int egn_conv_launch_c48(const ConvArgs& a, size_t lds, int waves, hipStream_t stream);
 int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t stream);
 size_t egn_conv_wino_lds_bytes(int variant);
@@ -53,9 +54,9 @@ static const ConvConfig kConfigs[] = {
     {28, 2, 2, 2, 2, 8, 8, 2},
     {29, 1, 4, 4, 1, 8, 8, 2},
     {30, 1, 4, 2, 3, 8, 8, 2},
-    {31, 4, 1, 4, 3, 8, 8, 3},  // persistent LDS-DMA pipeline (conv_pers.hip): blocks walk over
-    {32, 2, 2, 4, 3, 8, 8, 3},  // several tiles, next tile's stage 0 prefetched, wave-private
-    {33, 2, 2, 4, 2, 8, 8, 3},  // epilogue without block barriers
+    {31, 4, 1, 4, 3, 8, 8, 3},  // 31..40 retired (dma == 3): never planned, never launched
+    {32, 2, 2, 4, 3, 8, 8, 3},
+    {33, 2, 2, 4, 2, 8, 8, 3},
     {34, 4, 1, 4, 1, 8, 8, 3},
     {35, 4, 1, 4, 2, 8, 8, 3},
     {36, 4, 1, 2, 3, 8, 8, 3},
@@ -99,6 +100,7 @@ extern "C" int egn_conv_config_info(int cfg, int* tile_m, int* tile_n) {
 extern "C" int egn_conv_config_kind(int cfg) {
   if (cfg < 1 || cfg > kNumConfigs) return -1;
   const ConvConfig& c = kConfigs[cfg - 1];
+  if (c.dma == 3) return -1;  // retired ids
   if (c.dma != 5) return 0;
   return (c.bi >> 4) ? -1 : 1;
 }
@@ -118,7 +120,7 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   else if (c.dma == 4)
     snprintf(buf, len, "void conv_c48_kernel<%d>(ConvArgs)", c.wm);
   else if (c.dma == 3)
-    snprintf(buf, len, "void conv_pers_kernel<%d, %d, %d, %d, 8, 8>(ConvArgs)", c.wm, c.wn, c.mt, c.nt);
+    snprintf(buf, len, "(retired)");
   else if (c.dma)
     snprintf(buf, len, "void conv_dma_kernel<%d, %d, %d, %d, 8, 8, 0>(ConvArgs)", c.wm, c.wn, c.mt, c.nt);
   else
@@ -152,6 +154,7 @@ static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
 // LDS fill work) over power-of-two tile shapes, subject to the LDS budget and
 // to the per-lane staging depth (ai / bi dwordx4 loads per stage).
 static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, double* cost_out) {
+  if (cf.dma == 3) return false;  // retired ids
   if (cf.dma == 5) {
     // conv_wino.hip: 3x3 stride-1 pad-1 NHWC layers with unpadded channel strides, even maps
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % EGN_CK || a.cs_in != a.Cin ||
@@ -281,7 +284,7 @@ int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {
   const size_t lds = lds_bytes_for(a, cf);
   if (cf.dma == 5) return egn_conv_launch_wino(a, lds, cf.bi, stream);
   if (cf.dma == 4) return egn_conv_launch_c48(a, lds, cf.bi == 2 ? -1 : cf.bi == 1 ? 0 : cf.wm, stream);
-  if (cf.dma == 3) return egn_conv_launch_pers(a, (cfg_id - 1) % 10 + 1, lds, stream);
+  if (cf.dma == 3) return EGN_E_BADARG;
   return cf.dma ? egn_conv_launch_dma(a, (cfg_id - 1) % 10 + 1, lds, stream)
                 : egn_conv_launch_staged(a, cfg_id, lds, stream);
 }

@@ -1,6 +1,8 @@
 // decode.hip -- key-point decode from NCHW heat-maps, one 64-lane wavefront per
-// (n,k) map.  HBM-bound: every map element is read once (hard arg-max) or once
-// from HBM + once from L2/L1 (soft-arg-max second pass over a 16 KB map).
+// (n,k) map.  HBM-bound: every map element is read ONCE -- maps of up to 4096 elements (the 64 x 64
+// heat-maps of the network) are fetched with 16-byte loads, all in flight together, and stay in
+// registers for both passes (maximum, then the soft-arg-max moments); other sizes take the scalar
+// two-pass path.
 //
 // hard (img_proc.py:608-637): flat arg-max, first index on ties,
 //   (idx % W, floor(idx / W)), zeroed where max <= 0.
@@ -36,12 +38,34 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
   const int hw = H * W;
   const float* __restrict__ p = hm + (size_t)map * hw;
 
+  constexpr int VMAX = 16;  // float4 per lane held in registers: maps up to 64 * 16 * 4 = 4096 elements
+  const bool vec = (hw & 3) == 0 && hw <= 64 * VMAX * 4 && ((reinterpret_cast<size_t>(p) & 15) == 0);
+  float4 reg[VMAX];
+  const int nvec = hw >> 2;
+
   // pass 1: maximum and its first index
   float best = -INFINITY;
   int bidx = 0x7fffffff;
-  for (int i = lane; i < hw; i += 64) {
-    const float v = p[i];
-    if (v > best) { best = v; bidx = i; }
+  if (vec) {
+    const float4* __restrict__ p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int j = 0; j < VMAX; ++j) {
+      const int q = lane + 64 * j;
+      reg[j] = q < nvec ? p4[q] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    }
+#pragma unroll
+    for (int j = 0; j < VMAX; ++j) {  // a lane's indices ascend with j and with the component
+      const int i0 = 4 * (lane + 64 * j);
+      if (reg[j].x > best) { best = reg[j].x; bidx = i0; }
+      if (reg[j].y > best) { best = reg[j].y; bidx = i0 + 1; }
+      if (reg[j].z > best) { best = reg[j].z; bidx = i0 + 2; }
+      if (reg[j].w > best) { best = reg[j].w; bidx = i0 + 3; }
+    }
+  } else {
+    for (int i = lane; i < hw; i += 64) {
+      const float v = p[i];
+      if (v > best) { best = v; bidx = i; }
+    }
   }
   wave_argmax(best, bidx);
   if (bidx == 0x7fffffff) bidx = 0;  // all -inf / NaN map: numpy returns index 0
@@ -51,6 +75,31 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ h
     ox = (float)(bidx % W);
     oy = floorf((float)bidx / (float)W);
     if (!(best > 0.0f)) { ox = 0.f; oy = 0.f; }
+  } else if (vec) {
+    float s = 0.f, sx = 0.f, sy = 0.f;
+#pragma unroll
+    for (int j = 0; j < VMAX; ++j) {
+      const int q = lane + 64 * j;
+      if (q < nvec) {
+        const float vv[4] = {reg[j].x, reg[j].y, reg[j].z, reg[j].w};
+        const int i0 = 4 * q;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float e = mode == 1 ? __expf(vv[c] - best) : vv[c];
+          const int y = (i0 + c) / W;
+          const int x = (i0 + c) - y * W;
+          s += e;
+          sx += e * (float)x;
+          sy += e * (float)y;
+        }
+      }
+    }
+    s = wave_sum(s);
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    ox = sx / s;
+    oy = sy / s;
+    if (mode == 2 && !(best > 0.0f)) { ox = 0.f; oy = 0.f; }
   } else {
     float s = 0.f, sx = 0.f, sy = 0.f;
     for (int i = lane; i < hw; i += 64) {

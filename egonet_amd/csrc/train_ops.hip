@@ -656,6 +656,51 @@ __global__ __launch_bounds__(256) void pack_conv_weights_batch_kernel(const egn_
     }
     const egn_pack_desc d = descs[lo];
     const long long le = e - d.begin;
+    if (d.dgrad & 2) {
+      // Winograd filter U = G g G^T (conv_wino.hip layout [co-tile][chunk][f][quad][48][4]); one unit =
+      // one (co-tile, chunk, quad, co) = 4 input channels x 16 frequencies = 16 coalesced float4 stores
+      const int dg = d.dgrad & 1;
+      const int n_out = dg ? d.Cin : d.Cout, n_in = dg ? d.Cout : d.Cin;
+      const int nchunk = n_in / EGN_CK;
+      const int col = (int)(le % 48);
+      long long r_ = le / 48;
+      const int quad = (int)(r_ % 4);
+      r_ /= 4;
+      const int chunk = (int)(r_ % nchunk);
+      const int ct = (int)(r_ / nchunk);
+      const int o = ct * 48 + col;
+      float u[16][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = chunk * EGN_CK + quad * 4 + r;
+        double g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b)
+            g[a][b] = dg ? (double)d.w[((size_t)i * d.Cin + o) * 9 + (2 - a) * 3 + (2 - b)]
+                         : (double)d.w[((size_t)o * d.Cin + i) * 9 + a * 3 + b];
+        double t[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          t[0][b] = g[0][b];
+          t[1][b] = 0.5 * (g[0][b] + g[1][b] + g[2][b]);
+          t[2][b] = 0.5 * (g[0][b] - g[1][b] + g[2][b]);
+          t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          u[a * 4 + 0][r] = (float)t[a][0];
+          u[a * 4 + 1][r] = (float)(0.5 * (t[a][0] + t[a][1] + t[a][2]));
+          u[a * 4 + 2][r] = (float)(0.5 * (t[a][0] - t[a][1] + t[a][2]));
+          u[a * 4 + 3][r] = (float)t[a][2];
+        }
+      }
+      float4* slab = reinterpret_cast<float4*>(d.dst) + (size_t)(ct * nchunk + chunk) * (16 * 4 * 48);
+#pragma unroll
+      for (int f = 0; f < 16; ++f) slab[(f * 4 + quad) * 48 + col] = make_float4(u[f][0], u[f][1], u[f][2], u[f][3]);
+      continue;
+    }
     const int n_out = d.dgrad ? d.Cin : d.Cout;
     const int n_in = d.dgrad ? d.Cout : d.Cin;
     const int CoP = (n_out + 15) & ~15;

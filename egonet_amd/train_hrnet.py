@@ -104,20 +104,27 @@ class PackedFilters(object):
         self.total = 0
         self.ptrs = None
 
-    def get(self, weight, dgrad, stream):
-        ent = self.entries.get((id(weight), dgrad))
+    def get(self, weight, dgrad, stream, wino=False):
+        """``wino``: the Winograd-transformed filter (conv_wino.hip kernels) instead of the direct pack."""
+        code = int(dgrad) | (2 if wino else 0)
+        ent = self.entries.get((id(weight), code))
         if ent is not None and self.table is not None:
             return ent[1]
         cout, cin, kh, kw = weight.shape
         if ent is None:
-            wp = torch.empty(self.L.egn_packed_weight_floats(cout, cin, kh, kw, dgrad), dtype=torch.float32,
-                             device=self.dev)
-            self.entries[(id(weight), dgrad)] = (weight, wp)
+            nfl = self.L.egn_wino_weight_floats(cout, cin, dgrad) if wino else \
+                self.L.egn_packed_weight_floats(cout, cin, kh, kw, dgrad)
+            wp = torch.empty(nfl, dtype=torch.float32, device=self.dev)
+            self.entries[(id(weight), code)] = (weight, wp)
             self.table = None
         else:
             wp = ent[1]
-        _lib.check(self.L.egn_pack_conv_weight_f32(_lib.ptr(weight), cout, cin, kh, kw, dgrad, _lib.ptr(wp), stream),
-                   'pack')
+        if wino:
+            _lib.check(self.L.egn_wino_pack_weight_f32(_lib.ptr(weight), cout, cin, dgrad, _lib.ptr(wp), stream),
+                       'wino pack')
+        else:
+            _lib.check(self.L.egn_pack_conv_weight_f32(_lib.ptr(weight), cout, cin, kh, kw, dgrad, _lib.ptr(wp),
+                                                       stream), 'pack')
         return wp
 
     def _pointers(self):
@@ -131,10 +138,10 @@ class PackedFilters(object):
         desc = np.zeros(len(self.entries), dtype=np.dtype(self._DESC, align=True))
         assert desc.dtype.itemsize == self.L.egn_pack_desc_bytes(), (desc.dtype.itemsize, self.L.egn_pack_desc_bytes())
         begin = 0
-        for i, ((_, dgrad), (w, wp)) in enumerate(self.entries.items()):
+        for i, ((_, code), (w, wp)) in enumerate(self.entries.items()):
             cout, cin, kh, kw = w.shape
-            desc[i] = (w.data_ptr(), wp.data_ptr(), cout, cin, kh * kw, dgrad, begin)
-            begin += wp.numel() // 4
+            desc[i] = (w.data_ptr(), wp.data_ptr(), cout, cin, kh * kw, code, begin)
+            begin += wp.numel() // (64 if code & 2 else 4)     # work units (egonet_hip.h)
         self.total = begin
         self.table = torch.from_numpy(desc.view(np.uint8)).to(self.dev)
         self.ptrs = self._pointers()
@@ -218,9 +225,19 @@ class _Tape(object):
     def _pack(self, weight, dgrad):
         return self.o.packs.get(weight, dgrad, self.st)
 
-    def _conv_launch(self, x, wp, shift, y, n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, act):
+    def _conv_launch(self, x, wp, shift, y, n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, act,
+                     weight=None, dgrad=0):
+        """``wp``: the direct-packed filter (None: packed here from ``weight``).  With ``weight`` (+ ``dgrad``) given, the tuner may pick a
+        Winograd configuration for 3x3 stride-1 layers (forward and data gradient alike: the data
+        gradient is a stride-1 convolution with the rotated filter); the transformed filter then comes
+        from the step's PackedFilters like the direct one."""
         key = (n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, False, False)
-        cfg = tuner.choose(self.dev, key)
+        can_wino = weight is not None and act in (ACT_NONE, ACT_RELU) and self.o.allow_wino
+        cfg = tuner.choose(self.dev, key, allow_wino=can_wino)
+        if can_wino and cfg > 0 and self.L.egn_conv_config_kind(cfg) == 1:
+            wp = self.o.packs.get(weight, dgrad, self.st, wino=True)
+        elif wp is None:
+            wp = self._pack(weight, dgrad)
         tm = self.o.timing
         if tm is not None:         # bench.py: hipEvents around every forward / data-gradient conv launch
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -287,7 +304,7 @@ class _Tape(object):
                                         x.n, 1, 1, cout, cs_out, rows, rows, 1, 1, 1, 0, ACT_NONE, 0, cfg, self.st),
                        'conv')
             return dx
-        wq = self._pack(weight, 1)
+        wq = self._pack(weight, 1) if stride != 1 else None
         if stride == 2:
             up = self._empty(x.n * x.h * x.w * cs_out)
             _lib.check(L.egn_zero_insert2_f32(_lib.ptr(dy), _lib.ptr(up), x.n, ho, wo, x.h, x.w, cs_out, self.st),
@@ -299,7 +316,7 @@ class _Tape(object):
             raise NotImplementedError('stride %d' % stride)
         dx = self._empty(x.n * x.h * x.w * x.cs)
         self._conv_launch(src, wq, self.o.zeros, dx, x.n, sh, sw, cout, cs_out, cin, x.cs, kh, kw, 1, kh - 1 - pad,
-                          ACT_NONE)
+                          ACT_NONE, weight=weight if stride == 1 else None, dgrad=1)
         return dx
 
     # -- ops (engine._Recorder interface) -----------------------------------
@@ -331,14 +348,15 @@ class _Tape(object):
         # padded layout -- and copied out in the caller's NCHW format afterwards
         z = self.new(x.n, ho, wo, cout, cs=cout_cs, name=tag)
         xd, zd = self.data[id(x)], self.data[id(z)]
-        wp = self._pack(weight, 0)
+        wp = None                        # packed by _conv_launch in the layout its tile configuration reads
         rows = x.n * ho * wo
         if bn is None:
             shift = self.o.zeros
             if bias is not None:
                 shift = torch.zeros(_round_up(cout, 16), dtype=torch.float32, device=self.dev)
                 shift[:cout].copy_(bias.detach())
-            self._conv_launch(xd, wp, shift, zd, x.n, x.h, x.w, cin, x.cs, cout, z.cs, kh, kw, stride, pad, act)
+            self._conv_launch(xd, wp, shift, zd, x.n, x.h, x.w, cin, x.cs, cout, z.cs, kh, kw, stride, pad, act,
+                              weight=weight)
             if dst is not None or out_nchw:
                 u = torch.empty(x.n, cout, ho, wo, dtype=torch.float32, device=self.dev)
                 _lib.check(L.egn_nhwc_to_nchw_f32(_lib.ptr(zd), _lib.ptr(u), x.n, cout, ho, wo, z.cs, self.st), 'to_nchw')
@@ -369,7 +387,8 @@ class _Tape(object):
 
         if bias is not None:
             raise NotImplementedError('conv bias followed by BatchNorm')
-        self._conv_launch(xd, wp, self.o.zeros, zd, x.n, x.h, x.w, cin, x.cs, cout, z.cs, kh, kw, stride, pad, ACT_NONE)
+        self._conv_launch(xd, wp, self.o.zeros, zd, x.n, x.h, x.w, cin, x.cs, cout, z.cs, kh, kw, stride, pad, ACT_NONE,
+                          weight=weight)
         mean, istd = self._empty(cout), self._empty(cout)
         mom = 0.1 if bn.momentum is None else bn.momentum
         _lib.check(L.egn_bn_stats_f32(_lib.ptr(zd), rows, cout, z.cs, bn.eps, _lib.ptr(mean), _lib.ptr(istd), None,
@@ -504,6 +523,9 @@ class HRNetTrainStep(object):
         self.last_maps = self.last_coords = None
         self.debug_hook = None        # tests/train_debug.py: per-layer checks of the BatchNorm backward
         self.timing = None            # bench.py: a list collects (cfg, flops, start, end) per conv launch
+        # 3x3 stride-1 forward / data-gradient convolutions may run on the fused Winograd kernels
+        # (csrc/conv_wino.hip) where they measured faster (EGONET_AMD_TRAIN_WINO=0: direct kernels only)
+        self.allow_wino = os.environ.get('EGONET_AMD_TRAIN_WINO', '1') != '0'
 
     def wgrad_ws(self, nbytes):
         if self._wgrad_ws is None or self._wgrad_ws.numel() * 4 < nbytes:

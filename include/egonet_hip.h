@@ -311,8 +311,10 @@ int egn_pack_conv_weight_f32(const float* w, int Cout, int Cin, int KH, int KW,
 /* Every filter of a model packed in ONE launch (the weights only change in the
  * optimizer step; a W48 training step needs ~600 packs).  descs: DEVICE array of
  *   struct { const float* w; float* dst; int32 Cout, Cin, taps, dgrad; int64 begin; }
- * (egn_pack_desc_bytes() bytes each), `begin` = running sum of the float4 counts
- * egn_packed_weight_floats()/4 of the preceding descriptors. */
+ * (egn_pack_desc_bytes() bytes each), `begin` = running sum of the work units of the
+ * preceding descriptors: egn_packed_weight_floats()/4 (one float4 each) for the direct
+ * layouts (dgrad 0 / 1), egn_wino_weight_floats()/64 for the Winograd layout
+ * (dgrad | 2: taps must be 9; one unit = 4 input channels x 16 frequencies). */
 int egn_pack_desc_bytes(void);
 int egn_pack_conv_weights_batch_f32(const void* descs_dev, int n, long total_float4,
                                     void* stream);

@@ -106,6 +106,51 @@ def test_heatmap_head_vs_oracle():
     assert cos > 0.9999 and gl2 < 1e-2 and med < 5e-3, (gl2, cos, med)
 
 
+def test_step_with_winograd_forward_and_data_gradient_convs_vs_oracle(monkeypatch):
+    """48/96/192/384-channel topology (the widths of W48, one block per branch, 64 x 64 input): with
+    EGONET_AMD_WINO=1 every 3x3 stride-1 forward AND data-gradient convolution runs on the fused
+    Winograd kernels (csrc/conv_wino.hip; filters transformed on the device by the step's batched
+    pack).  Loss, maps and gradients against the CPU training oracle, and the second step (the
+    batched pack of direct + Winograd filters in one launch) against the oracle's second step."""
+    from egonet_amd import _lib
+    monkeypatch.setenv('EGONET_AMD_WINO', '1')
+    cfg = configs.tiny_config('coordinates', width=48)
+    net, sd = _tiny_model(cfg, seed=7)
+    gen = torch.Generator().manual_seed(2)
+    x = synth.synth_crops(2, 3, 64, 64, seed=3)
+    tgt = torch.rand(2, 5, 16, 16, generator=gen)
+    jt = torch.rand(2, 5, 2, generator=gen) * 64
+    orc = HRNetTrainOracle(sd, cfg, lr=1e-3)
+    tr = HRNetTrainStep(net, lr=1e-3)
+    for it in range(2):
+        want_loss, want_maps, _ = orc.step(x, tgt, jt, update=True)
+        loss = tr.step(x.cuda(), tgt.cuda(), jt, update=True)
+        # (after one Adam step every entry has moved by ~lr * sign(g): entries whose gradient is rounding
+        #  noise step either way, so the second iteration agrees to ~1e-4 like test_two_steps_vs_reference)
+        assert abs(float(loss.item()) - want_loss) < (5e-5 if it == 0 else 3e-4) * abs(want_loss), it
+        if it == 0:
+            np.testing.assert_allclose(tr.last_maps.cpu().numpy(), want_maps.numpy(), rtol=0, atol=3e-4)
+            gl2, cos, med = gradient_agreement(dict(net.named_parameters()), orc.grads())
+            assert cos > 0.9999 and gl2 < 1e-2 and med < 5e-3, (gl2, cos, med)
+    kinds = {code for (_, code) in tr.packs.entries}
+    assert kinds == {0, 1, 2, 3}                 # direct + Winograd filters, forward + data gradient
+    assert tr.packs.table is not None            # the second step packed them all in one launch
+    n_wino = sum(1 for (_, code) in tr.packs.entries if code & 2)
+    assert n_wino >= 2 * 16                      # 2 x (4 + 3 + 2 + ... ) 3x3 s1 convs of the branches / head
+    # the one-launch pack of every filter == the single-filter entry points, bit for bit
+    L = _lib.lib()
+    st = _lib.current_stream()
+    assert tr.packs.pack_all(st)
+    for (_, code), (w, wp) in tr.packs.entries.items():
+        one = torch.full_like(wp, float('nan'))
+        cout, cin, kh, kw = w.shape
+        if code & 2:
+            _lib.check(L.egn_wino_pack_weight_f32(_lib.ptr(w), cout, cin, code & 1, _lib.ptr(one), st))
+        else:
+            _lib.check(L.egn_pack_conv_weight_f32(_lib.ptr(w), cout, cin, kh, kw, code & 1, _lib.ptr(one), st))
+        assert torch.equal(one, wp), (tuple(w.shape), code)
+
+
 def test_frozen_prefix_gets_no_gradient_and_no_update():
     cfg = configs.tiny_config('coordinates')
     net, sd = _tiny_model(cfg, seed=9)
