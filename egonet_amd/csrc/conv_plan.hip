@@ -81,6 +81,8 @@ static const ConvConfig kConfigs[] = {
     {53, 8, 1, 1, 3, 4, 0x12, 5},  // timing ablations of 51
     {54, 8, 1, 1, 3, 4, 0x22, 5},
     {55, 8, 1, 1, 3, 4, 0x32, 5},
+    {56, 4, 1, 1, 3, 4, 4, 5},     // frequency-halves kernel with 4 waves on two 8 x 8 images (32 tiles per block)
+    {57, 4, 1, 1, 3, 4, 5, 5},     // ... on an 8 x 16 pixel tile of one image
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -111,8 +113,10 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (cfg < 1 || cfg > kNumConfigs || !buf || len < 8) return EGN_E_BADARG;
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 5)
-    snprintf(buf, len, "void conv_wino%s_kernel<%s, %d>(ConvArgs)", (c.bi & 2) ? "8" : "", (c.bi & 1) ? "8, 8, 4" : "16, 16, 1",
-             c.bi >> 4);
+    if ((c.bi & 15) == 4) snprintf(buf, len, "void conv_wino8_kernel<8, 8, 2, 0, 4>(ConvArgs)");
+    else if ((c.bi & 15) == 5) snprintf(buf, len, "void conv_wino8_kernel<8, 16, 1, 0, 4>(ConvArgs)");
+    else if (c.bi & 2) snprintf(buf, len, "void conv_wino8_kernel<%s, %d, 8>(ConvArgs)", (c.bi & 1) ? "8, 8, 4" : "16, 16, 1", c.bi >> 4);
+    else snprintf(buf, len, "void conv_wino_kernel<%s, %d>(ConvArgs)", (c.bi & 1) ? "8, 8, 4" : "16, 16, 1", c.bi >> 4);
   else if (c.dma == 4 && c.bi == 2)
     snprintf(buf, len, "conv_c48t_kernel(ConvArgs)");
   else if (c.dma == 4 && c.bi == 1)
@@ -160,9 +164,11 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % EGN_CK || a.cs_in != a.Cin ||
         a.Cout % 48 || a.cs_out != a.Cout || a.out_nchw || (a.Ho & 1) || (a.Wo & 1))
       return false;
-    if (cf.bi & 1) { a.TH = 8; a.TW = 8; a.TNB = 4; }
+    if ((cf.bi & 15) == 4) { a.TH = 8; a.TW = 8; a.TNB = 2; }
+    else if ((cf.bi & 15) == 5) { a.TH = 8; a.TW = 16; a.TNB = 1; }
+    else if ((cf.bi & 15) == 1 || (cf.bi & 15) == 3) { a.TH = 8; a.TW = 8; a.TNB = 4; }
     else { a.TH = 16; a.TW = 16; a.TNB = 1; }
-    if ((cf.bi & 1) && (a.Ho > 8 || a.Wo > 8)) return false;   // the batched variant is for the 8 x 8 maps
+    if (a.TH == 8 && a.TW == 8 && (a.Ho > 8 || a.Wo > 8)) return false;   // the batched variant is for the 8 x 8 maps
     a.HH = a.TH + 2; a.HW = a.TW + 2;
     a.npix = a.TNB * a.HH * a.HW; a.npixp = (a.npix + 15) & ~15; a.tps = 16;
     a.tiles_x = (a.Wo + a.TW - 1) / a.TW;

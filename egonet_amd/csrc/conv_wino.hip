@@ -98,6 +98,46 @@ struct WinoGeom<8, 8, 4> {
   static __device__ __forceinline__ int out_tile(int w, int m) { return ((m >> 2) << 16) | (w << 8) | (m & 3); }
 };
 
+// half of the 16 x 16 tile (8 rows x 16 columns = 32 Winograd tiles, conv_wino8_kernel with 4 waves): twice
+// the work items for maps / batches that leave CUs idle with the 64-tile form.  Same slots, fewer rows.
+template <>
+struct WinoGeom<8, 16, 1> {
+  static constexpr int TH = 8, TW = 16, TNB = 1, HH = 10, HW = 18;
+  static constexpr int RP = 24, PLANE = 256;     // 10 rows x 24 slots = 240, padded to 16 x 256 B
+  static constexpr int ROFF = RP;
+  static __device__ __forceinline__ int decode(int p) {
+    const int y = p / RP, x = p - y * RP - ((y >> 1) & 1);
+    return (y < HH && x >= 0 && x < HW) ? ((y << 8) | x) : -1;
+  }
+  static __device__ __forceinline__ int patch_base(int w, int li, int k) {
+    const int tyl = li >> 3, tx = li & 7;
+    return (4 * w + 2 * tyl) * RP + 2 * tx + ((tyl + k) & 1);
+  }
+  static __device__ __forceinline__ int out_tile(int w, int m) { return ((2 * w + (m >> 3)) << 8) | (m & 7); }
+};
+
+// two 8 x 8 images per block (32 Winograd tiles = 2 m-tiles; conv_wino8_kernel with 4 waves): m-tile mt
+// holds tile rows {2mt, 2mt+1} of both images, li = (b = li>>3, row = (li>>2)&1, tx = li&3):
+// slot = b*128 + b + y*12 + x -- 2tx + {0, 24 = 8 mod 16} + {0, 1} covers 0..15.
+template <>
+struct WinoGeom<8, 8, 2> {
+  static constexpr int TH = 8, TW = 8, TNB = 2, HH = 10, HW = 10;
+  static constexpr int RP = 12, IMGP = 128, PLANE = 256;   // 4096 B = 16 x 256
+  static constexpr int ROFF = RP;
+  static __device__ __forceinline__ int decode(int p) {
+    const int b = p / IMGP, r = p - b * IMGP - b;
+    const int y = r / RP, x = r - y * RP;
+    return (r >= 0 && r < HH * RP && x < HW) ? ((b << 16) | (y << 8) | x) : -1;
+  }
+  static __device__ __forceinline__ int patch_base(int mt, int li, int) {
+    const int b = li >> 3, tyl = (li >> 2) & 1, tx = li & 3;
+    return b * IMGP + b + 2 * (2 * mt + tyl) * RP + 2 * tx;
+  }
+  static __device__ __forceinline__ int out_tile(int mt, int m) {
+    return ((m >> 3) << 16) | ((2 * mt + ((m >> 2) & 1)) << 8) | (m & 3);
+  }
+};
+
 template <int TH, int TW, int TNB>
 struct WinoDims {
   using G = WinoGeom<TH, TW, TNB>;
@@ -105,7 +145,7 @@ struct WinoDims {
   static constexpr int IT = (SLOTS + WN_NTH - 1) / WN_NTH;  // DMA instructions per lane and halo chunk
   static constexpr int BUF = IT * WN_NTH;                   // every wave issues IT whole instructions
   static_assert(G::PLANE % 16 == 0, "planes must start on a 256-byte boundary");
-  static_assert(TNB * (TH / 2) * (TW / 2) == 64, "4 waves x 16 Winograd tiles");
+  static_assert(TNB * (TH / 2) * (TW / 2) == 64 || TNB * (TH / 2) * (TW / 2) == 32, "m-tiles of 16 Winograd tiles");
 };
 
 __device__ __forceinline__ void wino_dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
@@ -435,15 +475,21 @@ __global__ __launch_bounds__(WN_NTH, 1) void conv_wino_kernel(ConvArgs a) {
 // fh = 1 keeps -t2 - t3 and sends t2 -- 24 floats per lane through LDS, in the U stage buffer the
 // last K step has just consumed (8 waves x 6 KB = exactly its 48 KB), between two barriers; then
 // each wave finishes and stores the output rows a = fh of its tile.  Per item: nchunk + 2 barriers.
-template <int TH, int TW, int TNB, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvArgs a) {
+// NW = 8 waves on 64 tiles, or NW = 4 waves on 32 tiles (two 8 x 8 images): the 8 x 8 maps at batch 64
+// are only 128 (tile, co-tile) items in the 64-tile form -- half the CUs idle -- and 256 in this one.
+template <int TH, int TW, int TNB, int ABL = 0, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
   using G = WinoGeom<TH, TW, TNB>;
-  constexpr int NTH = 512;
+  constexpr int NTH = 64 * NW;
+  constexpr int MTILES = NW / 2;
+  static_assert(TNB * (TH / 2) * (TW / 2) == 16 * MTILES, "one m-tile per wave pair");
   constexpr int SLOTS = EGN_CKQ * G::PLANE;                 // multiple of 64: whole waves
   constexpr int IT = (SLOTS + NTH - 1) / NTH;               // halo DMA instructions (the last one partial)
   constexpr int BUF = SLOTS;
-  constexpr int UIT = WN_USLOTS / NTH;                      // 6
-  constexpr int NPIECE = IT + UIT;                          // 10
+  constexpr int UIT = WN_USLOTS / NTH;                      // 6 (12 with 4 waves)
+  constexpr int NPIECE = IT + UIT;                          // 10 (16)
+  constexpr int TOPP = 2;                                   // DMA pieces issued at the top of a K step ...
+  constexpr int PERF = (NPIECE - TOPP + 7) / 8;             // ... and after each of the 8 frequencies
   static_assert(SLOTS % 64 == 0 && WN_USLOTS % NTH == 0, "whole-wave DMA pieces");
   extern __shared__ float4 smem[];
   float4* sU = smem;                  // [2][WN_USLOTS]
@@ -452,8 +498,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int mt = wave & 3;   // m-tile (16 Winograd tiles)
-  const int fh = wave >> 2;  // frequency rows {2fh, 2fh+1}
+  const int mt = wave % MTILES;   // m-tile (16 Winograd tiles)
+  const int fh = wave / MTILES;   // frequency rows {2fh, 2fh+1}
   const int li = lane & 15;
   const int kq = lane >> 4;
 
@@ -611,7 +657,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvArgs a) {
           else d[k][cc] = *reinterpret_cast<const f32x4*>(&hb[prow[k] + cc]);
         }
       W8_NEXT(0) W8_NEXT(1)
-      static_assert(NPIECE <= 10, "2 DMA pieces at the top + one per frequency");
+      static_assert(TOPP == 2 && NPIECE <= TOPP + 8 * PERF, "every DMA piece has a slot");
       {
         f32x4 ta[4], tb[4];
         // fh = 0: rows (d0, d1, d2): T0 = d0 - d2, T1 = d1 + d2;  fh = 1: rows (d1, d2, d3): T2 = d2 - d1, T3 = d1 - d3
@@ -649,7 +695,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvArgs a) {
 #pragma unroll
           for (int nt = 0; nt < WN_NT; ++nt)
             acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[f][s], bf[f & 1][nt][s], acc[f][nt], 0, 0, 0);
-        if (2 + f < NPIECE) W8_NEXT(2 + f)
+#pragma unroll
+        for (int k_ = 0; k_ < PERF; ++k_)
+          if (TOPP + f * PERF + k_ < NPIECE) W8_NEXT(TOPP + f * PERF + k_)
       }
 #undef W8_NEXT
       if (last) {
@@ -712,7 +760,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino8_kernel(ConvArgs a) {
       asm volatile("" ::: "memory");
 #pragma unroll
       for (int k4 = 0; k4 < 6; ++k4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&xch[((wave ^ 4) * 6 + k4) * 64 + lane]);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&xch[((wave ^ MTILES) * 6 + k4) * 64 + lane]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int idx = k4 * 4 + e;
@@ -762,12 +810,12 @@ static int wino_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-template <int TH, int TW, int TNB, int ABL = 0>
+template <int TH, int TW, int TNB, int ABL = 0, int NW = 8>
 static int wino8_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
   static bool raised[EGN_MAX_DEVICES];
   static int cus = 0;
   if (egn_first_use_on_device(raised)) {
-    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<TH, TW, TNB, ABL>),
+    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<TH, TW, TNB, ABL, NW>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
   }
   if (!cus) {
@@ -782,16 +830,18 @@ static int wino8_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
   const int ntile = a.tiles_x * a.tiles_y * ((a.N + TNB - 1) / TNB);
   const int nwork = ((ntile + 7) / 8) * 8 * (a.Cout / WN_CO);
   const int grid = nwork < cus ? nwork : cus;
-  hipLaunchKernelGGL((conv_wino8_kernel<TH, TW, TNB, ABL>), dim3(grid), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((conv_wino8_kernel<TH, TW, TNB, ABL, NW>), dim3(grid), dim3(64 * NW), lds, stream, a);
   return (int)hipGetLastError();
 }
 
 // variant 0: 16 x 16 pixel tile of one image; variant 1: four 8 x 8 images (the 8 x 8 maps);
-// variants 2 / 3: the same two geometries on the 8-wave kernel
+// variants 2 / 3: the same two geometries on the 8-wave kernel; variant 4: two 8 x 8 images, 4 waves
 size_t egn_conv_wino_lds_bytes(int variant) {
   const int v = variant & 15;
   size_t halo = (v & 1) ? WinoDims<8, 8, 4>::BUF : WinoDims<16, 16, 1>::BUF;
   if (v >= 2) halo = (v & 1) ? EGN_CKQ * WinoGeom<8, 8, 4>::PLANE : EGN_CKQ * WinoGeom<16, 16, 1>::PLANE;
+  if (v == 4) halo = EGN_CKQ * WinoGeom<8, 8, 2>::PLANE;
+  if (v == 5) halo = EGN_CKQ * WinoGeom<8, 16, 1>::PLANE;
   return (2 * (size_t)WN_USLOTS + 2 * halo) * 16;
 }
 int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t stream) {
@@ -801,6 +851,8 @@ int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t
     case 1: return wino_launch<8, 8, 4>(a, lds, stream);
     case 2: return wino8_launch<16, 16, 1>(a, lds, stream);
     case 3: return wino8_launch<8, 8, 4>(a, lds, stream);
+    case 4: return wino8_launch<8, 8, 2, 0, 4>(a, lds, stream);
+    case 5: return wino8_launch<8, 16, 1, 0, 4>(a, lds, stream);
     case 0x12: return wino8_launch<16, 16, 1, 15>(a, lds, stream);
     case 0x22: return wino8_launch<16, 16, 1, 7>(a, lds, stream);
     case 0x32: return wino8_launch<16, 16, 1, 3>(a, lds, stream);

@@ -126,12 +126,12 @@ def test_conv_winograd_kernels(n, h, w, cin, cout, res, act):
     import ctypes as C
     from egonet_amd import _lib
     L = _lib.lib()
-    assert [L.egn_conv_config_kind(c) for c in (44, 45, 46, 51, 52)] == [0, 1, 1, 1, 1]
+    assert [L.egn_conv_config_kind(c) for c in (44, 45, 46, 51, 52, 56, 57)] == [0, 1, 1, 1, 1, 1, 1]
     assert L.egn_conv_config_kind(47) == -1 and L.egn_conv_config_kind(53) == -1     # timing ablations: never selectable
     out = (C.c_int * 12)()
-    for cfg in (45, 46, 51, 52):
+    for cfg in (45, 46, 51, 52, 56, 57):    # 56 / 57: 4 waves on 32 tiles (two 8 x 8 images / an 8 x 16 tile)
         rc = L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, cfg, out)
-        if cfg in (46, 52) and (h > 8 or w > 8):
+        if cfg in (46, 52, 56) and (h > 8 or w > 8):
             assert rc != 0
             continue
         assert rc == 0
