@@ -74,7 +74,11 @@ class FCModel(nn.Module):
 
     def _hip_engine(self):
         from egonet_amd import engine
-        if self._engine is None:
+        # `is not self`: an nn.DataParallel replica is a shallow copy whose `_engine` attribute still
+        # points at the original module's engine (and its packed weights) -- a replica folds its own
+        # parameters (re-built on every forward there: DataParallel is supported for API
+        # compatibility, the rank-per-GPU launcher is the performance path)
+        if self._engine is None or self._engine.model is not self:
             self._engine = engine.LifterEngine(self)
         return self._engine
 

@@ -191,6 +191,8 @@ def test_winograd_halo_layout_is_bank_conflict_free():
     import wino_emulator
     assert wino_emulator.worst_bank_conflict(16, 16, 1) == 1
     assert wino_emulator.worst_bank_conflict(8, 8, 4) == 1
+    assert wino_emulator.worst_bank_conflict(8, 8, 2) == 1          # the 32-tile forms of the 8-wave kernel
+    assert wino_emulator.worst_bank_conflict(8, 16, 1) == 1
 
 
 def test_winograd_kernel_design_vs_torch():
@@ -202,3 +204,16 @@ def test_winograd_kernel_design_vs_torch():
     assert wino_emulator.conv_case(1, 16, 16, 16, 48, 16, 16, 1) < 2e-5
     assert wino_emulator.conv_case(1, 24, 8, 32, 96, 16, 16, 1, seed=1) < 2e-5     # partial tiles, 2 co-tiles
     assert wino_emulator.conv_case(5, 8, 8, 16, 48, 8, 8, 4, seed=2) < 2e-5        # partial image batch
+
+
+def test_winograd_frequency_halves_kernel_design_vs_torch():
+    """conv_wino8_kernel (what runs): waves = (m-tile, frequency half), the three patch rows a half
+    reads, its half of the U slab, the t1 / t2 exchange between the two waves of an m-tile and the
+    output rows a = fh each wave stores -- for all four geometries (8 waves on 64 tiles, 4 waves on
+    32 tiles), incl. partial tiles / partial image batches."""
+    import wino_emulator
+    assert wino_emulator.conv_case8(1, 16, 16, 16, 48, 16, 16, 1) < 2e-5
+    assert wino_emulator.conv_case8(1, 24, 8, 32, 96, 16, 16, 1, seed=1) < 2e-5
+    assert wino_emulator.conv_case8(5, 8, 8, 16, 48, 8, 8, 4, seed=2) < 2e-5
+    assert wino_emulator.conv_case8(3, 8, 8, 32, 48, 8, 8, 2, seed=3) < 2e-5       # two images per block, odd batch
+    assert wino_emulator.conv_case8(1, 12, 16, 16, 96, 8, 16, 1, seed=4) < 2e-5    # 8 x 16 tile, partial rows

@@ -330,10 +330,20 @@ def test_engine_notices_every_weight_and_buffer_change():
     assert net._engine is None                              # dropped on .train()
     net.eval()
     np.testing.assert_array_equal(net(x)[0].cpu().numpy(), y1.cpu().numpy())
-    # ... and an nn.DataParallel-style shallow replica shares the programs but not the staleness
-    import copy
-    rep = copy.copy(net)
+    # ... an nn.DataParallel replica (shallow copy with its own parameter tensors, re-created on every
+    # forward) folds ITS parameters, not the engine it inherited from the original module
+    rep = torch.nn.parallel.replicate(net, [0, 0])[1]
+    assert rep._engine is net._engine                       # what the shallow copy starts with
     np.testing.assert_array_equal(rep(x)[0].cpu().numpy(), y1.cpu().numpy())
+    assert rep._engine is not net._engine and rep._engine.model is rep
+    with torch.no_grad():
+        for p_ in rep.parameters():
+            p_.mul_(0.5)                                    # replica-only change
+    assert float((rep(x)[0] - y1).abs().max()) > 1e-4
+    np.testing.assert_array_equal(net(x)[0].cpu().numpy(), y1.cpu().numpy())      # the original is untouched
+    # nn.DataParallel itself (one device: the module is called directly)
+    dp = torch.nn.DataParallel(net, device_ids=[0])
+    np.testing.assert_array_equal(dp(x)[0].cpu().numpy(), y1.cpu().numpy())
 
 
 def test_program_timing_and_graph_replay():

@@ -97,3 +97,18 @@ def test_pixel_shuffle_and_angle_heads_match_the_reference_on_cpu():
             out = net(x)
         assert tuple(out.shape) == shape == g['out'].shape
         np.testing.assert_allclose(out.numpy(), g['out'], rtol=0, atol=1e-5)
+
+
+def test_forward_hooks_fire_like_get_model_summary_expects():
+    """libs/common/utils.py:91-95 (get_model_summary) registers forward hooks on the leaf modules and
+    runs one CPU forward (tools/train_IGRs.py:54-57): every conv / BatchNorm leaf is called once."""
+    from egonet_amd import configs
+    from egonet_amd.model.heatmapModel import hrnet
+    net = hrnet.get_pose_net(configs.tiny_config('coordinates'), is_train=False).eval()
+    leaves = [m for m in net.modules() if isinstance(m, (torch.nn.Conv2d, torch.nn.BatchNorm2d))]
+    calls = []
+    hooks = [m.register_forward_hook(lambda mod, i, o: calls.append(id(mod))) for m in leaves]
+    net(torch.randn(1, 3, 64, 64))
+    for h in hooks:
+        h.remove()
+    assert sorted(calls) == sorted(id(m) for m in leaves)

@@ -23,8 +23,25 @@ B128_GROUPS += [[l + 32 for l in g] for g in B128_GROUPS]
 def geometry(TH, TW, TNB):
     """(PLANE, ROFF, decode, patch_base, out_tile) of WinoGeom<TH,TW,TNB>."""
     HH, HW = TH + 2, TW + 2
+    if (TH, TW, TNB) == (8, 8, 2):                      # WinoGeom<8,8,2>: two images, 4-wave kernel
+        RP, IMGP, PLANE = 12, 128, 256
+
+        def decode(p):
+            b = p // IMGP
+            r = p - b * IMGP - b
+            y = r // RP
+            x = r - y * RP
+            return (b, y, x) if (0 <= r < HH * RP and x < HW) else None
+
+        def patch_base(w, li, k):
+            b, tyl, tx = li >> 3, (li >> 2) & 1, li & 3
+            return b * IMGP + b + 2 * (2 * w + tyl) * RP + 2 * tx
+
+        def out_tile(w, m):
+            return (m >> 3, 2 * w + ((m >> 2) & 1), m & 3)
+        return PLANE, RP, decode, patch_base, out_tile
     if TNB == 1:
-        RP, PLANE = 24, 432
+        RP, PLANE = 24, (432 if TH == 16 else 256)      # WinoGeom<16,16,1> / <8,16,1>
 
         def decode(p):
             y = p // RP
@@ -64,7 +81,7 @@ def worst_bank_conflict(TH, TW, TNB):
     (1 = conflict free) over every patch element and wave."""
     PLANE, ROFF, _, patch_base, _ = geometry(TH, TW, TNB)
     worst = 0
-    for w in range(4):
+    for w in range(TNB * (TH // 2) * (TW // 2) // 16):
         for r in range(4):
             for cc in range(4):
                 for grp in B128_GROUPS:
@@ -163,4 +180,130 @@ def conv_case(N, H, W, C, Co, TH, TW, TNB, seed=0):
     y = emulate(x.permute(0, 2, 3, 1).contiguous().numpy(), pack_wino_weight(wt).numpy(), sc.numpy(), sh.numpy(),
                 res.permute(0, 2, 3, 1).contiguous().numpy(), N, H, W, C, Co, TH, TW, TNB, True)
     assert not np.isnan(y).any()          # every output written exactly once
+    return float(np.abs(y - ref.permute(0, 2, 3, 1).numpy()).max())
+
+
+def emulate8(x, upack, scale, shift, res, N, H, W, C, Co, TH, TW, TNB, relu):
+    """conv_wino8_kernel<TH,TW,TNB,0,NW>: NW = 2 * (tiles per block / 16) waves; wave (mt, fh) owns the
+    frequency rows {2fh, 2fh+1} of m-tile mt; partial exchange t1 / t2 between the two waves of an m-tile;
+    each wave stores the output rows a = fh of its tiles."""
+    HH, HW = TH + 2, TW + 2
+    PLANE, ROFF, decode, patch_base, out_tile = geometry(TH, TW, TNB)
+    MT = TNB * (TH // 2) * (TW // 2) // 16
+    NW = 2 * MT
+    NTH = 64 * NW
+    SLOTS = 4 * PLANE
+    IT = -(-SLOTS // NTH)
+    nct, nchunk = Co // 48, C // 16
+    tiles_x, tiles_y = -(-W // TW), -(-H // TH)
+    tiles_xy = tiles_x * tiles_y
+    ntile = tiles_xy * (-(-N // TNB))
+    nwork = ((ntile + 7) >> 3) * nct * 8
+    xf, uf = x.reshape(-1), upack.reshape(-1, 4)
+    y = np.full((N, H, W, Co), np.nan, np.float32)
+    for w in range(nwork):
+        x_, q_ = w & 7, w >> 3
+        tile, ct = (q_ // nct) * 8 + x_, q_ % nct
+        tb = tile // tiles_xy
+        r_ = tile - tb * tiles_xy
+        ty_, tx_ = r_ // tiles_x, r_ % tiles_x
+        n0, iy0, ix0 = tb * TNB, ty_ * TH - 1, tx_ * TW - 1
+        acc = np.zeros((NTH, 8, 3, 4), np.float32)          # per thread: [f][nt][r]
+        for c in range(nchunk):
+            sH = np.zeros((SLOTS, 4), np.float32)
+            for it in range(IT):
+                for t in range(NTH):
+                    e = it * NTH + t
+                    if e >= SLOTS:                           # waves beyond the image skip the partial piece
+                        continue
+                    q = e // PLANE
+                    m = decode(e - q * PLANE)
+                    if m is not None and tile < ntile:
+                        b, hy, hx = m
+                        n, iy, ix = n0 + b, iy0 + hy, ix0 + hx
+                        if n < N and 0 <= iy < H and 0 <= ix < W:
+                            off = ((n * H + iy) * W + ix) * C + q * 4 + c * 16
+                            sH[e] = xf[off:off + 4]
+            base = (ct * nchunk + c) * 3072
+            sU = uf[base:base + 3072]
+            Vall = np.zeros((NTH, 8, 4), np.float32)
+            for t in range(NTH):
+                wave, lane = t >> 6, t & 63
+                mt, fh, li, kq = wave % MT, wave // MT, lane & 15, lane >> 4
+                d = []
+                for k in range(3):
+                    r = fh + k
+                    row = kq * PLANE + patch_base(mt, li, r >> 1) + r * ROFF
+                    d.append(np.stack([sH[row + cc] for cc in range(4)]))
+                if fh == 0:
+                    ta, tb_ = d[0] - d[2], d[1] + d[2]
+                else:
+                    ta, tb_ = d[1] - d[0], d[0] - d[2]
+                for ii, tt in enumerate((ta, tb_)):
+                    Vall[t, ii * 4 + 0] = tt[0] - tt[2]
+                    Vall[t, ii * 4 + 1] = tt[1] + tt[2]
+                    Vall[t, ii * 4 + 2] = tt[2] - tt[1]
+                    Vall[t, ii * 4 + 3] = tt[1] - tt[3]
+            for wv in range(NW):
+                fh = wv // MT
+                for f in range(8):
+                    A = np.zeros((16, 16), np.float32)
+                    for l in range(64):
+                        A[l & 15, (l >> 4) * 4:(l >> 4) * 4 + 4] = Vall[wv * 64 + l, f]
+                    for nt in range(3):
+                        B = np.zeros((16, 16), np.float32)
+                        for l in range(64):
+                            B[(l >> 4) * 4:(l >> 4) * 4 + 4, l & 15] = \
+                                sU[((fh * 8 + f) * 4 + (l >> 4)) * 48 + nt * 16 + (l & 15)]
+                        Cm = A @ B
+                        for l in range(64):
+                            for r in range(4):
+                                acc[wv * 64 + l, f, nt, r] += Cm[4 * (l >> 4) + r, l & 15]
+        # output transform halves + exchange
+        keep = np.zeros((NTH, 3, 4, 2), np.float32)
+        send = np.zeros((NTH, 3, 4, 2), np.float32)
+        for t in range(NTH):
+            fh = (t >> 6) // MT
+            for nt in range(3):
+                for r in range(4):
+                    a = acc[t, :, nt, r]
+                    t0 = (a[0] + a[1] + a[2], a[1] - a[2] - a[3])
+                    t1 = (a[4] + a[5] + a[6], a[5] - a[6] - a[7])
+                    for pb in range(2):
+                        keep[t, nt, r, pb] = t0[pb] + t1[pb] if fh == 0 else -t0[pb] - t1[pb]
+                        send[t, nt, r, pb] = t1[pb] if fh == 0 else t0[pb]
+        for t in range(NTH):
+            wave, lane = t >> 6, t & 63
+            mt, fh, li, kq = wave % MT, wave // MT, lane & 15, lane >> 4
+            partner = ((wave ^ MT) << 6) | lane
+            for r in range(4):
+                b, ty, tx = out_tile(mt, 4 * kq + r)
+                n, oy, ox = tb * TNB + b, ty_ * TH + 2 * ty + fh, tx_ * TW + 2 * tx
+                if not (tile < ntile and n < N and oy < H and ox < W):
+                    continue
+                for nt in range(3):
+                    co = ct * 48 + nt * 16 + li
+                    for pb in range(2):
+                        v = (keep[t, nt, r, pb] + send[partner, nt, r, pb]) * scale[co] + shift[co]
+                        if res is not None:
+                            v += res[n, oy, ox + pb, co]
+                        if relu:
+                            v = max(v, 0.)
+                        assert np.isnan(y[n, oy, ox + pb, co])
+                        y[n, oy, ox + pb, co] = v
+    return y
+
+
+def conv_case8(N, H, W, C, Co, TH, TW, TNB, seed=0):
+    """max |emulated 8-/4-wave frequency-halves kernel - torch conv2d(+scale/shift, residual, ReLU)|."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C, H, W, generator=g)
+    wt = torch.randn(Co, C, 3, 3, generator=g) * 0.1
+    sc = torch.rand(Co, generator=g) + 0.5
+    sh = torch.randn(Co, generator=g)
+    res = torch.randn(N, Co, H, W, generator=g)
+    ref = torch.relu(torch.nn.functional.conv2d(x, wt, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res)
+    y = emulate8(x.permute(0, 2, 3, 1).contiguous().numpy(), pack_wino_weight(wt).numpy(), sc.numpy(), sh.numpy(),
+                 res.permute(0, 2, 3, 1).contiguous().numpy(), N, H, W, C, Co, TH, TW, TNB, True)
+    assert not np.isnan(y).any()
     return float(np.abs(y - ref.permute(0, 2, 3, 1).numpy()).max())
