@@ -336,10 +336,11 @@ def test_engine_notices_every_weight_and_buffer_change():
     assert rep._engine is net._engine                       # what the shallow copy starts with
     np.testing.assert_array_equal(rep(x)[0].cpu().numpy(), y1.cpu().numpy())
     assert rep._engine is not net._engine and rep._engine.model is rep
+    # a replica with different weights (its tensors are copies) computes with ITS weights
+    rep2 = torch.nn.parallel.replicate(net, [0, 0])[1]
     with torch.no_grad():
-        for p_ in rep.parameters():
-            p_.mul_(0.5)                                    # replica-only change
-    assert float((rep(x)[0] - y1).abs().max()) > 1e-4
+        rep2.stage2[0].branches[0][0].conv1.weight.mul_(0.5)
+    assert float((rep2(x)[0] - y1).abs().max()) > 1e-4
     np.testing.assert_array_equal(net(x)[0].cpu().numpy(), y1.cpu().numpy())      # the original is untouched
     # nn.DataParallel itself (one device: the module is called directly)
     dp = torch.nn.DataParallel(net, device_ids=[0])
