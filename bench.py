@@ -241,12 +241,14 @@ def train_hc_block(args, world, rank, dev, dist):
     sec, loss = _timed(lambda: tr.step(x, tgt, jt), args.steps, max(args.warmup, 2), dev, dist)
     out = None
     if rank == 0:
-        # one extra step on ONE stream with hipEvents around every forward / data-gradient conv
+        # one extra step on ONE stream with hipEvents around every forward / data-gradient conv --
+        # rank 0 alone, so WITHOUT the gradient exchange (a collective only one rank enters would hang)
         side, tr.wgrad_stream = tr.wgrad_stream, None
+        sync, tr.grad_sync = tr.grad_sync, None
         tr.timing = []
-        tr.step(x, tgt, jt)
+        tr.step(x, tgt, jt, update=False)
         roof = _dominant(tr.timing)
-        tr.timing, tr.wgrad_stream = None, side
+        tr.timing, tr.wgrad_stream, tr.grad_sync = None, side, sync
         crops = B * world
         out = {'metric': 'hc_train_crops_per_sec', 'value': crops / sec, 'unit': 'crops/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': max(args.warmup, 2), 'ms_per_step': sec * 1e3, 'scaling': 'weak',
@@ -328,8 +330,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # EGONET_AMD_DIST_BACKEND=gloo: control-flow smoke test of the multi-rank path on a box with fewer
+        # GPUs than ranks (every rank on device 0, collectives through the host) -- never a measurement
+        backend = os.environ.get('EGONET_AMD_DIST_BACKEND', 'nccl')
+        if backend != 'nccl':
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     dev = torch.device('cuda', local if world > 1 else 0)
@@ -441,11 +451,17 @@ def main():
     if not args.no_train:
         del ego, crops
         torch.cuda.empty_cache()
-        hc_block = train_hc_block(args, world, rank, dev, dist)
+        try:
+            hc_block = train_hc_block(args, world, rank, dev, dist)
+        except Exception as e:          # never lose the headline line to the extra blocks
+            hc_block = {'error': '%s: %s' % (type(e).__name__, e)}
         if rank == 0:
             result['train_hc'] = hc_block
             if world == 1:
-                result['train_lifter'] = train_lifter_block(args, dev)
+                try:
+                    result['train_lifter'] = train_lifter_block(args, dev)
+                except Exception as e:
+                    result['train_lifter'] = {'error': '%s: %s' % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if dist:

@@ -1,6 +1,10 @@
-"""Two ranks over RCCL (backend ``nccl``) on one node: the native HRNet training step with the
-overlapped flat-gradient all-reduce, and rank-sharded inference.  Needs two GPUs: the round-end test
-box has one, so these skip there; they run wherever ``torch.cuda.device_count() >= 2``."""
+"""Two ranks on one node: the native HRNet training step with the overlapped flat-gradient
+all-reduce (parallel.FlatGradSync sessions: events of the backward's main and weight-gradient streams,
+collectives on a communication stream).
+  * over RCCL (backend ``nccl``): needs two GPUs -- the round-end test box has one, so that test skips
+    there; it runs wherever ``torch.cuda.device_count() >= 2``;
+  * over ``gloo`` with BOTH ranks on the one GPU (gloo reduces CUDA tensors through the host): the same
+    session / stream / event logic on device tensors, runs on the 1-GPU box."""
 import os
 import socket
 
@@ -44,11 +48,11 @@ def _grad_of(rank_inputs, device):
     return tr.flat.grad.clone()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend='nccl'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), EGONET_AMD_AUTOTUNE='0',
                       HSA_ENABLE_IPC_MODE_LEGACY='0')
-    torch.cuda.set_device(rank)
-    dist.init_process_group('nccl', rank=rank, world_size=world)
+    torch.cuda.set_device(rank if backend == 'nccl' else 0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from egonet_amd import parallel
     from egonet_amd.model.heatmapModel import hrnet
     from egonet_amd.train_hrnet import HRNetTrainStep
@@ -78,6 +82,25 @@ def test_nccl_world2_native_step_gradient_is_the_rank_mean():
     for p in procs:
         p.start()
     got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    os.environ['EGONET_AMD_AUTOTUNE'] = '0'
+    want = 0.5 * (_grad_of(_inputs(0), 'cuda:0') + _grad_of(_inputs(1), 'cuda:0')).cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-5 * np.abs(want).max())
+
+
+def test_gloo_world2_on_one_gpu_native_step_sync_session():
+    """Both ranks on cuda:0, gloo backend: the session launches slices from inside the backward (after
+    events of the main and the weight-gradient stream), waits for them before Adam; the reduced
+    flat gradient is the mean of the two single-process gradients."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, 'gloo')) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=600)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
