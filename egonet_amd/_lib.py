@@ -60,6 +60,9 @@ SIGNATURES = {
     'egn_colreduce_ws_bytes': (C.c_long, [_i]),
     'egn_colsum_f32': (_i, [_p, _i, _i, _i, _p, _p, _p]),
     'egn_bn_stats_f32': (_i, [_p, _i, _i, _i, C.c_float, _p, _p, _p, _p, _p, C.c_float, _p, _p]),
+    'egn_conv2d_bnstats_rows': (C.c_long, [_i] * 12),
+    'egn_conv2d_bnstats_f32': (_i, [_p] * 5 + [_i] * 12 + [_p, C.c_long, _p]),
+    'egn_bn_stats_finalize_f32': (_i, [_p, C.c_long, _i, _i, C.c_float, _p, _p, _p, _p, _p, C.c_float, _p]),
     'egn_bn_act_fwd_f32': (_i, [_p, _p, _p, _p, _p, _p, C.c_float, _i, _p, _p, _i, _i, _i, _p]),
     'egn_bn_bwd_sums_f32': (_i, [_p, _p, _p, C.c_float, _p, _p, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p]),
     'egn_bn_bwd_dz_f32': (_i, [_p, _p, _p, C.c_float, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),

@@ -21,6 +21,7 @@ int egn_conv_launch_dma(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t s
 int egn_conv_launch_c48(const ConvArgs& a, size_t lds, int waves, hipStream_t stream);
 int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t stream);
 size_t egn_conv_wino_lds_bytes(int variant);
+int egn_conv_wino_stats_rows(const ConvArgs& a, int variant);
 
 static const ConvConfig kConfigs[] = {
     // id wm wn mt nt ai bi dma (ai / bi = staging depth in dwordx4 per lane)
@@ -282,6 +283,14 @@ int egn_conv_plan(ConvArgs& a, int& cfg_id, size_t& lds_bytes) {
   // 32-bit byte offsets into y / res (buffer stores in the NHWC epilogue)
   if (!a.out_nchw && (double)a.N * a.Ho * a.Wo * a.cs_out * 4.0 >= 2147483648.0) return EGN_E_BADARG;
   return 0;
+}
+
+// rows of the partial-statistics table a launch with a.stats != NULL writes; 0 = config without fused
+// BatchNorm statistics (a must be planned for cfg_id)
+int egn_conv_stats_rows(const ConvArgs& a, int cfg_id) {
+  if (cfg_id < 1 || cfg_id > kNumConfigs) return 0;
+  const ConvConfig& cf = kConfigs[cfg_id - 1];
+  return cf.dma == 5 ? egn_conv_wino_stats_rows(a, cf.bi) : 0;
 }
 
 int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {

@@ -494,6 +494,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
   extern __shared__ float4 smem[];
   float4* sU = smem;                  // [2][WN_USLOTS]
   float4* sH = smem + 2 * WN_USLOTS;  // [2][BUF]
+  double* sS = reinterpret_cast<double*>(smem + 2 * WN_USLOTS + 2 * BUF);  // [NW][2][48] BatchNorm partial sums
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -578,6 +579,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
   int w = blockIdx.x;
   int tile = 0, ct = 0;
   W8_ITEM(w, tile, ct)
+  const int ct_block = ct;            // constant over the block's items (the launcher sizes the grid for it)
+  if (a.stats != nullptr) {           // own-wave rows only: no barrier needed before the first use
+    for (int e = lane; e < 2 * WN_CO; e += 64) sS[wave * 2 * WN_CO + e] = 0.0;
+  }
   unsigned doff[IT];
   W8_DOFF(tile, doff)
   if (w < nwork) {
@@ -768,6 +773,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
         }
       }
     }
+    float st1[WN_NT] = {0.f, 0.f, 0.f}, st2[WN_NT] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int nt = 0; nt < WN_NT; ++nt)
 #pragma unroll
@@ -777,9 +783,46 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
           float v = keep[nt][r][pb] * sc[nt] + sh[nt] + rv[r][pb][nt];
           v = fmaxf(v, act_lo);
           wino_store4(ry, ((ABL & 4) && v != 12345.678f) ? EGN_OOB : voff[r], pb * colpitch + nt * 64u, v);
+          if (voff[r] != EGN_OOB) { st1[nt] += v; st2[nt] += v * v; }
         }
+    if (a.stats != nullptr) {
+      // BatchNorm batch statistics ride in the epilogue (training: raw conv output, scale 1 / shift 0):
+      // this wave's column sums over its 16 tiles x 2 pixels -- lanes li + 16*kq hold the same channel --
+      // are added to the wave's own row of a small LDS table (doubles); the block writes ONE partial
+      // row at the end of the kernel (its co-tile is the same for all its items, see wino8_grid)
+#pragma unroll
+      for (int nt = 0; nt < WN_NT; ++nt) {
+        st1[nt] += __shfl_xor(st1[nt], 16);
+        st1[nt] += __shfl_xor(st1[nt], 32);
+        st2[nt] += __shfl_xor(st2[nt], 16);
+        st2[nt] += __shfl_xor(st2[nt], 32);
+      }
+      if (kq == 0) {
+        double* srow = sS + wave * 2 * WN_CO + li;
+#pragma unroll
+        for (int nt = 0; nt < WN_NT; ++nt) {
+          srow[nt * 16] += (double)st1[nt];
+          srow[WN_CO + nt * 16] += (double)st2[nt];
+        }
+      }
+    }
     tile = tile_n;
     ct = ct_n;
+  }
+  if (a.stats != nullptr) {
+    // one partial row per block: [2][Cout] doubles, the block's 48 columns = its waves' sums in wave
+    // order, zeros elsewhere (egn_bn_stats_finalize_f32 adds the rows of all blocks in a fixed order)
+    __syncthreads();
+    double* row = a.stats + (size_t)blockIdx.x * 2 * Co;
+    for (int e = tid; e < 2 * Co; e += NTH) {
+      const int which = e / Co, c = e - which * Co;
+      const int cl = c - ct_block * WN_CO;
+      double v = 0.0;
+      if (cl >= 0 && cl < WN_CO) {
+        for (int k = 0; k < NW; ++k) v += sS[(k * 2 + which) * WN_CO + cl];
+      }
+      row[e] = v;
+    }
   }
 #undef W8_ITEM
 #undef W8_DOFF
@@ -810,28 +853,44 @@ static int wino_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-template <int TH, int TW, int TNB, int ABL = 0, int NW = 8>
-static int wino8_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
-  static bool raised[EGN_MAX_DEVICES];
+// persistent grid of the frequency-halves kernel: at most one block per CU, a multiple of 8 * nct so that
+// (a) blocks w, w+8, ... stay on one XCD and (b) a block's items all have the same co-tile
+// (ct = (w >> 3) % nct and w advances by the grid size) -- its BatchNorm partial row covers one co-tile
+static int wino8_grid(const ConvArgs& a, int tnb) {
   static int cus = 0;
-  if (egn_first_use_on_device(raised)) {
-    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<TH, TW, TNB, ABL, NW>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-  }
   if (!cus) {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
       cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
-    cus &= ~7;
-    if (cus <= 0) cus = 8;
   }
-  const int ntile = a.tiles_x * a.tiles_y * ((a.N + TNB - 1) / TNB);
-  const int nwork = ((ntile + 7) / 8) * 8 * (a.Cout / WN_CO);
-  const int grid = nwork < cus ? nwork : cus;
+  const int nct = a.Cout / WN_CO;
+  const int ntile = a.tiles_x * a.tiles_y * ((a.N + tnb - 1) / tnb);
+  const int nwork = ((ntile + 7) / 8) * 8 * nct;
+  int cap = cus / (8 * nct) * (8 * nct);
+  if (cap <= 0) cap = 8 * nct;
+  return nwork < cap ? nwork : cap;
+}
+
+template <int TH, int TW, int TNB, int ABL = 0, int NW = 8>
+static int wino8_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
+  static bool raised[EGN_MAX_DEVICES];
+  if (egn_first_use_on_device(raised)) {
+    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<TH, TW, TNB, ABL, NW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+  }
+  const int grid = wino8_grid(a, TNB);
   hipLaunchKernelGGL((conv_wino8_kernel<TH, TW, TNB, ABL, NW>), dim3(grid), dim3(64 * NW), lds, stream, a);
   return (int)hipGetLastError();
+}
+
+// rows of the BatchNorm partial table a launch writes (0 = this variant has no fused statistics)
+int egn_conv_wino_stats_rows(const ConvArgs& a, int variant) {
+  const int v = variant & 15;
+  if ((variant >> 4) || v < 2) return 0;
+  const int tnb = v == 3 ? 4 : (v == 4 ? 2 : 1);
+  return wino8_grid(a, tnb);       // one partial row per block
 }
 
 // variant 0: 16 x 16 pixel tile of one image; variant 1: four 8 x 8 images (the 8 x 8 maps);
@@ -842,7 +901,8 @@ size_t egn_conv_wino_lds_bytes(int variant) {
   if (v >= 2) halo = (v & 1) ? EGN_CKQ * WinoGeom<8, 8, 4>::PLANE : EGN_CKQ * WinoGeom<16, 16, 1>::PLANE;
   if (v == 4) halo = EGN_CKQ * WinoGeom<8, 8, 2>::PLANE;
   if (v == 5) halo = EGN_CKQ * WinoGeom<8, 16, 1>::PLANE;
-  return (2 * (size_t)WN_USLOTS + 2 * halo) * 16;
+  const size_t stats = v >= 2 ? (size_t)((v == 4 || v == 5) ? 4 : 8) * 2 * WN_CO * sizeof(double) : 0;
+  return (2 * (size_t)WN_USLOTS + 2 * halo) * 16 + stats;
 }
 int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t stream) {
   const int act = a.act & EGN_ACT_MASK;

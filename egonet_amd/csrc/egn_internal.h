@@ -42,6 +42,9 @@ struct ConvArgs {
   int nchunk, taps, tps;  // K chunks, taps = KH*KW, taps per LDS stage
   int act, out_nchw;
   int spix_off;  // LDS offset (float4 units) of the tile-row -> output-pixel table
+  // training: per-(tile, wave) partial column sums of the stored outputs, [row][2][Cout] doubles
+  // (sum, sum of squares), written by the kernels that support it (conv_wino8_kernel); NULL = off
+  double* stats;
 };
 
 struct ConvConfig {
@@ -57,3 +60,4 @@ struct ConvConfig {
 int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream);
 int egn_conv_plan(ConvArgs& a, int& cfg_id, size_t& lds_bytes);
 const ConvConfig* egn_conv_config(int cfg);
+int egn_conv_stats_rows(const ConvArgs& a, int cfg_id);

@@ -49,6 +49,38 @@ extern "C" int egn_conv2d_f32(const float* x, const float* wpack, const float* s
   return egn_conv_launch(a, cfg, (hipStream_t)stream);
 }
 
+// raw convolution (scale 1, shift 0, no residual, no activation) whose epilogue also writes per-tile
+// partial column sums / sums of squares of its output: BatchNorm's batch statistics without a second
+// pass over z.  Only tile configurations with fused statistics (egn_conv2d_bnstats_rows > 0).
+extern "C" long egn_conv2d_bnstats_rows(int N, int H, int W, int Cin, int cs_in, int Cout, int cs_out, int KH,
+                                        int KW, int stride, int pad, int cfg) {
+  ConvArgs a;
+  if (fill_conv_args(a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, cs_in, Cout, cs_out, KH,
+                     KW, stride, pad, 0, 0))
+    return 0;
+  size_t lds;
+  if (cfg < 1 || egn_conv_plan(a, cfg, lds)) return 0;
+  return egn_conv_stats_rows(a, cfg);
+}
+
+extern "C" int egn_conv2d_bnstats_f32(const float* x, const float* wpack, const float* ones, const float* zeros,
+                                      float* y, int N, int H, int W, int Cin, int cs_in, int Cout, int cs_out,
+                                      int KH, int KW, int stride, int pad, int cfg, double* partials,
+                                      long partial_rows, void* stream) {
+  ConvArgs a;
+  int rc = fill_conv_args(a, x, wpack, ones, zeros, nullptr, y, N, H, W, Cin, cs_in, Cout, cs_out, KH, KW, stride,
+                          pad, EGN_ACT_NONE, 0);
+  if (rc) return rc;
+  if (cfg < 1 || !partials) return EGN_E_BADARG;
+  size_t lds;
+  rc = egn_conv_plan(a, cfg, lds);
+  if (rc) return rc;
+  const int rows = egn_conv_stats_rows(a, cfg);
+  if (rows <= 0 || partial_rows < rows) return EGN_E_BADARG;
+  a.stats = partials;
+  return egn_conv_launch(a, cfg, (hipStream_t)stream);
+}
+
 extern "C" int egn_conv_plan_query(int N, int H, int W, int Cin, int cs_in, int Cout, int cs_out, int KH,
                                    int KW, int stride, int pad, int out_nchw, int cfg, int* out) {
   if (!out) return EGN_E_BADARG;

@@ -294,6 +294,22 @@ extern "C" int egn_bn_stats_f32(const float* z, int rows, int cols, int ld, floa
   return launch_col(p, (double*)ws, stream);
 }
 
+// BatchNorm statistics from partial rows [nrows][2][cols] (doubles: sum, sum of squares) that a
+// convolution epilogue wrote (egn_conv2d_bnstats_f32): the finalise stage of egn_bn_stats_f32 alone
+extern "C" int egn_bn_stats_finalize_f32(const double* partials, long nrows, int rows, int cols, float eps,
+                                         float* mean, float* invstd, float* var_unbiased, float* running_mean,
+                                         float* running_var, float momentum, void* stream) {
+  if (!partials || nrows <= 0 || nrows > 0x7fffffffL || rows <= 0 || cols <= 0 || !mean || !invstd)
+    return EGN_E_BADARG;
+  ColArgs p = {};
+  p.out0 = mean; p.out1 = invstd; p.out2 = var_unbiased;
+  p.run_mean = running_mean; p.run_var = running_var; p.momentum = momentum;
+  p.rows = rows; p.cols = cols; p.ld = cols; p.mode = 1; p.eps = eps;
+  p.nsplit = (int)nrows;
+  hipLaunchKernelGGL(colreduce_final_kernel, dim3((cols + 7) / 8), dim3(256), 0, (hipStream_t)stream, p, partials);
+  return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // y = act(gamma * (z - mean) * invstd + beta) * (mask ? mask * keep_scale : 1)
 // (BatchNorm with the given statistics + ReLU/LeakyReLU + inverted dropout)

@@ -226,7 +226,7 @@ class _Tape(object):
         return self.o.packs.get(weight, dgrad, self.st)
 
     def _conv_launch(self, x, wp, shift, y, n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, act,
-                     weight=None, dgrad=0):
+                     weight=None, dgrad=0, want_stats=False):
         """``wp``: the direct-packed filter (None: packed here from ``weight``).  With ``weight`` (+ ``dgrad``) given, the tuner may pick a
         Winograd configuration for 3x3 stride-1 layers (forward and data gradient alike: the data
         gradient is a stride-1 convolution with the rotated filter); the transformed filter then comes
@@ -238,17 +238,30 @@ class _Tape(object):
             wp = self.o.packs.get(weight, dgrad, self.st, wino=True)
         elif wp is None:
             wp = self._pack(weight, dgrad)
+        stats = None
+        if want_stats and self.o.fuse_bn_stats and cfg > 0:
+            # BatchNorm batch statistics in the conv epilogue (per-tile partial sums, csrc/conv_wino.hip):
+            # saves the separate reduction pass over z where the tile configuration supports it
+            nrows = self.L.egn_conv2d_bnstats_rows(n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, cfg)
+            if nrows > 0:
+                stats = (torch.empty(nrows * 2 * cout, dtype=torch.float64, device=self.dev), nrows)
         tm = self.o.timing
         if tm is not None:         # bench.py: hipEvents around every forward / data-gradient conv launch
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.dev))
-        _lib.check(self.L.egn_conv2d_f32(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(self.o.ones), _lib.ptr(shift), None,
-                                         _lib.ptr(y), n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, act,
-                                         0, cfg, self.st), 'conv')
+        if stats is not None:
+            _lib.check(self.L.egn_conv2d_bnstats_f32(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(self.o.ones), _lib.ptr(shift),
+                                                     _lib.ptr(y), n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride,
+                                                     pad, cfg, _lib.ptr(stats[0]), stats[1], self.st), 'conv+stats')
+        else:
+            _lib.check(self.L.egn_conv2d_f32(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(self.o.ones), _lib.ptr(shift), None,
+                                             _lib.ptr(y), n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, act,
+                                             0, cfg, self.st), 'conv')
         if tm is not None:
             e1.record(torch.cuda.current_stream(self.dev))
             ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
             tm.append((cfg, 2.0 * n * ho * wo * cout * cin * kh * kw, e0, e1))
+        return stats
 
     def _wgrad(self, x, xd, dy, cs_out, weight, stride, pad):
         cout, cin, kh, kw = weight.shape
@@ -387,13 +400,18 @@ class _Tape(object):
 
         if bias is not None:
             raise NotImplementedError('conv bias followed by BatchNorm')
-        self._conv_launch(xd, wp, self.o.zeros, zd, x.n, x.h, x.w, cin, x.cs, cout, z.cs, kh, kw, stride, pad, ACT_NONE,
-                          weight=weight)
+        stats = self._conv_launch(xd, wp, self.o.zeros, zd, x.n, x.h, x.w, cin, x.cs, cout, z.cs, kh, kw, stride, pad,
+                                  ACT_NONE, weight=weight, want_stats=True)
         mean, istd = self._empty(cout), self._empty(cout)
         mom = 0.1 if bn.momentum is None else bn.momentum
-        _lib.check(L.egn_bn_stats_f32(_lib.ptr(zd), rows, cout, z.cs, bn.eps, _lib.ptr(mean), _lib.ptr(istd), None,
-                                      _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), mom,
-                                      _lib.ptr(self.o.col_ws), self.st), 'bn_stats')
+        if stats is not None:      # the conv epilogue wrote per-tile partial sums: only the finalise stage is left
+            _lib.check(L.egn_bn_stats_finalize_f32(_lib.ptr(stats[0]), stats[1], rows, cout, bn.eps, _lib.ptr(mean),
+                                                   _lib.ptr(istd), None, _lib.ptr(bn.running_mean),
+                                                   _lib.ptr(bn.running_var), mom, self.st), 'bn_stats_finalize')
+        else:
+            _lib.check(L.egn_bn_stats_f32(_lib.ptr(zd), rows, cout, z.cs, bn.eps, _lib.ptr(mean), _lib.ptr(istd), None,
+                                          _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var), mom,
+                                          _lib.ptr(self.o.col_ws), self.st), 'bn_stats')
         self.bns.append(bn)
         y = self.new(x.n, ho, wo, cout, cs=z.cs, name=tag)
         yd = self.data[id(y)]
@@ -526,6 +544,7 @@ class HRNetTrainStep(object):
         # 3x3 stride-1 forward / data-gradient convolutions may run on the fused Winograd kernels
         # (csrc/conv_wino.hip) where they measured faster (EGONET_AMD_TRAIN_WINO=0: direct kernels only)
         self.allow_wino = os.environ.get('EGONET_AMD_TRAIN_WINO', '1') != '0'
+        self.fuse_bn_stats = os.environ.get('EGONET_AMD_FUSE_BN_STATS', '1') != '0'
 
     def wgrad_ws(self, nbytes):
         if self._wgrad_ws is None or self._wgrad_ws.numel() * 4 < nbytes:

@@ -251,6 +251,24 @@ int egn_bn_stats_f32(const float* z, int rows, int cols, int ld, float eps,
                      float* mean, float* invstd, float* var_unbiased,
                      float* running_mean, float* running_var, float momentum,
                      void* ws, void* stream);
+/* BatchNorm batch statistics WITHOUT a second pass over the conv output: the raw convolution
+ * (scale = ones, shift = zeros, no residual / activation; `wpack` as egn_conv_config_kind(cfg) says)
+ * whose epilogue also writes, per (tile, wave), the column sums and sums of squares of what it stores:
+ * partials [rows][2][Cout] doubles, rows = egn_conv2d_bnstats_rows(...) (0 = this tile configuration
+ * has no fused statistics: use egn_conv2d_f32 + egn_bn_stats_f32).  egn_bn_stats_finalize_f32 adds
+ * the rows in a fixed order (deterministic) and produces what egn_bn_stats_f32 produces
+ * (`rows` there = N*Ho*Wo, the number of samples per channel). */
+long egn_conv2d_bnstats_rows(int N, int H, int W, int Cin, int cs_in, int Cout,
+                             int cs_out, int KH, int KW, int stride, int pad, int cfg);
+int egn_conv2d_bnstats_f32(const float* x, const float* wpack, const float* ones,
+                           const float* zeros, float* y, int N, int H, int W,
+                           int Cin, int cs_in, int Cout, int cs_out, int KH, int KW,
+                           int stride, int pad, int cfg, double* partials,
+                           long partial_rows, void* stream);
+int egn_bn_stats_finalize_f32(const double* partials, long nrows, int rows, int cols,
+                              float eps, float* mean, float* invstd,
+                              float* var_unbiased, float* running_mean,
+                              float* running_var, float momentum, void* stream);
 /* y = relu?(gamma*(z-mean)*invstd + beta + res?) * (mask ? mask*keep_scale : 1)
  * (BatchNorm on batch statistics + residual + ReLU + inverted dropout) */
 int egn_bn_act_fwd_f32(const float* z, const float* mean, const float* invstd,

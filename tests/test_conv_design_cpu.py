@@ -152,14 +152,15 @@ def test_winograd_configs_plan_and_kinds():
     L = _lib.lib()
     assert [L.egn_conv_config_kind(c) for c in (0, 1, 44, 45, 46, 47, 51, 52, 53, 999)] == \
         [-1, 0, 0, 1, 1, -1, 1, 1, -1, -1]
-    # the 8-wave variants: exact-size halo planes (no padding to whole 512-thread pieces)
+    # the 8-wave variants: exact-size halo planes (no padding to whole 512-thread pieces) + the
+    # [waves][2][48] double table of the BatchNorm partial sums (training)
     p8 = _plan((64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0), cfg=51)
-    assert p8[0] == 51 and p8[1] == 8 and p8[5:8] == [16, 16, 1] and p8[9] == 2 * 49152 + 2 * 4 * 432 * 16
+    assert p8[0] == 51 and p8[1] == 8 and p8[5:8] == [16, 16, 1] and p8[9] == 2 * 49152 + 2 * 4 * 432 * 16 + 8 * 2 * 48 * 8
     p8 = _plan((64, 8, 8, 384, 384, 384, 384, 3, 3, 1, 1, 0), cfg=52)
-    assert p8[5:8] == [8, 8, 4] and p8[9] == 2 * 49152 + 2 * 4 * 448 * 16 and p8[11] == 8
+    assert p8[5:8] == [8, 8, 4] and p8[9] == 2 * 49152 + 2 * 4 * 448 * 16 + 8 * 2 * 48 * 8 and p8[11] == 8
     # 4 waves on 32 tiles: twice the work items for the 8 x 8 maps (128 -> 256 at batch 64) / small batches
     p4 = _plan((64, 8, 8, 384, 384, 384, 384, 3, 3, 1, 1, 0), cfg=56)
-    assert p4[1] == 4 and p4[5:8] == [8, 8, 2] and p4[10] * p4[11] == 256 and p4[9] == 2 * 49152 + 2 * 4 * 256 * 16
+    assert p4[1] == 4 and p4[5:8] == [8, 8, 2] and p4[10] * p4[11] == 256 and p4[9] == 2 * 49152 + 2 * 4 * 256 * 16 + 4 * 2 * 48 * 8
     p4 = _plan((32, 16, 16, 192, 192, 192, 192, 3, 3, 1, 1, 0), cfg=57)
     assert p4[5:8] == [8, 16, 1] and p4[10] * p4[11] == 256
     assert L.egn_conv_plan_query(64, 16, 16, 192, 192, 192, 192, 3, 3, 1, 1, 0, 56, (C.c_int * 12)()) != 0

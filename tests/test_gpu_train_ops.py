@@ -483,3 +483,50 @@ def test_cross_ratio_term_accumulates_and_scales():
     assert loss2 == loss
     L = _lib.lib()
     assert L.egn_cross_ratio_f32(_lib.ptr(c), 6, 33, None, 12, 4 / 3, 0.15, 2, 1.0, None, None, None, _st()) != 0
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,cfg', [
+    (3, 32, 32, 48, 48, 51),      # 8 waves, 16 x 16 tiles
+    (5, 8, 8, 32, 96, 52),        # four 8 x 8 images per block, partial batch, two co-tiles
+    (3, 8, 8, 48, 48, 56),        # 4 waves, two images per block
+    (2, 24, 16, 16, 144, 57),     # 4 waves, 8 x 16 tiles, three co-tiles
+])
+def test_bn_statistics_fused_into_the_winograd_conv_epilogue(n, h, w, cin, cout, cfg):
+    """egn_conv2d_bnstats_f32 + egn_bn_stats_finalize_f32 == egn_conv2d_f32 + egn_bn_stats_f32: same
+    conv output bit for bit, mean / invstd / running statistics to fp32 rounding (the partial sums are
+    grouped per (tile, wave) instead of per row block)."""
+    from egonet_amd import _lib, engine
+    L = _lib.lib()
+    st = _lib.current_stream()
+    g = torch.Generator().manual_seed(cfg)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    wu = engine.pack_wino_weight(wt).cuda()
+    ones, zeros = torch.ones(cout + 16).cuda(), torch.zeros(cout + 16).cuda()
+    rows = n * h * w
+    nrows = L.egn_conv2d_bnstats_rows(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, cfg)
+    assert nrows > 0 and L.egn_conv2d_bnstats_rows(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 16) == 0
+    part = torch.full((nrows * 2 * cout,), float('nan'), dtype=torch.float64, device='cuda')
+    y1, y2 = torch.empty(n, h, w, cout).cuda(), torch.empty(n, h, w, cout).cuda()
+    _lib.check(L.egn_conv2d_bnstats_f32(_lib.ptr(x), _lib.ptr(wu), _lib.ptr(ones), _lib.ptr(zeros), _lib.ptr(y1),
+                                        n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, cfg, _lib.ptr(part), nrows, st))
+    _lib.check(L.egn_conv2d_f32(_lib.ptr(x), _lib.ptr(wu), _lib.ptr(ones), _lib.ptr(zeros), None, _lib.ptr(y2),
+                                n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, 0, cfg, st))
+    assert torch.equal(y1, y2) and not torch.isnan(part).any()
+    outs = []
+    for fused in (True, False):
+        mean, istd, varu = (torch.empty(cout).cuda() for _ in range(3))
+        rm, rv = torch.zeros(cout).cuda() + 0.25, torch.ones(cout).cuda()
+        if fused:
+            _lib.check(L.egn_bn_stats_finalize_f32(_lib.ptr(part), nrows, rows, cout, 1e-5, _lib.ptr(mean),
+                                                   _lib.ptr(istd), _lib.ptr(varu), _lib.ptr(rm), _lib.ptr(rv), 0.1, st))
+        else:
+            ws = torch.empty(L.egn_colreduce_ws_bytes(cout) // 4).cuda()
+            _lib.check(L.egn_bn_stats_f32(_lib.ptr(y2), rows, cout, cout, 1e-5, _lib.ptr(mean), _lib.ptr(istd),
+                                          _lib.ptr(varu), _lib.ptr(rm), _lib.ptr(rv), 0.1, _lib.ptr(ws), st))
+        outs.append([t.cpu().numpy() for t in (mean, istd, varu, rm, rv)])
+    z = y2.double().reshape(rows, cout).cpu()
+    np.testing.assert_allclose(outs[0][0], z.mean(0).numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(outs[0][1], (1.0 / torch.sqrt(z.var(0, unbiased=False) + 1e-5)).numpy(), rtol=2e-5)
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_allclose(a, b, rtol=3e-6, atol=3e-7)
