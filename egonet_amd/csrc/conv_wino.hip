@@ -475,6 +475,8 @@ __global__ __launch_bounds__(WN_NTH, 1) void conv_wino_kernel(ConvArgs a) {
 // fh = 1 keeps -t2 - t3 and sends t2 -- 24 floats per lane through LDS, in the U stage buffer the
 // last K step has just consumed (8 waves x 6 KB = exactly its 48 KB), between two barriers; then
 // each wave finishes and stores the output rows a = fh of its tile.  Per item: nchunk + 2 barriers.
+// (ABL bit 4, this kernel only: the input transform of chunk 0 is re-used by every K step -- an upper
+//  bound on what hiding the step-start patch reads + transform would buy: 61 -> 57, 56 -> 51, 51 -> 46 us)
 // NW = 8 waves on 64 tiles, or NW = 4 waves on 32 tiles (two 8 x 8 images): the 8 x 8 maps at batch 64
 // are only 128 (tile, co-tile) items in the 64-tile form -- half the CUs idle -- and 256 in this one.
 template <int TH, int TW, int TNB, int ABL = 0, int NW = 8>
@@ -629,6 +631,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
 #pragma unroll
       for (int nt = 0; nt < WN_NT; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float rv[4][2][WN_NT];  // residual of this lane's outputs: [tile r][b][nt]
+    f32x4 Vkeep[8];         // (ABL & 16 only: the transform of chunk 0 re-used by every K step)
 
     for (int c = 0; c < nchunk; ++c) {
       const bool last = c + 1 == nchunk;
@@ -659,6 +662,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
           if constexpr ((ABL & 2)) d[k][cc] = f32x4{(float)lane, (float)(k + c), (float)cc, 1.f};
+          else if ((ABL & 16) && c != 0) d[k][cc] = f32x4{0.f, 0.f, 0.f, 0.f};
           else d[k][cc] = *reinterpret_cast<const f32x4*>(&hb[prow[k] + cc]);
         }
       W8_NEXT(0) W8_NEXT(1)
@@ -681,6 +685,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
         }
         V[0] = ta[0] - ta[2]; V[1] = ta[1] + ta[2]; V[2] = ta[2] - ta[1]; V[3] = ta[1] - ta[3];
         V[4] = tb[0] - tb[2]; V[5] = tb[1] + tb[2]; V[6] = tb[2] - tb[1]; V[7] = tb[1] - tb[3];
+      }
+      if constexpr ((ABL & 16) != 0) {  // timing experiment: what would hiding the step-start transform buy
+        if (c == 0) {
+#pragma unroll
+          for (int f = 0; f < 8; ++f) Vkeep[f] = V[f];
+        } else {
+#pragma unroll
+          for (int f = 0; f < 8; ++f) V[f] = Vkeep[f];
+        }
       }
 
       // ---- 8 frequencies x 3 co sub-tiles x 4 k-steps ----
@@ -913,7 +926,7 @@ int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t
     case 3: return wino8_launch<8, 8, 4>(a, lds, stream);
     case 4: return wino8_launch<8, 8, 2, 0, 4>(a, lds, stream);
     case 5: return wino8_launch<8, 16, 1, 0, 4>(a, lds, stream);
-    case 0x12: return wino8_launch<16, 16, 1, 15>(a, lds, stream);
+    case 0x12: return wino8_launch<16, 16, 1, 16>(a, lds, stream);
     case 0x22: return wino8_launch<16, 16, 1, 7>(a, lds, stream);
     case 0x32: return wino8_launch<16, 16, 1, 3>(a, lds, stream);
     case 0x10: return wino_launch<16, 16, 1, 15>(a, lds, stream);
