@@ -145,6 +145,37 @@ def test_conv_winograd_kernels(n, h, w, cin, cout, res, act):
     assert L.egn_wino_weight_floats(64, 48, 0) == 0 and L.egn_wino_weight_floats(48, 64, 1) == 0
 
 
+@pytest.mark.parametrize('h,c,cfg', [(64, 48, 51), (32, 96, 51), (16, 192, 51), (8, 384, 56), (16, 192, 57)])
+def test_winograd_at_the_bench_batch_size_agrees_with_direct_and_is_linear(h, c, cfg):
+    """BASELINE configs[1] size (64 crops): the Winograd kernel of each shape class against the direct
+    kernel on the same tensors (two independent HIP implementations of the same layer), and the
+    size-independent property of a convolution without activation: conv(x1 + x2) = conv(x1) + conv(x2)."""
+    from egonet_amd import _lib, engine
+    L = _lib.lib()
+    st = _lib.current_stream()
+    n = 64
+    g = torch.Generator().manual_seed(h + c)
+    x1 = torch.randn(n, h, h, c, generator=g).cuda()
+    x2 = torch.randn(n, h, h, c, generator=g).cuda()
+    wt = torch.randn(c, c, 3, 3, generator=g) / (3 * c ** 0.5)
+    wd, wu = engine.pack_conv_weight(wt).cuda(), engine.pack_wino_weight(wt).cuda()
+    ones, zeros = torch.ones(c + 16).cuda(), torch.zeros(c + 16).cuda()
+
+    def conv(x, wp, cfg_, act=0):
+        y = torch.empty(n, h, h, c, device='cuda')
+        _lib.check(L.egn_conv2d_f32(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(ones), _lib.ptr(zeros), None, _lib.ptr(y),
+                                    n, h, h, c, c, c, c, 3, 3, 1, 1, act, 0, cfg_, st))
+        return y
+    yw, yd = conv(x1, wu, cfg), conv(x1, wd, 0)
+    scale = float(yd.abs().max())
+    assert float((yw - yd).abs().max()) < 3e-5 * max(scale, 1.0)
+    lin = conv(x1 + x2, wu, cfg) - (yw + conv(x2, wu, cfg))
+    assert float(lin.abs().max()) < 3e-5 * max(scale, 1.0)
+    # every output element is written (no stale NaN), ReLU variant clamps exactly at zero
+    yr = conv(x1, wu, cfg, act=1)
+    assert torch.equal(yr, torch.clamp_min(yw, 0.0))
+
+
 def test_winograd_filter_pack_device_vs_host():
     """egn_wino_pack_weight_f32 == engine.pack_wino_weight (the float64 host transform the inference
     programs use), forward and data-gradient filters."""
