@@ -137,12 +137,9 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // LDS layout: [ K-loop stage buffers | epilogue sC (aliases them) ][ sPix: TM ints ]
-// (persistent family: the wave-private epilogue slabs, 4 waves x 16 rows, live
-//  BEHIND the stage buffers because the next tile's DMA is in flight during an epilogue)
 static size_t lds_stage_bytes(const ConvArgs& a, const ConvConfig& cf) {
   size_t main_loop = (size_t)(EGN_CKQ * a.npixp + a.tps * EGN_CKQ * cf.tile_n()) * 16;
   if (cf.dma) main_loop *= 2;  // double-buffered stage
-  if (cf.dma == 3) return main_loop;
   // epilogue: 4 waves x (MT*16 rows) x (NT*16 + 4) floats
   const size_t epi = a.out_nchw ? 0 : (size_t)4 * cf.mt * 16 * (cf.nt * 16 + 4) * 4;
   return ((main_loop > epi ? main_loop : epi) + 15) & ~(size_t)15;
@@ -151,7 +148,6 @@ static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
   if (cf.dma == 5) return egn_conv_wino_lds_bytes(cf.bi);
   if (cf.dma == 4 && cf.bi == 2) return (size_t)(3 * 336 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // chunk ring + filter
   if (cf.dma == 4) return (size_t)(2 * 3 * 192 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // 2 halo buffers + filter
-  if (cf.dma == 3) return lds_stage_bytes(a, cf) + (size_t)4 * 16 * (cf.nt * 16 + 4) * 4;
   return lds_stage_bytes(a, cf) + (size_t)cf.tile_m() * 4;
 }
 
@@ -238,7 +234,7 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
 
 static size_t budget_for(const ConvConfig& cf) {
   // staged: 3 blocks / CU; dma: 2 (ids 11..20) or 3 (ids 21..30) blocks / CU of the 160 KiB LDS
-  return (cf.dma == 1 || cf.dma == 3) ? 80 * 1024 : (cf.dma == 2 ? 53 * 1024 : 64 * 1024);
+  return cf.dma == 1 ? 80 * 1024 : (cf.dma == 2 ? 53 * 1024 : 64 * 1024);
 }
 
 int egn_conv_plan(ConvArgs& a, int& cfg_id, size_t& lds_bytes) {
