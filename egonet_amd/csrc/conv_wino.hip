@@ -31,6 +31,12 @@
 //   * persistent blocks walk over (spatial tile, co-tile) items; a K step = one 16-channel chunk:
 //     halo chunk + U slab arrive by LDS-DMA in double-buffered stages, ONE barrier per step.
 //
+// Two kernels in this file.  conv_wino_kernel (configs 45 / 46) is the design just described: 4 waves,
+// all 16 frequencies in one wave.  conv_wino8_kernel (configs 51 / 52 / 56 / 57, further down) is what
+// the measured table selects: the frequency rows of an m-tile split between two waves (96 accumulators,
+// two waves per SIMD), a partial exchange through LDS at the end of an item, BatchNorm statistics in
+// the epilogue for the training step.  Kernel symbol <-> config: egn_conv_config_name (conv_plan.hip).
+//
 // Numerics: exact fp32 products, fp32 accumulation; the +/- transforms add a few ulp relative to
 // the direct sum (the filter transform is done in float64).  Not bit-identical to the direct
 // kernels -- the parity bar is the reference's (1e-3 px on key-points, arg-max indices exact).
