@@ -20,7 +20,7 @@ int egn_conv_launch_staged(const ConvArgs& a, int cfg_id, size_t lds, hipStream_
 int egn_conv_launch_dma(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
 int egn_conv_launch_c48(const ConvArgs& a, size_t lds, int waves, hipStream_t stream);
 int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t stream);
-size_t egn_conv_wino_lds_bytes(int variant);
+size_t egn_conv_wino_lds_bytes(int variant, int cout);
 int egn_conv_wino_stats_rows(const ConvArgs& a, int variant);
 
 static const ConvConfig kConfigs[] = {
@@ -145,7 +145,7 @@ static size_t lds_stage_bytes(const ConvArgs& a, const ConvConfig& cf) {
   return ((main_loop > epi ? main_loop : epi) + 15) & ~(size_t)15;
 }
 static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
-  if (cf.dma == 5) return egn_conv_wino_lds_bytes(cf.bi);
+  if (cf.dma == 5) return egn_conv_wino_lds_bytes(cf.bi, a.Cout);
   if (cf.dma == 4 && cf.bi == 2) return (size_t)(3 * 336 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // chunk ring + filter
   if (cf.dma == 4) return (size_t)(2 * 3 * 192 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // 2 halo buffers + filter
   return lds_stage_bytes(a, cf) + (size_t)cf.tile_m() * 4;
@@ -159,8 +159,10 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
   if (cf.dma == 5) {
     // conv_wino.hip: 3x3 stride-1 pad-1 NHWC layers with unpadded channel strides, even maps
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % EGN_CK || a.cs_in != a.Cin ||
-        a.Cout % 48 || a.cs_out != a.Cout || a.out_nchw || (a.Ho & 1) || (a.Wo & 1))
+        a.cs_out != a.Cout || a.out_nchw || (a.Ho & 1) || (a.Wo & 1))
       return false;
+    // co-tile 48 (4- and 8-wave kernels) or 32 (8-wave kernels only): egn_wino_cot in conv_wino.hip
+    if (a.Cout % 48 != 0 && !(a.Cout % 32 == 0 && (cf.bi & 15) >= 2)) return false;
     if ((cf.bi & 15) == 4) { a.TH = 8; a.TW = 8; a.TNB = 2; }
     else if ((cf.bi & 15) == 5) { a.TH = 8; a.TW = 16; a.TNB = 1; }
     else if ((cf.bi & 15) == 1 || (cf.bi & 15) == 3) { a.TH = 8; a.TW = 8; a.TNB = 4; }

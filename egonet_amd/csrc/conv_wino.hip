@@ -44,8 +44,13 @@
 
 typedef __attribute__((address_space(3))) void* lds_ptr_wino_t;
 
+// Output channels per block (co-tile, egn_wino_cot in egn_internal.h): 48 (NT = 3 MFMA column tiles)
+// where Cout allows -- the widths of HRNet-W48 (48 / 96 / 192 / 384) -- else 32 (NT = 2): the W32 /
+// Pedestrian widths (32 / 64 / 128 / 256) and the 64-channel stem layers.  The SAME rule in the filter
+// packing, the planner and the launcher.
+
 namespace {
-constexpr int WN_CO = 48;                          // output channels per block (NT = 3)
+constexpr int WN_CO = 48;                          // the 4-wave kernel: 48 output channels per block (NT = 3)
 constexpr int WN_NT = 3;
 constexpr int WN_USLOTS = 16 * EGN_CKQ * WN_CO;    // float4 per (chunk, co-tile) slab of U: 3072 = 48 KB
 constexpr int WN_NTH = 256;
@@ -485,8 +490,10 @@ __global__ __launch_bounds__(WN_NTH, 1) void conv_wino_kernel(ConvArgs a) {
 //  bound on what hiding the step-start patch reads + transform would buy: 61 -> 57, 56 -> 51, 51 -> 46 us)
 // NW = 8 waves on 64 tiles, or NW = 4 waves on 32 tiles (two 8 x 8 images): the 8 x 8 maps at batch 64
 // are only 128 (tile, co-tile) items in the 64-tile form -- half the CUs idle -- and 256 in this one.
-template <int TH, int TW, int TNB, int ABL = 0, int NW = 8>
+template <int TH, int TW, int TNB, int ABL = 0, int NW = 8, int NT = 3>
 __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
+  constexpr int CO_T = 16 * NT;                             // output channels per block
+  constexpr int USL = 16 * EGN_CKQ * CO_T;                  // float4 per (chunk, co-tile) slab of U
   using G = WinoGeom<TH, TW, TNB>;
   constexpr int NTH = 64 * NW;
   constexpr int MTILES = NW / 2;
@@ -494,15 +501,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
   constexpr int SLOTS = EGN_CKQ * G::PLANE;                 // multiple of 64: whole waves
   constexpr int IT = (SLOTS + NTH - 1) / NTH;               // halo DMA instructions (the last one partial)
   constexpr int BUF = SLOTS;
-  constexpr int UIT = WN_USLOTS / NTH;                      // 6 (12 with 4 waves)
+  constexpr int UIT = USL / NTH;                      // 6 (12 with 4 waves)
   constexpr int NPIECE = IT + UIT;                          // 10 (16)
   constexpr int TOPP = 2;                                   // DMA pieces issued at the top of a K step ...
   constexpr int PERF = (NPIECE - TOPP + 7) / 8;             // ... and after each of the 8 frequencies
-  static_assert(SLOTS % 64 == 0 && WN_USLOTS % NTH == 0, "whole-wave DMA pieces");
+  static_assert(SLOTS % 64 == 0 && USL % NTH == 0, "whole-wave DMA pieces");
+  static_assert(NW * 2 * NT * 64 <= USL, "the partial exchange fits in one U stage buffer");
   extern __shared__ float4 smem[];
-  float4* sU = smem;                  // [2][WN_USLOTS]
-  float4* sH = smem + 2 * WN_USLOTS;  // [2][BUF]
-  double* sS = reinterpret_cast<double*>(smem + 2 * WN_USLOTS + 2 * BUF);  // [NW][2][48] BatchNorm partial sums
+  float4* sU = smem;                  // [2][USL]
+  float4* sH = smem + 2 * USL;  // [2][BUF]
+  double* sS = reinterpret_cast<double*>(smem + 2 * USL + 2 * BUF);  // [NW][2][CO_T] BatchNorm partial sums
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
   const int kq = lane >> 4;
 
   const int C = a.Cin, Co = a.Cout;
-  const int nct = Co / WN_CO;
+  const int nct = Co / CO_T;
   const int nchunk = a.nchunk;
 
   const unsigned long long xaddr = reinterpret_cast<unsigned long long>(a.x);
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
   const u32x4 rxv = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu,
                      (unsigned)((size_t)a.N * a.H * a.W * C * 4), 0x00020000u};
   const u32x4 ruv = {(unsigned)uaddr, (unsigned)(uaddr >> 32) & 0xffffu,
-                     (unsigned)((size_t)nct * nchunk * WN_USLOTS * 16), 0x00020000u};
+                     (unsigned)((size_t)nct * nchunk * USL * 16), 0x00020000u};
   const unsigned out_bytes = (unsigned)((size_t)a.N * a.Ho * a.Wo * Co * 4);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr =
@@ -579,8 +587,8 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
         wino_dma16(rxv, wino_lds_addr(sH + (P)*BUF + wave * 64) + (K)*NTH * 16, OFF[(K) < IT ? (K) : 0], \
                    (unsigned)(CH)*64u);                                                              \
     } else {                                                                                         \
-      wino_dma16(ruv, wino_lds_addr(sU + (P)*WN_USLOTS + wave * 64) + ((K)-IT) * NTH * 16, (unsigned)tid * 16u, \
-                 (unsigned)(((CT)*nchunk + (CH)) * WN_USLOTS) * 16u + ((K)-IT) * NTH * 16);          \
+      wino_dma16(ruv, wino_lds_addr(sU + (P)*USL + wave * 64) + ((K)-IT) * NTH * 16, (unsigned)tid * 16u, \
+                 (unsigned)(((CT)*nchunk + (CH)) * USL) * 16u + ((K)-IT) * NTH * 16);          \
     }                                                                                                \
   }
 
@@ -589,7 +597,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
   W8_ITEM(w, tile, ct)
   const int ct_block = ct;            // constant over the block's items (the launcher sizes the grid for it)
   if (a.stats != nullptr) {           // own-wave rows only: no barrier needed before the first use
-    for (int e = lane; e < 2 * WN_CO; e += 64) sS[wave * 2 * WN_CO + e] = 0.0;
+    for (int e = lane; e < 2 * CO_T; e += 64) sS[wave * 2 * CO_T + e] = 0.0;
   }
   unsigned doff[IT];
   W8_DOFF(tile, doff)
@@ -620,23 +628,23 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
         const int n = tb_ * TNB + (og[r] >> 16);
         const int oy = ty_ * TH + 2 * ((og[r] >> 8) & 255) + fh, ox = tx_ * TW + 2 * (og[r] & 255);
         voff[r] = (tile < ntile && n < a.N && oy < a.Ho && ox < a.Wo)
-                      ? (unsigned)(((n * a.Ho + oy) * a.Wo + ox) * Co + ct * WN_CO + li) * 4u
+                      ? (unsigned)(((n * a.Ho + oy) * a.Wo + ox) * Co + ct * CO_T + li) * 4u
                       : EGN_OOB;
       }
     }
-    float sc[WN_NT], sh[WN_NT];
+    float sc[NT], sh[NT];
 #pragma unroll
-    for (int nt = 0; nt < WN_NT; ++nt) {
-      sc[nt] = a.scale[ct * WN_CO + nt * 16 + li];
-      sh[nt] = a.shift[ct * WN_CO + nt * 16 + li];
+    for (int nt = 0; nt < NT; ++nt) {
+      sc[nt] = a.scale[ct * CO_T + nt * 16 + li];
+      sh[nt] = a.shift[ct * CO_T + nt * 16 + li];
     }
 
-    f32x4 acc[8][WN_NT];
+    f32x4 acc[8][NT];
 #pragma unroll
     for (int f = 0; f < 8; ++f)
 #pragma unroll
-      for (int nt = 0; nt < WN_NT; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float rv[4][2][WN_NT];  // residual of this lane's outputs: [tile r][b][nt]
+      for (int nt = 0; nt < NT; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rv[4][2][NT];  // residual of this lane's outputs: [tile r][b][nt]
     f32x4 Vkeep[8];         // (ABL & 16 only: the transform of chunk 0 re-used by every K step)
 
     for (int c = 0; c < nchunk; ++c) {
@@ -703,21 +711,21 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
       }
 
       // ---- 8 frequencies x 3 co sub-tiles x 4 k-steps ----
-      const float4* ub = sU + par * WN_USLOTS + (fh * 8 * EGN_CKQ + kq) * WN_CO + li;
-      f32x4 bf[2][WN_NT];
+      const float4* ub = sU + par * USL + (fh * 8 * EGN_CKQ + kq) * CO_T + li;
+      f32x4 bf[2][NT];
 #pragma unroll
-      for (int nt = 0; nt < WN_NT; ++nt) bf[0][nt] = *reinterpret_cast<const f32x4*>(&ub[nt * 16]);
+      for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *reinterpret_cast<const f32x4*>(&ub[nt * 16]);
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
         if (f + 1 < 8) {
 #pragma unroll
-          for (int nt = 0; nt < WN_NT; ++nt)
-            bf[(f + 1) & 1][nt] = *reinterpret_cast<const f32x4*>(&ub[(f + 1) * EGN_CKQ * WN_CO + nt * 16]);
+          for (int nt = 0; nt < NT; ++nt)
+            bf[(f + 1) & 1][nt] = *reinterpret_cast<const f32x4*>(&ub[(f + 1) * EGN_CKQ * CO_T + nt * 16]);
         }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int nt = 0; nt < WN_NT; ++nt)
+          for (int nt = 0; nt < NT; ++nt)
             acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[f][s], bf[f & 1][nt][s], acc[f][nt], 0, 0, 0);
 #pragma unroll
         for (int k_ = 0; k_ < PERF; ++k_)
@@ -734,16 +742,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
 #pragma unroll
           for (int pb = 0; pb < 2; ++pb)
 #pragma unroll
-            for (int nt = 0; nt < WN_NT; ++nt) rv[r][pb][nt] = wino_load4(rr, ro, pb * colpitch + nt * 64u);
+            for (int nt = 0; nt < NT; ++nt) rv[r][pb][nt] = wino_load4(rr, ro, pb * colpitch + nt * 64u);
         }
       }
       par ^= 1;
     }
 
     // ---- output transform: this wave's frequency rows, then the exchange with the partner wave ----
-    float keep[WN_NT][4][2], send[WN_NT][4][2];
+    float keep[NT][4][2], send[NT][4][2];
 #pragma unroll
-    for (int nt = 0; nt < WN_NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -763,28 +771,28 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
     {
       // the U buffer of the last K step (par ^ 1 after the toggle) is free once every wave is past its
       // MFMAs: barrier, write, barrier, read the partner's
-      float4* xch = sU + (par ^ 1) * WN_USLOTS;
+      float4* xch = sU + (par ^ 1) * USL;
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int k4 = 0; k4 < 6; ++k4) {
+      for (int k4 = 0; k4 < 2 * NT; ++k4) {
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int idx = k4 * 4 + e;  // (nt*4 + r)*2 + pb
           v[e] = send[idx >> 3][(idx >> 1) & 3][idx & 1];
         }
-        *reinterpret_cast<f32x4*>(&xch[(wave * 6 + k4) * 64 + lane]) = v;
+        *reinterpret_cast<f32x4*>(&xch[(wave * 2 * NT + k4) * 64 + lane]) = v;
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(0xC07F);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
 #pragma unroll
-      for (int k4 = 0; k4 < 6; ++k4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(&xch[((wave ^ MTILES) * 6 + k4) * 64 + lane]);
+      for (int k4 = 0; k4 < 2 * NT; ++k4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&xch[((wave ^ MTILES) * 2 * NT + k4) * 64 + lane]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int idx = k4 * 4 + e;
@@ -792,9 +800,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
         }
       }
     }
-    float st1[WN_NT] = {0.f, 0.f, 0.f}, st2[WN_NT] = {0.f, 0.f, 0.f};
+    float st1[NT], st2[NT];
 #pragma unroll
-    for (int nt = 0; nt < WN_NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) st1[nt] = st2[nt] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -810,18 +820,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
       // are added to the wave's own row of a small LDS table (doubles); the block writes ONE partial
       // row at the end of the kernel (its co-tile is the same for all its items, see wino8_grid)
 #pragma unroll
-      for (int nt = 0; nt < WN_NT; ++nt) {
+      for (int nt = 0; nt < NT; ++nt) {
         st1[nt] += __shfl_xor(st1[nt], 16);
         st1[nt] += __shfl_xor(st1[nt], 32);
         st2[nt] += __shfl_xor(st2[nt], 16);
         st2[nt] += __shfl_xor(st2[nt], 32);
       }
       if (kq == 0) {
-        double* srow = sS + wave * 2 * WN_CO + li;
+        double* srow = sS + wave * 2 * CO_T + li;
 #pragma unroll
-        for (int nt = 0; nt < WN_NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           srow[nt * 16] += (double)st1[nt];
-          srow[WN_CO + nt * 16] += (double)st2[nt];
+          srow[CO_T + nt * 16] += (double)st2[nt];
         }
       }
     }
@@ -835,10 +845,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
     double* row = a.stats + (size_t)blockIdx.x * 2 * Co;
     for (int e = tid; e < 2 * Co; e += NTH) {
       const int which = e / Co, c = e - which * Co;
-      const int cl = c - ct_block * WN_CO;
+      const int cl = c - ct_block * CO_T;
       double v = 0.0;
-      if (cl >= 0 && cl < WN_CO) {
-        for (int k = 0; k < NW; ++k) v += sS[(k * 2 + which) * WN_CO + cl];
+      if (cl >= 0 && cl < CO_T) {
+        for (int k = 0; k < NW; ++k) v += sS[(k * 2 + which) * CO_T + cl];
       }
       row[e] = v;
     }
@@ -876,6 +886,7 @@ static int wino_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
 // (a) blocks w, w+8, ... stay on one XCD and (b) a block's items all have the same co-tile
 // (ct = (w >> 3) % nct and w advances by the grid size) -- its BatchNorm partial row covers one co-tile
 static int wino8_grid(const ConvArgs& a, int tnb) {
+  const int cot = egn_wino_cot(a.Cout);
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -884,7 +895,7 @@ static int wino8_grid(const ConvArgs& a, int tnb) {
       cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
-  const int nct = a.Cout / WN_CO;
+  const int nct = a.Cout / (cot ? cot : 48);
   const int ntile = a.tiles_x * a.tiles_y * ((a.N + tnb - 1) / tnb);
   const int nwork = ((ntile + 7) / 8) * 8 * nct;
   int cap = cus / (8 * nct) * (8 * nct);
@@ -892,16 +903,24 @@ static int wino8_grid(const ConvArgs& a, int tnb) {
   return nwork < cap ? nwork : cap;
 }
 
-template <int TH, int TW, int TNB, int ABL = 0, int NW = 8>
-static int wino8_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
+template <int TH, int TW, int TNB, int ABL, int NW, int NT>
+static int wino8_launch_nt(const ConvArgs& a, size_t lds, hipStream_t stream) {
   static bool raised[EGN_MAX_DEVICES];
   if (egn_first_use_on_device(raised)) {
-    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<TH, TW, TNB, ABL, NW>),
+    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino8_kernel<TH, TW, TNB, ABL, NW, NT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
   }
   const int grid = wino8_grid(a, TNB);
-  hipLaunchKernelGGL((conv_wino8_kernel<TH, TW, TNB, ABL, NW>), dim3(grid), dim3(64 * NW), lds, stream, a);
+  hipLaunchKernelGGL((conv_wino8_kernel<TH, TW, TNB, ABL, NW, NT>), dim3(grid), dim3(64 * NW), lds, stream, a);
   return (int)hipGetLastError();
+}
+template <int TH, int TW, int TNB, int ABL = 0, int NW = 8>
+static int wino8_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
+  if (egn_wino_cot(a.Cout) == 48) return wino8_launch_nt<TH, TW, TNB, ABL, NW, 3>(a, lds, stream);
+  if constexpr (ABL == 0) {
+    if (egn_wino_cot(a.Cout) == 32) return wino8_launch_nt<TH, TW, TNB, 0, NW, 2>(a, lds, stream);
+  }
+  return EGN_E_BADARG;
 }
 
 // rows of the BatchNorm partial table a launch writes (0 = this variant has no fused statistics)
@@ -914,14 +933,15 @@ int egn_conv_wino_stats_rows(const ConvArgs& a, int variant) {
 
 // variant 0: 16 x 16 pixel tile of one image; variant 1: four 8 x 8 images (the 8 x 8 maps);
 // variants 2 / 3: the same two geometries on the 8-wave kernel; variant 4: two 8 x 8 images, 4 waves
-size_t egn_conv_wino_lds_bytes(int variant) {
+size_t egn_conv_wino_lds_bytes(int variant, int cout) {
   const int v = variant & 15;
   size_t halo = (v & 1) ? WinoDims<8, 8, 4>::BUF : WinoDims<16, 16, 1>::BUF;
   if (v >= 2) halo = (v & 1) ? EGN_CKQ * WinoGeom<8, 8, 4>::PLANE : EGN_CKQ * WinoGeom<16, 16, 1>::PLANE;
   if (v == 4) halo = EGN_CKQ * WinoGeom<8, 8, 2>::PLANE;
   if (v == 5) halo = EGN_CKQ * WinoGeom<8, 16, 1>::PLANE;
-  const size_t stats = v >= 2 ? (size_t)((v == 4 || v == 5) ? 4 : 8) * 2 * WN_CO * sizeof(double) : 0;
-  return (2 * (size_t)WN_USLOTS + 2 * halo) * 16 + stats;
+  const int cot = v >= 2 && egn_wino_cot(cout) ? egn_wino_cot(cout) : WN_CO;   // the 4-wave kernel: 48 only
+  const size_t stats = v >= 2 ? (size_t)((v == 4 || v == 5) ? 4 : 8) * 2 * cot * sizeof(double) : 0;
+  return (2 * (size_t)(16 * EGN_CKQ * cot) + 2 * halo) * 16 + stats;
 }
 int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t stream) {
   const int act = a.act & EGN_ACT_MASK;
@@ -969,23 +989,24 @@ __global__ __launch_bounds__(256) void wino_pack_weight_kernel(const float* __re
       t[2][b] = 0.5 * (g[0][b] - g[1][b] + g[2][b]);
       t[3][b] = g[2][b];
     }
-    const int ct = o / WN_CO, col = o - ct * WN_CO;
+    const int cot = egn_wino_cot(n_out);
+    const int ct = o / cot, col = o - ct * cot;
     const int chunk = i / EGN_CK, q = (i % EGN_CK) >> 2, r = i & 3;
-    float* base = dst + ((size_t)(ct * nchunk + chunk) * WN_USLOTS) * 4 + ((size_t)q * WN_CO + col) * 4 + r;
+    float* base = dst + ((size_t)(ct * nchunk + chunk) * (16 * EGN_CKQ * cot)) * 4 + ((size_t)q * cot + col) * 4 + r;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const double u0 = t[a][0], u1 = 0.5 * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5 * (t[a][0] - t[a][1] + t[a][2]),
                    u3 = t[a][2];
       const double u[4] = {u0, u1, u2, u3};
 #pragma unroll
-      for (int b = 0; b < 4; ++b) base[(size_t)(a * 4 + b) * EGN_CKQ * WN_CO * 4] = (float)u[b];
+      for (int b = 0; b < 4; ++b) base[(size_t)(a * 4 + b) * EGN_CKQ * cot * 4] = (float)u[b];
     }
   }
 }
 
 extern "C" long egn_wino_weight_floats(int Cout, int Cin, int dgrad) {
   const int n_out = dgrad ? Cin : Cout, n_in = dgrad ? Cout : Cin;
-  if (n_out <= 0 || n_in <= 0 || n_out % WN_CO || n_in % EGN_CK) return 0;
+  if (n_out <= 0 || n_in <= 0 || egn_wino_cot(n_out) == 0 || n_in % EGN_CK) return 0;
   return (long)n_out * n_in * 16;
 }
 extern "C" int egn_wino_pack_weight_f32(const float* w, int Cout, int Cin, int dgrad, float* dst, void* stream) {

@@ -57,6 +57,9 @@ struct ConvConfig {
   int threads() const { return 64 * wm * wn; }
 };
 
+// co-tile of the Winograd kernels (conv_wino.hip): 48 where Cout allows, else 32, 0 = not supported
+__host__ __device__ inline int egn_wino_cot(int cout) { return cout % 48 == 0 ? 48 : (cout % 32 == 0 ? 32 : 0); }
+
 int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream);
 int egn_conv_plan(ConvArgs& a, int& cfg_id, size_t& lds_bytes);
 const ConvConfig* egn_conv_config(int cfg);

@@ -10,6 +10,8 @@
 
 #include "egn_internal.h"
 
+extern "C" int egn_conv_config_kind(int cfg);
+
 extern "C" int egn_version(void) { return (1 << 16) | 0; }
 
 extern "C" const char* egn_strerror(int code) {
@@ -98,6 +100,7 @@ extern "C" int egn_conv_plan_query(int N, int H, int W, int Cin, int cs_in, int 
   out[5] = a.TH; out[6] = a.TW; out[7] = a.TNB; out[8] = a.tps; out[9] = (int)lds;
   out[10] = a.tiles_x * a.tiles_y * ((a.N + a.TNB - 1) / a.TNB);
   out[11] = (a.CoutP + tn - 1) / tn;
+  if (egn_conv_config_kind(cfg) == 1 && egn_wino_cot(Cout)) out[11] = Cout / egn_wino_cot(Cout);
   return 0;
 }
 

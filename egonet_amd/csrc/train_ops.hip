@@ -678,13 +678,14 @@ __global__ __launch_bounds__(256) void pack_conv_weights_batch_kernel(const egn_
       const int dg = d.dgrad & 1;
       const int n_out = dg ? d.Cin : d.Cout, n_in = dg ? d.Cout : d.Cin;
       const int nchunk = n_in / EGN_CK;
-      const int col = (int)(le % 48);
-      long long r_ = le / 48;
+      const int cot = egn_wino_cot(n_out);   // 48 or 32 output channels per co-tile (conv_wino.hip)
+      const int col = (int)(le % cot);
+      long long r_ = le / cot;
       const int quad = (int)(r_ % 4);
       r_ /= 4;
       const int chunk = (int)(r_ % nchunk);
       const int ct = (int)(r_ / nchunk);
-      const int o = ct * 48 + col;
+      const int o = ct * cot + col;
       float u[16][4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -712,9 +713,9 @@ __global__ __launch_bounds__(256) void pack_conv_weights_batch_kernel(const egn_
           u[a * 4 + 3][r] = (float)t[a][2];
         }
       }
-      float4* slab = reinterpret_cast<float4*>(d.dst) + (size_t)(ct * nchunk + chunk) * (16 * 4 * 48);
+      float4* slab = reinterpret_cast<float4*>(d.dst) + (size_t)(ct * nchunk + chunk) * (16 * 4 * cot);
 #pragma unroll
-      for (int f = 0; f < 16; ++f) slab[(f * 4 + quad) * 48 + col] = make_float4(u[f][0], u[f][1], u[f][2], u[f][3]);
+      for (int f = 0; f < 16; ++f) slab[(f * 4 + quad) * cot + col] = make_float4(u[f][0], u[f][1], u[f][2], u[f][3]);
       continue;
     }
     const int n_out = d.dgrad ? d.Cin : d.Cout;

@@ -52,21 +52,25 @@ def pack_conv_weight(w):
     return wp.reshape(-1)
 
 
-WINO_CFGS = (45, 46)     # conv_wino.hip tile configs (csrc/conv_plan.hip)
-WINO_CO = 48
+def wino_cot(cout):
+    """Output channels per block (co-tile) of the Winograd kernels: 48 where Cout allows (the W48
+    widths), else 32 (the W32 / Pedestrian widths and 64-channel layers); 0 = not supported
+    (egn_wino_cot in csrc/egn_internal.h)."""
+    return 48 if cout % 48 == 0 else (32 if cout % 32 == 0 else 0)
 
 
 def pack_wino_weight(w):
     """[Cout,Cin,3,3] -> the Winograd F(2x2,3x3) filter U = G g G^T (float64, rounded once to
     fp32) in the layout conv_wino.hip stages through LDS:
-    flat fp32 [co-tile = Cout/48][chunk = Cin/16][f = 4i+j][quad][48][4]
-    (ci = chunk*16 + quad*4 + r), one 48 KB slab per (co-tile, chunk)."""
+    flat fp32 [co-tile = Cout/T][chunk = Cin/16][f = 4i+j][quad][T][4], T = wino_cot(Cout)
+    (ci = chunk*16 + quad*4 + r), one contiguous slab (48 KB for T = 48) per (co-tile, chunk)."""
     w = w.detach().to(torch.float64).cpu()
     cout, cin, kh, kw = w.shape
-    assert (kh, kw) == (3, 3) and cout % WINO_CO == 0 and cin % CK == 0, w.shape
+    cot = wino_cot(cout)
+    assert (kh, kw) == (3, 3) and cot and cin % CK == 0, w.shape
     G = torch.tensor([[1., 0., 0.], [.5, .5, .5], [.5, -.5, .5], [0., 0., 1.]], dtype=torch.float64)
     u = torch.einsum('ia,ocab,jb->ocij', G, w, G).to(torch.float32)        # [Cout,Cin,4,4]
-    u = u.reshape(cout // WINO_CO, WINO_CO, cin // CK, CK // 4, 4, 16)     # ct, co, chunk, quad, r, f
+    u = u.reshape(cout // cot, cot, cin // CK, CK // 4, 4, 16)             # ct, co, chunk, quad, r, f
     return u.permute(0, 2, 5, 3, 1, 4).contiguous().reshape(-1)
 
 

@@ -70,8 +70,8 @@ def _time_cfg(L, args, cfg, stream, x, w, sc, sh, res, y):
     return best
 
 
-def tune(device, args):
-    """Time every tile configuration on the real shape; returns (cfg, {cfg: ms})."""
+def tune(device, args, skip=()):
+    """Time every tile configuration on the real shape (except ``skip``); returns (cfg, {cfg: ms})."""
     L = _lib.lib()
     n, h, wd, cin, cs_in, cout, cs_out, kh, kw, stride, pad, has_res, out_nchw = args
     ho = (h + 2 * pad - kh) // stride + 1
@@ -92,7 +92,7 @@ def tune(device, args):
         stream = _lib.current_stream(device)
         times = {}
         for cfg in range(1, L.egn_conv_num_configs() + 1):
-            if L.egn_conv_config_kind(cfg) < 0:      # timing-ablation builds
+            if L.egn_conv_config_kind(cfg) < 0 or cfg in skip:      # timing-ablation builds
                 continue
             out = (C.c_int * 12)()
             if L.egn_conv_plan_query(n, h, wd, cin, cs_in, cout, cs_out, kh, kw, stride, pad,

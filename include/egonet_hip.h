@@ -81,14 +81,15 @@ int egn_conv_config_name(int cfg, char* buf, int len);
 /* which filter packing config id expects in `wpack`:
  *   0  direct kernels: egn_pack_conv_weight_f32 (layout above)
  *   1  fused Winograd F(2x2,3x3) kernels (3x3, stride 1, pad 1, Cin % 16 == 0,
- *      Cout % 48 == 0, unpadded channel strides, act none/ReLU): the TRANSFORMED
- *      filter from egn_wino_pack_weight_f32
+ *      Cout % 48 == 0 or -- the 8-wave kernels -- Cout % 32 == 0, unpadded channel
+ *      strides, act none/ReLU): the TRANSFORMED filter from egn_wino_pack_weight_f32
  *  -1  not selectable (timing-ablation builds, invalid id) */
 int egn_conv_config_kind(int cfg);
 /* Winograd filter transform on the device: torch weight [Cout][Cin][3][3] ->
  * U = G g G^T (float64 arithmetic, rounded once to fp32) packed as
- * [Cout/48][Cin/16][f = 4i+j][quad][48][4] floats (ci = chunk*16 + quad*4 + r):
- * one contiguous 48 KB slab per (output-channel tile, input-channel chunk).
+ * [Cout/T][Cin/16][f = 4i+j][quad][T][4] floats (ci = chunk*16 + quad*4 + r),
+ * T = 48 if Cout % 48 == 0 else 32 (Cout % 32 == 0): one contiguous slab per
+ * (output-channel tile, input-channel chunk).
  * dgrad 1 = the data-gradient filter (channels swapped, taps rotated 180 deg).
  * egn_wino_weight_floats = floats dst must hold (0 = shape not supported).
  * Replaces nothing in the reference (cuDNN picks its Winograd algorithms

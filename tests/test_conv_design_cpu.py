@@ -175,7 +175,7 @@ def test_winograd_configs_plan_and_kinds():
     for bad in ((64, 64, 64, 48, 48, 48, 48, 3, 3, 2, 1, 0),          # stride 2
                 (64, 64, 64, 48, 48, 48, 48, 1, 1, 1, 0, 0),          # 1x1
                 (64, 64, 64, 35, 36, 48, 48, 3, 3, 1, 1, 0),          # padded / odd input channels
-                (64, 64, 64, 48, 48, 64, 64, 3, 3, 1, 1, 0),          # Cout % 48
+                (64, 64, 64, 48, 48, 64, 64, 3, 3, 1, 1, 0),          # Cout % 48 (the 4-wave kernel has no 32-wide co-tile)
                 (64, 63, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0),          # odd map
                 (64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 1)):         # NCHW output
         assert L.egn_conv_plan_query(*bad, 45, out) != 0
@@ -183,6 +183,12 @@ def test_winograd_configs_plan_and_kinds():
     name = C.create_string_buffer(96)
     assert L.egn_conv_config_name(45, name, 96) == 0 and name.value == b'void conv_wino_kernel<16, 16, 1, 0>(ConvArgs)'
     assert L.egn_wino_weight_floats(96, 48, 0) == 96 * 48 * 16 and L.egn_wino_weight_floats(40, 48, 0) == 0
+    # the 8-wave kernels also take 32-channel co-tiles: W32 widths plan, LDS = 2 x 32 KB U slabs + halo + stats
+    p32 = _plan((32, 64, 48, 32, 32, 32, 32, 3, 3, 1, 1, 0), cfg=51)
+    assert p32[5:8] == [16, 16, 1] and p32[11] == 1 and p32[9] == 2 * 32768 + 2 * 4 * 432 * 16 + 8 * 2 * 32 * 8
+    assert _plan((8, 8, 8, 256, 256, 256, 256, 3, 3, 1, 1, 0), cfg=56)[11] == 8
+    assert L.egn_conv_plan_query(8, 16, 16, 80, 80, 80, 80, 3, 3, 1, 1, 0, 51, out) != 0       # 80: neither 48 | nor 32 |
+    assert L.egn_wino_weight_floats(64, 64, 0) == 64 * 64 * 16 and L.egn_wino_weight_floats(256, 128, 1) == 256 * 128 * 16
 
 
 def test_winograd_halo_layout_is_bank_conflict_free():
@@ -218,3 +224,6 @@ def test_winograd_frequency_halves_kernel_design_vs_torch():
     assert wino_emulator.conv_case8(5, 8, 8, 16, 48, 8, 8, 4, seed=2) < 2e-5
     assert wino_emulator.conv_case8(3, 8, 8, 32, 48, 8, 8, 2, seed=3) < 2e-5       # two images per block, odd batch
     assert wino_emulator.conv_case8(1, 12, 16, 16, 96, 8, 16, 1, seed=4) < 2e-5    # 8 x 16 tile, partial rows
+    # 32-channel co-tiles (NT = 2): the W32 / Pedestrian widths and the 64-channel layers
+    assert wino_emulator.conv_case8(1, 16, 16, 32, 64, 16, 16, 1, seed=5) < 2e-5
+    assert wino_emulator.conv_case8(3, 8, 8, 16, 32, 8, 8, 2, seed=6) < 2e-5

@@ -118,6 +118,11 @@ def test_conv_every_tile_config(cfg):
     (3, 24, 40, 32, 96, True, 1),      # partial tiles in x and y (24 = 16 + 8, 40 = 32 + 8)
     (70, 32, 32, 48, 48, True, 1),     # more work items than one round of persistent blocks
     (9, 6, 4, 64, 144, False, 1),      # maps smaller than a tile, 3 co-tiles
+    (2, 64, 48, 32, 32, True, 1),      # the W32 / Pedestrian widths: 32-channel co-tiles (8-wave kernels only)
+    (2, 32, 24, 64, 64, True, 1),
+    (3, 16, 12, 128, 128, False, 0),
+    (5, 8, 6, 256, 256, True, 1),
+    (2, 64, 64, 64, 64, False, 1),     # the 64-channel stem / layer1 3x3 convs of every model
 ])
 def test_conv_winograd_kernels(n, h, w, cin, cout, res, act):
     """Configs 45 / 46 (4 waves) and 51 / 52 (8 waves, frequency halves + partial exchange) of
@@ -131,7 +136,7 @@ def test_conv_winograd_kernels(n, h, w, cin, cout, res, act):
     out = (C.c_int * 12)()
     for cfg in (45, 46, 51, 52, 56, 57):    # 56 / 57: 4 waves on 32 tiles (two 8 x 8 images / an 8 x 16 tile)
         rc = L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, cfg, out)
-        if cfg in (46, 52, 56) and (h > 8 or w > 8):
+        if (cfg in (46, 52, 56) and (h > 8 or w > 8)) or (cfg in (45, 46) and cout % 48):
             assert rc != 0
             continue
         assert rc == 0
@@ -141,8 +146,8 @@ def test_conv_winograd_kernels(n, h, w, cin, cout, res, act):
     assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 48, 48, 3, 3, 2, 1, 0, 45, out) != 0
     assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 48, 48, 1, 1, 1, 0, 0, 45, out) != 0
     assert L.egn_conv_plan_query(2, 16, 16, 35, 36, 48, 48, 3, 3, 1, 1, 0, 45, out) != 0
-    assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 64, 64, 3, 3, 1, 1, 0, 45, out) != 0
-    assert L.egn_wino_weight_floats(64, 48, 0) == 0 and L.egn_wino_weight_floats(48, 64, 1) == 0
+    assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 80, 80, 3, 3, 1, 1, 0, 51, out) != 0
+    assert L.egn_wino_weight_floats(80, 48, 0) == 0 and L.egn_wino_weight_floats(48, 80, 1) == 0
 
 
 @pytest.mark.parametrize('h,c,cfg', [(64, 48, 51), (32, 96, 51), (16, 192, 51), (8, 384, 56), (16, 192, 57)])
@@ -182,7 +187,7 @@ def test_winograd_filter_pack_device_vs_host():
     from egonet_amd import _lib, engine
     L = _lib.lib()
     g = torch.Generator().manual_seed(5)
-    for cout, cin in ((48, 48), (96, 32), (144, 192)):
+    for cout, cin in ((48, 48), (96, 32), (144, 192), (64, 64), (32, 128)):
         wt = torch.randn(cout, cin, 3, 3, generator=g)
         for dgrad in (0, 1):
             if L.egn_wino_weight_floats(cout, cin, dgrad) == 0:
