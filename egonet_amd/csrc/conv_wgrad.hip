@@ -26,20 +26,8 @@
 
 #include "egn_internal.h"
 #include "conv_common.h"
+#include "conv_wgrad.h"
 
-struct WgradArgs {
-  const float* x;
-  const float* dy;
-  float* part;  // [nsplit][taps][CoP][CiP]
-  int N, H, W, Cin, cs_in;
-  int Ho, Wo, Cout, cs_out;
-  int KH, KW, stride, pad, taps;
-  int TH, TW, TNB, lg_tw, lg_thw;  // output-pixel tile: TNB images x TH x TW (TW, TH*TW powers of two)
-  int HH, HWd;                     // halo rows / cols per image
-  int TP, NHP;                     // output pixels (multiple of 4) / halo pixels per tile
-  int tiles_x, tiles_y, ntiles, tiles_per_split, nsplit;
-  int co_tiles, ci_tiles, CoP, CiP;
-};
 
 // J = channels per lane and operand (4: 64-wide tiles, ds_read_b128; 3: 48-wide
 // tiles for the 48 / 96 channel branches, 9 instead of 16 MFMAs per K step).
@@ -240,7 +228,7 @@ __global__ __launch_bounds__(64 * NTAPW * WM * WN * KS) void conv_wgrad_kernel(W
 template <int LANES>
 __global__ __launch_bounds__(32 * LANES) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                                   int nsplit, int taps, int Cout, int Cin, int CoP,
-                                                                  int CiP) {
+                                                                  int CiP, int frag_co_tiles) {
   __shared__ float4 red[LANES][32];
   const int ci4n = CiP >> 2;
   const size_t total4 = (size_t)taps * CoP * ci4n;
@@ -267,6 +255,17 @@ __global__ __launch_bounds__(32 * LANES) void wgrad_reduce_kernel(const float* _
     float4 t = red[0][el];
 #pragma unroll 4
     for (int r = 1; r < LANES; ++r) { const float4 o = red[r][el]; t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w; }
+    if (frag_co_tiles > 0) {
+      // conv_wgrad_wino.hip slabs: [co-tile + ci-tile * co_tiles][tap][e = ja*3+jc][lane][r] in MFMA fragment
+      // order -- co = 16 ja + 4 (lane >> 4) + r, ci = 16 jc + (lane & 15) inside the 48 x 48 tile
+      const int ln = (int)(e & 63), ee = (int)((e >> 6) % 9), tap = (int)((e / 576) % 9), blk = (int)(e / 5184);
+      const int co = (blk % frag_co_tiles) * 48 + 16 * (ee / 3) + 4 * (ln >> 4);
+      const int ci = (blk / frag_co_tiles) * 48 + 16 * (ee % 3) + (ln & 15);
+      float* d = dw + ((size_t)co * Cin + ci) * taps + tap;
+      const size_t rs = (size_t)Cin * taps;
+      d[0] = t.x; d[rs] = t.y; d[2 * rs] = t.z; d[3 * rs] = t.w;
+      return;
+    }
     const int ci = (int)(e % ci4n) * 4;
     const int co = (int)((e / ci4n) % CoP);
     const int tap = (int)(e / ((size_t)ci4n * CoP));
@@ -297,6 +296,7 @@ struct WgradVariant {
   int ntapw, tpw, wm, wn;
   int j, a_it, b_it;  // channels per lane, register-staging depth (float4 per lane) of the dy / x tiles
   int ks;             // K slices inside the block (0 = 1)
+  int wino;           // conv_wgrad_wino.hip variant (0 = direct kernels of this file)
 };
 
 static int pad_to(int v, int m) { return (v + m - 1) / m * m; }
@@ -315,6 +315,27 @@ static int wgrad_plan(WgradArgs& a, WgradVariant& v, size_t& lds) {
   a.Wo = (a.W + 2 * a.pad - a.KW) / a.stride + 1;
   if (a.Ho <= 0 || a.Wo <= 0) return EGN_E_BADARG;
   a.taps = a.KH * a.KW;
+  // 3x3 / stride 1 / pad 1 layers with 48-multiple channel counts (the HRNet-W48 branches): the Winograd
+  // form, 2.25x fewer MFMAs (conv_wgrad_wino.hip).  EGN_WGRAD_WINO=0: direct kernels only.
+  static const bool wino_on = !(getenv("EGN_WGRAD_WINO") && !atoi(getenv("EGN_WGRAD_WINO")));
+  if (wino_on && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 48 == 0 && a.Cout % 48 == 0 &&
+      a.cs_in == a.Cin && a.cs_out == a.Cout && (size_t)a.N * a.H * a.W * std::max(a.Cin, a.Cout) * 4 < (1ull << 31)) {
+    v = WgradVariant{};
+    v.wino = a.W <= 8 ? 2 : 1;
+    a.TH = 8; a.TW = v.wino == 2 ? 8 : 16; a.TNB = v.wino == 2 ? 2 : 1;
+    a.tiles_x = (a.W + a.TW - 1) / a.TW;
+    a.tiles_y = (a.H + 7) / 8;
+    a.ntiles = a.tiles_x * a.tiles_y * ((a.N + a.TNB - 1) / a.TNB);
+    a.co_tiles = a.Cout / 48; a.ci_tiles = a.Cin / 48;
+    a.CoP = a.Cout; a.CiP = a.Cin;
+    const int base = a.co_tiles * a.ci_tiles;
+    int want = (256 + base - 1) / base;        // one 8-wave block per CU
+    want = std::max(1, std::min(std::min(want, a.ntiles), EGN_WGRAD_MAX_SPLITS));
+    a.tiles_per_split = (a.ntiles + want - 1) / want;
+    a.nsplit = (a.ntiles + a.tiles_per_split - 1) / a.tiles_per_split;
+    lds = EGN_WGW_LDS_BYTES;
+    return 0;
+  }
   if (a.taps == 1) {
     v = (a.Cout > 64 && a.Cin > 64) ? WgradVariant{1, 1, 2, 2, 4, 4, 4}
         : (a.Cout > 64)             ? WgradVariant{1, 1, 2, 1, 4, 8, 4}
@@ -423,7 +444,8 @@ extern "C" int egn_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
   if (rc != 0) return rc;
   if ((size_t)ws_bytes < (size_t)a.nsplit * a.taps * a.CoP * a.CiP * sizeof(float)) return EGN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  if (v.ks == 4) rc = v.b_it == 3 ? wgrad_launch<3, 3, 1, 1, 3, 2, 3, 4>(a, lds, st) : wgrad_launch<3, 3, 1, 1, 3, 2, 5, 4>(a, lds, st);
+  if (v.wino) rc = egn_wgrad_wino_launch(a, v.wino, st);
+  else if (v.ks == 4) rc = v.b_it == 3 ? wgrad_launch<3, 3, 1, 1, 3, 2, 3, 4>(a, lds, st) : wgrad_launch<3, 3, 1, 1, 3, 2, 5, 4>(a, lds, st);
   else if (v.ntapw == 9 && v.j == 3) rc = v.a_it == 3 ? wgrad_launch<9, 1, 1, 1, 3, 3, 5>(a, lds, st) : wgrad_launch<9, 1, 1, 1, 3, 2, 5>(a, lds, st);
   else if (v.ntapw == 9) rc = wgrad_launch<9, 1, 1, 1, 4, 2, 5>(a, lds, st);
   else if (v.ntapw == 8) rc = v.j == 3 ? wgrad_launch<8, 2, 1, 1, 3, 2, 5>(a, lds, st) : wgrad_launch<8, 2, 1, 1, 4, 2, 5>(a, lds, st);
@@ -435,12 +457,12 @@ extern "C" int egn_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
   const size_t total4 = (size_t)a.taps * a.CoP * (a.CiP / 4);
   if (a.nsplit > 64)
     hipLaunchKernelGGL(wgrad_reduce_kernel<32>, dim3((unsigned)((total4 + 31) / 32)), dim3(1024), 0, st, a.part, dw,
-                       a.nsplit, a.taps, Cout, Cin, a.CoP, a.CiP);
+                       a.nsplit, a.taps, Cout, Cin, a.CoP, a.CiP, v.wino ? a.co_tiles : 0);
   else if (a.nsplit > 4)
     hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3((unsigned)((total4 + 31) / 32)), dim3(256), 0, st, a.part, dw,
-                       a.nsplit, a.taps, Cout, Cin, a.CoP, a.CiP);
+                       a.nsplit, a.taps, Cout, Cin, a.CoP, a.CiP, v.wino ? a.co_tiles : 0);
   else
     hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3((unsigned)((total4 + 31) / 32)), dim3(64), 0, st, a.part, dw,
-                       a.nsplit, a.taps, Cout, Cin, a.CoP, a.CiP);
+                       a.nsplit, a.taps, Cout, Cin, a.CoP, a.CiP, v.wino ? a.co_tiles : 0);
   return (int)hipGetLastError();
 }

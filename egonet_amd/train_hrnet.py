@@ -226,7 +226,7 @@ class _Tape(object):
         return self.o.packs.get(weight, dgrad, self.st)
 
     def _conv_launch(self, x, wp, shift, y, n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, act,
-                     weight=None, dgrad=0, want_stats=False):
+                     weight=None, dgrad=0, want_stats=False, res=None):
         """``wp``: the direct-packed filter (None: packed here from ``weight``).  With ``weight`` (+ ``dgrad``) given, the tuner may pick a
         Winograd configuration for 3x3 stride-1 layers (forward and data gradient alike: the data
         gradient is a stride-1 convolution with the rotated filter); the transformed filter then comes
@@ -254,9 +254,9 @@ class _Tape(object):
                                                      _lib.ptr(y), n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride,
                                                      pad, cfg, _lib.ptr(stats[0]), stats[1], self.st), 'conv+stats')
         else:
-            _lib.check(self.L.egn_conv2d_f32(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(self.o.ones), _lib.ptr(shift), None,
-                                             _lib.ptr(y), n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, act,
-                                             0, cfg, self.st), 'conv')
+            _lib.check(self.L.egn_conv2d_f32(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(self.o.ones), _lib.ptr(shift),
+                                             _lib.ptr(res), _lib.ptr(y), n, h, w, cin, cs_in, cout, cs_out, kh, kw,
+                                             stride, pad, act, 0, cfg, self.st), 'conv')
         if tm is not None:
             e1.record(torch.cuda.current_stream(self.dev))
             ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
@@ -293,7 +293,19 @@ class _Tape(object):
             torch.cuda.current_stream(self.dev).wait_event(ev)
             self.side_keep = []
 
-    def _dgrad(self, dy, ho, wo, cs_out, weight, stride, pad, x):
+    def _accum_dgrad(self, x, dy, ho, wo, cs_out, weight, stride, pad):
+        """grad(x) += data gradient of the conv.  Where x already has a gradient tensor of its own (the
+        residual path of a block reaches x first) the conv adds it in its epilogue and writes in place
+        (every element is read and written by the same lane) instead of a separate add pass."""
+        if id(x) in self.no_grad:
+            return
+        cur = self.grad.get(id(x))
+        into = cur[0] if (cur is not None and cur[1] and weight.shape[2] == weight.shape[3] and self.o.fuse_grad_add) else None
+        g = self._dgrad(dy, ho, wo, cs_out, weight, stride, pad, x, into=into)
+        if into is None:
+            self._accum(x, g)
+
+    def _dgrad(self, dy, ho, wo, cs_out, weight, stride, pad, x, into=None):
         cout, cin, kh, kw = weight.shape
         L = self.L
         if kh != kw:
@@ -317,7 +329,6 @@ class _Tape(object):
                                         x.n, 1, 1, cout, cs_out, rows, rows, 1, 1, 1, 0, ACT_NONE, 0, cfg, self.st),
                        'conv')
             return dx
-        wq = self._pack(weight, 1) if stride != 1 else None
         if stride == 2:
             up = self._empty(x.n * x.h * x.w * cs_out)
             _lib.check(L.egn_zero_insert2_f32(_lib.ptr(dy), _lib.ptr(up), x.n, ho, wo, x.h, x.w, cs_out, self.st),
@@ -327,9 +338,10 @@ class _Tape(object):
             src, sh, sw = dy, ho, wo
         else:
             raise NotImplementedError('stride %d' % stride)
-        dx = self._empty(x.n * x.h * x.w * x.cs)
-        self._conv_launch(src, wq, self.o.zeros, dx, x.n, sh, sw, cout, cs_out, cin, x.cs, kh, kw, 1, kh - 1 - pad,
-                          ACT_NONE, weight=weight if stride == 1 else None, dgrad=1)
+        # a stride-2 conv's data gradient is a stride-1 conv over the zero-inserted dy: Winograd applies too
+        dx = into if into is not None else self._empty(x.n * x.h * x.w * x.cs)
+        self._conv_launch(src, None, self.o.zeros, dx, x.n, sh, sw, cout, cs_out, cin, x.cs, kh, kw, 1, kh - 1 - pad,
+                          ACT_NONE, weight=weight, dgrad=1, res=into)
         return dx
 
     # -- ops (engine._Recorder interface) -----------------------------------
@@ -392,8 +404,7 @@ class _Tape(object):
                                                 _lib.ptr(self.o.col_ws), self.st), 'bias grad')
                 if weight.requires_grad:
                     self._wgrad(x, xd, dy, z.cs, weight, stride, pad)
-                if id(x) not in self.no_grad:
-                    self._accum(x, self._dgrad(dy, ho, wo, z.cs, weight, stride, pad, x))
+                self._accum_dgrad(x, dy, ho, wo, z.cs, weight, stride, pad)
             backward.params = [weight] + ([bias] if bias is not None else [])     # gradients final after it
             self.back.append(backward)
             return z
@@ -447,8 +458,7 @@ class _Tape(object):
                 self._accum(res, dres)
             if weight.requires_grad:
                 self._wgrad(x, xd, dz, z.cs, weight, stride, pad)
-            if id(x) not in self.no_grad:
-                self._accum(x, self._dgrad(dz, ho, wo, z.cs, weight, stride, pad, x))
+            self._accum_dgrad(x, dz, ho, wo, z.cs, weight, stride, pad)
         backward.params = [weight, bn.weight, bn.bias]
         self.back.append(backward)
         return y
@@ -545,6 +555,7 @@ class HRNetTrainStep(object):
         # (csrc/conv_wino.hip) where they measured faster (EGONET_AMD_TRAIN_WINO=0: direct kernels only)
         self.allow_wino = os.environ.get('EGONET_AMD_TRAIN_WINO', '1') != '0'
         self.fuse_bn_stats = os.environ.get('EGONET_AMD_FUSE_BN_STATS', '1') != '0'
+        self.fuse_grad_add = os.environ.get('EGONET_AMD_FUSE_GRAD_ADD', '1') != '0'
 
     def wgrad_ws(self, nbytes):
         if self._wgrad_ws is None or self._wgrad_ws.numel() * 4 < nbytes:

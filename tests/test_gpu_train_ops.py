@@ -198,7 +198,12 @@ def _nhwc(t, cs):
     (100, 66, 128, 1, 1, 1, 1, 0),       # Linear 66 -> 128 (ld 68), ragged batch
     (4096, 1024, 96, 1, 1, 1, 1, 0),     # lifter output layer at the bench batch
     (64, 128, 128, 1, 1, 1, 1, 0),       # 2x2-wave variant, one tile in each direction
-    (3, 48, 48, 12, 20, 3, 1, 1),        # 3x3 with partial spatial tiles
+    (3, 48, 48, 12, 20, 3, 1, 1),        # 3x3 with partial spatial tiles (Winograd form: 48-multiples, s1 p1)
+    (2, 96, 192, 16, 16, 3, 1, 1),       # Winograd form, several co / ci tiles, one 16-wide tile per row
+    (3, 48, 96, 8, 8, 3, 1, 1),          # Winograd form on 8x8 maps: image pairs, odd batch
+    (2, 48, 48, 5, 7, 3, 1, 1),          # odd map sizes: the last Winograd tiles hang over the border
+    (5, 192, 48, 4, 4, 3, 1, 1),
+    (1, 48, 48, 40, 40, 3, 1, 1),        # more tiles than K splits: several stages per block
     (2, 96, 200, 16, 16, 3, 1, 1),       # several co / ci tiles
     (2, 48, 96, 16, 16, 3, 2, 1),        # strided 3x3 (fuse-layer down path)
     (5, 3, 64, 16, 16, 3, 2, 1),         # stem: 3 input channels (cs 4)

@@ -54,8 +54,13 @@ class LayerChecks(object):
             me.wgrad.append((rel(weight.grad.double().cpu().numpy(), wt.grad.numpy()),
                              (x.n, x.h, x.w, cin, cout, kh, stride)))
 
-        def dgrad(tape, dy, ho, wo, cs_out, weight, stride, pad, x):
-            dx = orig_d(tape, dy, ho, wo, cs_out, weight, stride, pad, x)
+        def dgrad(tape, dy, ho, wo, cs_out, weight, stride, pad, x, into=None):
+            # ``into``: the conv adds the gradient x already has in its epilogue and writes in place
+            before = None if into is None else into.clone()
+            dx = orig_d(tape, dy, ho, wo, cs_out, weight, stride, pad, x, into=into)
+            if before is not None:
+                assert dx.data_ptr() == into.data_ptr()
+                dx = dx - before
             cout, cin, kh, kw = weight.shape
             xs = torch.zeros(x.n, cin, x.h, x.w, dtype=torch.float64, requires_grad=True)
             with torch.enable_grad():
@@ -64,7 +69,7 @@ class LayerChecks(object):
             e = rel(_nchw(dx, x.n, x.h, x.w, x.cs, cin).numpy(), xs.grad.numpy())
             padmax = float(dx.view(x.n, x.h, x.w, x.cs)[..., cin:].abs().max()) if x.cs > cin else 0.0
             me.dgrad.append((max(e, padmax), (x.n, x.h, x.w, cin, cout, kh, stride)))
-            return dx
+            return into if into is not None else dx
 
         T._Tape._wgrad, T._Tape._dgrad = wgrad, dgrad
         self._prev_hook = self.tr.debug_hook
