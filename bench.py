@@ -179,9 +179,15 @@ GFLOP_FWD_PER_CROP = 42.035      # HRNet-W48 coordinates head, f
 
 
 def _timed(step, steps, warmup, dev, dist):
-    """warmup untimed + `steps` timed calls, barrier + synchronize on both sides, max over ranks."""
+    """warmup untimed + `steps` timed calls, barrier + synchronize on both sides, max over ranks.
+    Like the product's hot loop (egonet_amd.trainer.train freezes after its first iteration) the objects
+    alive after the warm-up go to the garbage collector's permanent generation: a full collection costs
+    35 ms of host time otherwise and lands in one step out of ~10."""
+    import gc
     for _ in range(warmup):
         step()
+    gc.collect()
+    gc.freeze()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -198,6 +204,7 @@ def _timed(step, steps, warmup, dev, dist):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    gc.unfreeze()
     return dt / steps, out
 
 

@@ -149,7 +149,13 @@ class LifterTrainStep(object):
     @torch.no_grad()
     def step(self, x, target, update=True):
         """One zero_grad/forward/loss/backward/Adam iteration.  Returns the loss
-        (Python float is NOT forced: a 1-element float64 device tensor)."""
+        (Python float is NOT forced: a 1-element float64 device tensor).  The cyclic garbage collector
+        is paused while the launches are issued (train_hrnet.HRNetTrainStep.step)."""
+        from .train_hrnet import _gc_paused
+        with _gc_paused():
+            return self._step(x, target, update)
+
+    def _step(self, x, target, update):
         L, dev = self.L, self.dev
         B = x.shape[0]              # any size: the reference's DataLoader has no drop_last (trainer.py:113-125)
         if B < 2:

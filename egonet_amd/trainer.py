@@ -19,6 +19,7 @@ executed: the loss weights come from ``loss_func.comp_dict`` when it has one
 read from ``optim.param_groups`` after ``sche.step()``.  Plotting and debug-image
 dumps of the reference are not reproduced.
 """
+import gc
 import os
 import time
 
@@ -192,6 +193,7 @@ def train(train_dataset, model, loss_func, optim, sche, cfgs, logger, metric_fun
     is_hc = isinstance(step, HRNetTrainStep)
     dev = step.dev
     x_buffer, y_buffer = [], []
+    frozen = False
     for epoch in range(1, total_epochs + 1):
         if epoch > 1 and is_hc:
             step.apply_cr_loss = True                       # trainer.py:168-169: L_cr from the second epoch on
@@ -218,6 +220,14 @@ def train(train_dataset, model, loss_func, optim, sche, cfgs, logger, metric_fun
             if metric_func is not None and prediction is not None:
                 avg_acc, cnt, others = metric_func(prediction, meta, cfgs)
                 acc.update(avg_acc, n=cnt, others=others)
+            if not frozen:
+                # everything built so far (model, datasets, the step's packed filters, torch's module
+                # tables: millions of objects) moves to the permanent generation: the full collections
+                # the per-iteration Python objects trigger every ~10 iterations then take < 1 ms
+                # instead of 35 ms of a host that has 1 500 launches per iteration to issue
+                gc.collect()
+                gc.freeze()
+                frozen = True
             if batch_idx % report_every == 0:               # loss read-back only here
                 lv = float(loss.item())
                 logger.info('Epoch: [%d][%d/%d]  loss %.6f  lr %.2e  %.1f samples/s' % (
@@ -238,6 +248,8 @@ def train(train_dataset, model, loss_func, optim, sche, cfgs, logger, metric_fun
             logger.info('=> Snapshot model to {}'.format(path))
             inner = model.module if hasattr(model, 'module') else model
             torch.save(inner.state_dict(), path)
+    if frozen:
+        gc.unfreeze()
     logger.info('Training finished.')
     return {'model': model, 'batch_idx': x_buffer, 'loss': y_buffer}
 

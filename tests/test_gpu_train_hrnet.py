@@ -51,7 +51,9 @@ def test_first_step_gradients_vs_reference():
     loss = tr.step(x, torch.from_numpy(g['target'][0]).cuda(), torch.from_numpy(g['joints'][0]), update=False)
     assert abs(float(loss.item()) - float(g['losses'][0])) < 2e-5 * abs(float(g['losses'][0]))
     np.testing.assert_allclose(tr.last_maps.cpu().numpy(), g['maps1'], rtol=0, atol=2e-4)
-    np.testing.assert_allclose(tr.last_coords.cpu().numpy(), g['coords1'], rtol=0, atol=1e-5)
+    # coordinates are normalised by the 64-pixel crop: the parity bar of 1e-3 px is 1.5e-5 here (which tile
+    # configuration -- direct or Winograd -- the tuner measures fastest on this box moves them by ~1e-5)
+    np.testing.assert_allclose(tr.last_coords.cpu().numpy(), g['coords1'], rtol=0, atol=1.5e-5)
     named = dict(net.named_parameters())
     order = json.loads(str(g['param_order']))
     assert list(named) == order
@@ -64,24 +66,32 @@ def test_first_step_gradients_vs_reference():
     assert max(errs) < 5e-2 and np.median(errs) < 2e-3, errs
 
 
-def test_two_steps_vs_reference():
+@pytest.mark.parametrize('wino', [False, True])
+def test_two_steps_vs_reference(wino):
+    """Two optimisation steps against the reference's fixture.  wino=False pins the direct kernels (tight
+    bounds); wino=True lets the tuner put eligible layers (32-multiple widths) on the Winograd kernels:
+    the first step agrees as tightly, after it Adam's scale-free update turns the sign of gradients that
+    are numerically zero into +-lr moves, so the second loss is only bounded to 2e-3."""
     g = golden('hrnet_train.npz')
     cfg = fixture_cfg(g)
     net, _ = _tiny_model(cfg)
     tr = HRNetTrainStep(net, lr=1e-3)
+    tr.allow_wino = wino
     losses = []
     for it in range(2):
         x = synth.synth_crops(4, 3, 64, 64, seed=30 + it).cuda()
         loss = tr.step(x, torch.from_numpy(g['target'][it]).cuda(), torch.from_numpy(g['joints'][it]))
         losses.append(float(loss.item()))
-    np.testing.assert_allclose(losses, g['losses'], rtol=2e-4)
+    np.testing.assert_allclose(losses[0], g['losses'][0], rtol=2e-5)
+    np.testing.assert_allclose(losses[1], g['losses'][1], rtol=2e-3 if wino else 2e-4)
     fin = {k: v.detach().cpu().numpy() for k, v in net.state_dict().items()}
     # after two Adam steps every entry has moved by ~2e-3 (lr * m/sqrt(v) is scale free):
     # agreement to a few 1e-6 is the rule; an entry whose two gradients nearly cancel
     # amplifies a ReLU-tie difference (tests/train_checks.py) -- those are bounded in number
     for k in json.loads(str(g['keys'])):
         d = np.abs(fin[k] - g['p2/' + k])
-        assert np.median(d) < 5e-6 and np.mean(d > 5e-4) < 0.02, (k, float(np.median(d)), float(np.mean(d > 5e-4)))
+        assert np.median(d) < (5e-5 if wino else 5e-6) and np.mean(d > 5e-4) < (0.1 if wino else 0.02), \
+            (k, float(np.median(d)), float(np.mean(d > 5e-4)))
     for k in ('bn1.running_mean', 'bn1.running_var', 'stage3.0.branches.2.0.bn1.running_var',
               'head2.1.bn2.running_mean'):
         np.testing.assert_allclose(fin[k], g['p2/' + k], rtol=1e-3, atol=1e-5, err_msg=k)

@@ -60,6 +60,10 @@ def main():
         step = lambda: graphed(x, tgt, jt)                 # noqa: E731
         step()
 
+    import gc
+    gc.collect()
+    gc.freeze()             # as egonet_amd.trainer.train does after its first iteration
+
     def fence():
         torch.cuda.synchronize()
         if world > 1:
