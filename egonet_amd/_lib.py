@@ -69,6 +69,7 @@ SIGNATURES = {
     'egn_add_f32': (_i, [_p, _p, _p, C.c_long, _p]),
     'egn_mse_f32': (_i, [_p, _p, _i, _i, _i, _i, C.c_float, _i, _p, _p, _p]),
     'egn_l1_f32': (_i, [_p, _p, C.c_long, C.c_float, _p, _p, _p]),
+    'egn_elem_loss_f32': (_i, [_p, _p, _i, _i, _i, _i, _i, C.c_float, _i, _p, _p, _p]),
     'egn_cross_ratio_ws_bytes': (C.c_long, [_i, _i]),
     'egn_cross_ratio_f32': (_i, [_p, _i, _i, _p, _i, _d, C.c_float, _i, C.c_float, _p, _p, _p, _p]),
     'egn_sigmoid_bwd_f32': (_i, [_p, _p, _p, C.c_long, _p]),
@@ -82,6 +83,8 @@ SIGNATURES = {
     'egn_ema_f32': (_i, [_p, _p, C.c_float, _i, _p]),
     'egn_adam_step_f32': (_i, [_p, _p, _p, _p, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, _i, _p]),
     'egn_adam_step_dev_f32': (_i, [_p, _p, _p, _p, C.c_long, _p, C.c_float, C.c_float, C.c_float, _p, _p]),
+    'egn_adam_l2_step_dev_f32': (_i, [_p, _p, _p, _p, C.c_long, _p, C.c_float, C.c_float, C.c_float, C.c_float, _p, _p]),
+    'egn_sgd_step_dev_f32': (_i, [_p, _p, _p, C.c_long, _p, C.c_float, C.c_float, _p, _p]),
     'egn_program_create': (_p, [_i]),
     'egn_program_destroy': (None, [_p]),
     'egn_program_bind': (_i, [_p, _i, _p]),

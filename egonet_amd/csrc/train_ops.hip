@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(ColArgs p, doubl
           for (int k = 0; k < 4; ++k) {
             const float xhat = (v[k] - mean[k]) * istd[k];
             float dd = d[k];
-            if (p.relu && !(gm[k] * xhat + bt[k] + rs[k] > 0.f)) dd = 0.f;
+            if (p.relu && !(gm[k] * xhat + bt[k] + rs[k] > 0.f)) dd = p.relu == 2 ? 0.01f * dd : 0.f;
             f0[k] += dd;
             f1[k] += dd * xhat;
           }
@@ -358,7 +358,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
       float o = 0.f;
       if (ok[k]) {
         o = pg[k] * ((in[k] - pm[k]) * pi[k]) + pb[k] + ra[k];
-        if (relu) o = fmaxf(o, 0.f);
+        if (relu == 2) o = o > 0.f ? o : 0.01f * o;   // nn.LeakyReLU() default slope (FCmodel.py:19-22)
+        else if (relu) o = fmaxf(o, 0.f);
         if (mask) o *= mka[k] * keep_scale;
       }
       out[k] = o;
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict_
         const float xhat = (zi[k] - pm[k]) * pi[k];
         d = di[k];
         if (mask) d *= mi[k] * keep_scale;
-        if (relu && !(pg[k] * xhat + pb[k] + ri[k] > 0.f)) d = 0.f;
+        if (relu && !(pg[k] * xhat + pb[k] + ri[k] > 0.f)) d = relu == 2 ? 0.01f * d : 0.f;
         o = pg[k] * pi[k] * (d - pdb[k] * inv_rows - xhat * pdg[k] * inv_rows);
       }
       out[k] = o;
@@ -518,6 +519,46 @@ extern "C" int egn_mse_f32(const float* pred, const float* tgt, int rows, int co
   if (rows <= 0 || cols <= 0 || ld_pred < cols || ld_tgt < cols) return EGN_E_BADARG;
   hipLaunchKernelGGL(mse_kernel, dim3(grid_for((size_t)rows * cols, 256) > 256 ? 256 : grid_for((size_t)rows * cols, 256)),
                      dim3(256), 0, (hipStream_t)stream, pred, tgt, rows, cols, ld_pred, ld_tgt, weight, accumulate, dpred, loss);
+  return (int)hipGetLastError();
+}
+
+// The three criteria of the reference's loss_dict (function.py:17-20) over a [rows, cols] view with row
+// pitches: crit 0 = MSELoss, 1 = L1Loss, 2 = SmoothL1Loss (beta = 1), all reduction='mean':
+//   loss[0] += weight * mean(c(pred - tgt));   dpred (= or +=) weight * c'(pred - tgt) / (rows*cols)
+__global__ __launch_bounds__(256) void elem_loss_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                        int rows, int cols, int ldp, int ldt, int crit, float weight,
+                                                        int accumulate, float* __restrict__ dpred,
+                                                        double* __restrict__ loss) {
+  const size_t total = (size_t)rows * cols;
+  const double inv = (double)weight / (double)total;
+  double acc = 0.0;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(e / cols), c = (int)(e % cols);
+    const float d = pred[(size_t)r * ldp + c] - tgt[(size_t)r * ldt + c];
+    const float ad = fabsf(d);
+    double v, gd;
+    if (crit == 0) { v = (double)d * d; gd = 2.0 * d; }
+    else if (crit == 1) { v = ad; gd = d > 0.f ? 1.0 : (d < 0.f ? -1.0 : 0.0); }
+    else if (ad < 1.f) { v = 0.5 * (double)d * d; gd = d; }
+    else { v = (double)ad - 0.5; gd = d > 0.f ? 1.0 : -1.0; }
+    acc += v;
+    if (dpred) {
+      float* q = dpred + (size_t)r * ldp + c;
+      const float gf = (float)(gd * inv);
+      *q = accumulate ? *q + gf : gf;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv);
+}
+extern "C" int egn_elem_loss_f32(const float* pred, const float* tgt, int rows, int cols, int ld_pred, int ld_tgt,
+                                 int crit, float weight, int accumulate, float* dpred, double* loss, void* stream) {
+  if (rows <= 0 || cols <= 0 || ld_pred < cols || ld_tgt < cols || crit < 0 || crit > 2 || !loss) return EGN_E_BADARG;
+  int g = grid_for((size_t)rows * cols, 256);
+  if (g > 256) g = 256;
+  hipLaunchKernelGGL(elem_loss_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, pred, tgt, rows, cols, ld_pred,
+                     ld_tgt, crit, weight, accumulate, dpred, loss);
   return (int)hipGetLastError();
 }
 
@@ -591,6 +632,68 @@ extern "C" int egn_adam_step_dev_f32(float* p, const float* g, float* m, float* 
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
   hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
                      (size_t)n, lr_dev, beta1, beta2, eps, step_dev);
+  return (int)hipGetLastError();
+}
+
+// torch.optim.Adam with weight_decay (L2, coupled: g += wd * p before the moments, optimizer.py:19-21) and
+// torch.optim.SGD(momentum, weight_decay) with dampening 0, no Nesterov (optimizer.py:23-26):
+//   g' = g + wd p;   buf = g' on the first step, momentum * buf + g' after;   p -= lr * buf
+// Step counter and learning rate in device memory like egn_adam_step_dev_f32.
+__global__ __launch_bounds__(256) void adam_l2_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                          const float* __restrict__ hyper, float b1, float b2, float eps,
+                                                          float wd, const int* __restrict__ state) {
+  __shared__ float s_step, s_bc2;
+  if (threadIdx.x == 0) {
+    const double t = (double)state[0];
+    s_step = (float)((double)hyper[0] / (1.0 - pow((double)b1, t)));
+    s_bc2 = (float)sqrt(1.0 - pow((double)b2, t));
+  }
+  __syncthreads();
+  const float step_size = s_step, bc2_sqrt = s_bc2;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float pe = p[e];
+    const float gi = g[e] + wd * pe;
+    const float mi = b1 * m[e] + (1.f - b1) * gi;
+    const float vi = b2 * v[e] + (1.f - b2) * gi * gi;
+    m[e] = mi;
+    v[e] = vi;
+    p[e] = pe - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+  }
+}
+extern "C" int egn_adam_l2_step_dev_f32(float* p, const float* g, float* m, float* v, long n, const float* lr_dev,
+                                        float beta1, float beta2, float eps, float weight_decay, int* step_dev,
+                                        void* stream) {
+  if (n <= 0 || !lr_dev || !step_dev || weight_decay < 0.f) return EGN_E_BADARG;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  hipLaunchKernelGGL(adam_l2_dev_kernel, dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (size_t)n, lr_dev, beta1, beta2, eps, weight_decay, step_dev);
+  return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void sgd_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ buf, size_t n,
+                                                      const float* __restrict__ hyper, float momentum, float wd,
+                                                      const int* __restrict__ state) {
+  const float lr = hyper[0];
+  const bool first = state[0] <= 1;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t)gridDim.x * blockDim.x) {
+    const float pe = p[e];
+    float gi = g[e] + wd * pe;
+    if (momentum != 0.f) {
+      gi = first ? gi : momentum * buf[e] + gi;
+      buf[e] = gi;
+    }
+    p[e] = pe - lr * gi;
+  }
+}
+extern "C" int egn_sgd_step_dev_f32(float* p, const float* g, float* buf, long n, const float* lr_dev, float momentum,
+                                    float weight_decay, int* step_dev, void* stream) {
+  if (n <= 0 || !lr_dev || !step_dev || momentum < 0.f || weight_decay < 0.f || (momentum != 0.f && !buf))
+    return EGN_E_BADARG;
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+  hipLaunchKernelGGL(sgd_dev_kernel, dim3(grid_for((size_t)n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, buf,
+                     (size_t)n, lr_dev, momentum, weight_decay, step_dev);
   return (int)hipGetLastError();
 }
 

@@ -78,13 +78,38 @@ class FlatParams(object):
     def t(self):
         return int(self.step_dev.item())
 
-    def adam_step(self, lr, betas, eps, stream):
+    def adam_step(self, lr, betas, eps, stream, weight_decay=0.0):
+        """torch.optim.Adam (optimizer.py:19-21); weight_decay is the coupled L2 form torch implements."""
         if lr != self._lr_host:                 # only when the scheduler changed it (never inside a graph)
             self.lr_dev.fill_(lr)
             self._lr_host = lr
-        _lib.check(_lib.lib().egn_adam_step_dev_f32(_lib.ptr(self.flat), _lib.ptr(self.grad), _lib.ptr(self.m),
-                                                    _lib.ptr(self.v), self.numel, _lib.ptr(self.lr_dev), betas[0],
-                                                    betas[1], eps, _lib.ptr(self.step_dev), stream), 'adam')
+        L = _lib.lib()
+        if weight_decay:
+            _lib.check(L.egn_adam_l2_step_dev_f32(_lib.ptr(self.flat), _lib.ptr(self.grad), _lib.ptr(self.m),
+                                                  _lib.ptr(self.v), self.numel, _lib.ptr(self.lr_dev), betas[0],
+                                                  betas[1], eps, weight_decay, _lib.ptr(self.step_dev), stream), 'adam')
+        else:
+            _lib.check(L.egn_adam_step_dev_f32(_lib.ptr(self.flat), _lib.ptr(self.grad), _lib.ptr(self.m),
+                                               _lib.ptr(self.v), self.numel, _lib.ptr(self.lr_dev), betas[0],
+                                               betas[1], eps, _lib.ptr(self.step_dev), stream), 'adam')
+
+    def sgd_step(self, lr, momentum, weight_decay, stream):
+        """torch.optim.SGD(momentum, weight_decay), dampening 0, no Nesterov (optimizer.py:23-26); the
+        momentum buffer lives in ``m``."""
+        if lr != self._lr_host:
+            self.lr_dev.fill_(lr)
+            self._lr_host = lr
+        _lib.check(_lib.lib().egn_sgd_step_dev_f32(_lib.ptr(self.flat), _lib.ptr(self.grad), _lib.ptr(self.m),
+                                                   self.numel, _lib.ptr(self.lr_dev), momentum, weight_decay,
+                                                   _lib.ptr(self.step_dev), stream), 'sgd')
+
+    def update(self, o, stream):
+        """One optimizer step as configured on the step object ``o`` (lr, optim_type, betas, eps, momentum,
+        weight_decay)."""
+        if o.optim_type == 'sgd':
+            self.sgd_step(o.lr, o.momentum, o.weight_decay, stream)
+        else:
+            self.adam_step(o.lr, o.betas, o.eps, stream, o.weight_decay)
 
 
 @contextlib.contextmanager
@@ -526,7 +551,8 @@ class HRNetTrainStep(object):
     CR_CRITERIA = {'mse': 0, 'l1': 1, 'sl1': 2}      # loss_dict, function.py:17-20
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, w_hm=1.0, w_coor=0.1, grad_sync=None,
-                 sigma=1, w_cr=None, cr_type='sl1', cr_indices=None, target_cr=4.0 / 3.0, cr_loss_thres=0.15):
+                 sigma=1, w_cr=None, cr_type='sl1', cr_indices=None, target_cr=4.0 / 3.0, cr_loss_thres=0.15,
+                 hm_type='mse', coor_type='l1', optim_type='adam', momentum=0.0, weight_decay=0.0):
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise ValueError('HRNetTrainStep needs the model on a GPU')
@@ -539,6 +565,11 @@ class HRNetTrainStep(object):
         self.dev = p0.device
         self.L = _lib.lib()
         self.lr, self.betas, self.eps = lr, betas, eps
+        if optim_type not in ('adam', 'sgd'):
+            raise NotImplementedError('optimizer %r (optimizer.py:8-40 knows adam and sgd)' % (optim_type,))
+        self.optim_type, self.momentum, self.weight_decay = optim_type, float(momentum), float(weight_decay)
+        # criteria of the heat-map and coordinate terms: any of loss_dict (function.py:17-20)
+        self.hm_crit, self.coor_crit = self.CR_CRITERIA[hm_type], self.CR_CRITERIA[coor_type]
         self.w_hm, self.w_coor = float(w_hm), float(w_coor or 0.0)
         # cross-ratio term (function.py:113-153, train_IGRs.py:44-46): off unless a weight is
         # given ('None' in the shipped YAML) AND apply_cr_loss is set (trainer.py:168-169:
@@ -639,8 +670,9 @@ class HRNetTrainStep(object):
                         gt[..., 0] /= w            # function.py:160-161 (img_size = (width, height))
                         gt[..., 1] /= h
                         gt = gt.contiguous()
-                        _lib.check(L.egn_l1_f32(_lib.ptr(cd), _lib.ptr(gt), cd.numel(), self.w_coor, _lib.ptr(dc),
-                                                _lib.ptr(self.loss_dev), st), 'l1')
+                        _lib.check(L.egn_elem_loss_f32(_lib.ptr(cd), _lib.ptr(gt), 1, cd.numel(), cd.numel(),
+                                                       cd.numel(), self.coor_crit, self.w_coor, 0, _lib.ptr(dc),
+                                                       _lib.ptr(self.loss_dev), st), 'coor loss')
                     else:
                         dc.zero_()
                     if use_cr:
@@ -674,9 +706,10 @@ class HRNetTrainStep(object):
             tg = tape._empty(n * aug.h * aug.w * aug.cs)
             _lib.check(L.egn_nchw_to_nhwc_f32(_lib.ptr(target), _lib.ptr(tg), n, J, aug.h, aug.w, aug.cs, st))
             da = torch.zeros(n * aug.h * aug.w * aug.cs, dtype=torch.float32, device=self.dev)
-            # (1/K) sum_k 0.5*MSE_k = 0.5 * MSE over all joints (equal element counts)
-            _lib.check(L.egn_mse_f32(_lib.ptr(tape.data[id(aug)]), _lib.ptr(tg), n * aug.h * aug.w, J, aug.cs, aug.cs,
-                                     0.5 * self.w_hm, 0, _lib.ptr(da), _lib.ptr(self.loss_dev), st), 'mse')
+            # (1/K) sum_k 0.5*crit_k = 0.5 * crit over all joints (equal element counts), function.py:95-111
+            _lib.check(L.egn_elem_loss_f32(_lib.ptr(tape.data[id(aug)]), _lib.ptr(tg), n * aug.h * aug.w, J, aug.cs,
+                                           aug.cs, self.hm_crit, 0.5 * self.w_hm, 0, _lib.ptr(da),
+                                           _lib.ptr(self.loss_dev), st), 'hm loss')
             tape._accum(aug, da)
             # the gradient all-reduce of a slice of the flat buffer starts (on a communication
             # stream) as soon as every parameter in it has its gradient kernels issued
@@ -692,7 +725,7 @@ class HRNetTrainStep(object):
             elif self.grad_sync is not None:
                 self.grad_sync(self.flat.grad)
             if update:
-                self.flat.adam_step(self.lr, self.betas, self.eps, st)
+                self.flat.update(self, st)
             self.packs.finalize()     # first step: the set of filters is known now
             invalidate(m)             # the inference engine caches folded weights (raw-pointer writes)
             if self.debug_hook is not None:

@@ -37,15 +37,18 @@ class _Unit(object):
 
 
 class LifterTrainStep(object):
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, dropout=None, grad_sync=None):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, dropout=None, grad_sync=None,
+                 optim_type='adam', momentum=0.0, weight_decay=0.0):
         p0 = next(model.parameters())
         if not p0.is_cuda:
             raise ValueError('LifterTrainStep needs the model on a GPU')
-        if model.leaky:
-            raise NotImplementedError('native training implements ReLU (the shipped configs); leaky=False')
+        if optim_type not in ('adam', 'sgd'):
+            raise NotImplementedError('optimizer %r (optimizer.py:8-40 knows adam and sgd)' % (optim_type,))
         self.model = model
         self.dev = p0.device
         self.lr, self.betas, self.eps = lr, betas, eps
+        self.optim_type, self.momentum, self.weight_decay = optim_type, float(momentum), float(weight_decay)
+        self.act = 2 if model.leaky else 1       # nn.LeakyReLU() / nn.ReLU (FCmodel.py:19-22) in the BN kernels
         self.grad_sync = grad_sync
         self.p = float(model.p_dropout if dropout is None else dropout)
         self.units = [_Unit(model.w1, model.batch_norm1)]
@@ -190,7 +193,7 @@ class LifterTrainStep(object):
                     mask.bernoulli_(1.0 - self.p)          # keep mask (0/1), one launch, capture-aware RNG
                 y = self._buf('y%d' % ui, B, u.outf)
                 _lib.check(L.egn_bn_act_fwd_f32(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(u.bn.weight),
-                                                _lib.ptr(u.bn.bias), _lib.ptr(mask), keep, 1, None, _lib.ptr(y), B,
+                                                _lib.ptr(u.bn.bias), _lib.ptr(mask), keep, self.act, None, _lib.ptr(y), B,
                                                 u.outf, u.outf, st), 'bn_act_fwd')
                 saved.append((a, ld_a, z, mean, istd, mask))
                 if ui == 0:
@@ -235,12 +238,12 @@ class LifterTrainStep(object):
                     d_y = d_block_out     # unit 0 and the second unit of a block see the block-output gradient
                 dbeta, dgamma = g[id(u.bn.bias)], g[id(u.bn.weight)]
                 _lib.check(L.egn_bn_bwd_sums_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
-                                                 _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), 1, None,
+                                                 _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), self.act, None,
                                                  B, u.outf, u.outf, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(ws),
                                                  st), 'bn_bwd_sums')
                 dz = self._buf('dz%d' % ui, B, u.outf)     # per unit: the side stream reads it until the join
                 _lib.check(L.egn_bn_bwd_dz_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
-                                               _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), 1, None,
+                                               _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), self.act, None,
                                                _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(dz), None, B, u.outf,
                                                u.outf, st), 'bn_bwd_dz')
                 self._wgrad(a_in, ld_in, u.inf, dz, u.outf, u.outf, B, g[id(u.fc.weight)])
@@ -264,7 +267,7 @@ class LifterTrainStep(object):
             elif self.grad_sync is not None:
                 self.grad_sync(self.flat.grad)
             if update:
-                self.flat.adam_step(self.lr, self.betas, self.eps, st)
+                self.flat.update(self, st)
             # weights and BatchNorm buffers were written through raw pointers: eval-mode forwards
             # between steps (eval_during, EgoNet.L after fine-tuning) must re-fold them
             invalidate(self.model)

@@ -44,14 +44,36 @@ def get_loader(dataset, cfgs, split, collate_fn=None):
 def prepare_optim(model, cfgs):
     """optimizer.py:8-40 -- the torch objects carry the schedule; the native step does the update."""
     o = cfgs['optimizer']
-    if o['optim_type'] != 'adam':
-        raise NotImplementedError('native training implements Adam (the shipped configs), got %r' % o['optim_type'])
-    if o.get('weight_decay', 0.0):
-        raise NotImplementedError('weight_decay != 0')
     params = [p for p in model.parameters() if p.requires_grad]
-    optim = torch.optim.Adam(params, lr=o['lr'], weight_decay=0.0)
+    wd = float(o.get('weight_decay', 0.0) or 0.0)
+    if o['optim_type'] == 'adam':
+        optim = torch.optim.Adam(params, lr=o['lr'], weight_decay=wd)
+    elif o['optim_type'] == 'sgd':
+        optim = torch.optim.SGD(params, lr=o['lr'], momentum=float(o.get('momentum', 0.0) or 0.0), weight_decay=wd)
+    else:
+        raise NotImplementedError(o['optim_type'])              # as the reference (optimizer.py:27-28)
     sche = torch.optim.lr_scheduler.MultiStepLR(optim, milestones=o['milestones'], gamma=o['gamma'])
     return optim, sche
+
+
+def _optim_kwargs(optim, cfgs):
+    """optimizer family / momentum / weight decay of the native update, from the torch optimizer object
+    ``prepare_optim`` made (or, without one, from cfgs['optimizer'])."""
+    if optim is not None:
+        g = optim.param_groups[0]
+        if isinstance(optim, torch.optim.SGD):
+            if g.get('dampening', 0) or g.get('nesterov', False):
+                raise NotImplementedError('SGD with dampening / Nesterov momentum')
+            return dict(optim_type='sgd', momentum=float(g.get('momentum', 0.0)), weight_decay=float(g['weight_decay']))
+        if isinstance(optim, torch.optim.Adam) and not isinstance(optim, torch.optim.AdamW):
+            if g.get('amsgrad', False):
+                raise NotImplementedError('Adam with amsgrad')
+            return dict(optim_type='adam', betas=tuple(g['betas']), eps=float(g['eps']),
+                        weight_decay=float(g['weight_decay']))
+        raise NotImplementedError('native update for %s' % type(optim).__name__)
+    o = cfgs['optimizer']
+    return dict(optim_type=o.get('optim_type', 'adam'), momentum=float(o.get('momentum', 0.0) or 0.0),
+                weight_decay=float(o.get('weight_decay', 0.0) or 0.0))
 
 
 _CRITERION_NAMES = {'MSELoss': 'mse', 'L1Loss': 'l1', 'SmoothL1Loss': 'sl1'}      # loss_dict, function.py:17-20
@@ -71,16 +93,20 @@ def _loss_weights(loss_func, cfgs):
     else:
         wl = list(hm.get('loss_weight_list', [1.0, 0.1, 'None']))
         spec = list(hm.get('loss_spec_list', ['mse', 'l1', 'None']))
-    if spec[0] not in ('mse', 'None') or spec[1] not in ('l1', 'None'):
-        raise NotImplementedError('native loss: heat-map term mse, coordinate term l1 (the shipped configs); got %r'
-                                  % (spec[:2],))
+    for k in spec[:2]:
+        if k not in ('mse', 'l1', 'sl1', 'None'):
+            raise NotImplementedError('loss criterion %r (loss_dict knows mse, l1, sl1)' % (k,))
     w_hm = float(wl[0]) if spec[0] != 'None' else 0.0
     w_coor = float(wl[1]) if spec[1] != 'None' else 0.0
     cr = {}
+    if spec[0] not in ('mse', 'None'):
+        cr['hm_type'] = spec[0]          # keywords of HRNetTrainStep beyond the shipped mse / l1 pair
+    if spec[1] not in ('l1', 'None'):
+        cr['coor_type'] = spec[1]
     if spec[2] != 'None' and wl[2] not in _OFF:
         if spec[2] not in ('mse', 'l1', 'sl1'):
             raise NotImplementedError('cross-ratio criterion %r' % spec[2])
-        cr = dict(w_cr=float(wl[2]), cr_type=spec[2],
+        cr.update(w_cr=float(wl[2]), cr_type=spec[2],
                   cr_indices=getattr(loss_func, 'cr_indices', None),
                   target_cr=getattr(loss_func, 'target_cr', None) or 4.0 / 3.0,
                   cr_loss_thres=getattr(loss_func, 'cr_loss_thres', hm.get('cr_loss_threshold', 0.15)))
@@ -97,12 +123,13 @@ def make_step(model, cfgs, loss_func=None, optim=None):
         w_hm, w_coor, cr = _loss_weights(loss_func, cfgs)
         sigma = cfgs.get('heatmapModel', {}).get('sigma', 1)
         if inner.head_type == 'heatmap':
-            w_coor, cr = 0.0, {}
+            w_coor, cr = 0.0, {k: v for k, v in cr.items() if k == 'hm_type'}
+        cr.update(_optim_kwargs(optim, cfgs))
         step = HRNetTrainStep(inner, lr=lr, w_hm=w_hm, w_coor=w_coor, grad_sync=sync, sigma=sigma, **cr)
         step.apply_cr_loss = bool(getattr(loss_func, 'apply_cr_loss', False))
         return step
     if isinstance(inner, FCmodel.FCModel):
-        return LifterTrainStep(inner, lr=lr, grad_sync=sync)
+        return LifterTrainStep(inner, lr=lr, grad_sync=sync, **_optim_kwargs(optim, cfgs))
     raise TypeError('no native training step for %s' % type(inner).__name__)
 
 

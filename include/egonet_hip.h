@@ -270,7 +270,9 @@ int egn_bn_stats_finalize_f32(const double* partials, long nrows, int rows, int 
                               float eps, float* mean, float* invstd,
                               float* var_unbiased, float* running_mean,
                               float* running_var, float momentum, void* stream);
-/* y = relu?(gamma*(z-mean)*invstd + beta + res?) * (mask ? mask*keep_scale : 1)
+/* relu: 0 none, 1 nn.ReLU, 2 nn.LeakyReLU() (slope 0.01, FCmodel.py:19-22) -- here and in the two
+ * backward entry points below.
+ * y = relu?(gamma*(z-mean)*invstd + beta + res?) * (mask ? mask*keep_scale : 1)
  * (BatchNorm on batch statistics + residual + ReLU + inverted dropout) */
 int egn_bn_act_fwd_f32(const float* z, const float* mean, const float* invstd,
                        const float* gamma, const float* beta, const float* mask,
@@ -299,6 +301,16 @@ int egn_add_f32(const float* a, const float* b, float* y, long n, void* stream);
 int egn_mse_f32(const float* pred, const float* tgt, int rows, int cols,
                 int ld_pred, int ld_tgt, float weight, int accumulate,
                 float* dpred, double* loss, void* stream);
+/* The three criteria of the reference's loss_dict (libs/loss/function.py:17-20)
+ * over a [rows, cols] view with row pitches; crit 0 = nn.MSELoss, 1 = nn.L1Loss,
+ * 2 = nn.SmoothL1Loss (beta 1), reduction 'mean':
+ *   *loss += weight * mean(c(pred - tgt)) (zero it first);
+ *   dpred (= or, with accumulate, +=) weight * c'(pred - tgt) / (rows*cols).
+ * Heat-map term L_hm (function.py:95-111): weight 0.5 * w_hm over all joints;
+ * coordinate term L_2d (:155-168): rows 1, cols N*K*2. */
+int egn_elem_loss_f32(const float* pred, const float* tgt, int rows, int cols,
+                      int ld_pred, int ld_tgt, int crit, float weight,
+                      int accumulate, float* dpred, double* loss, void* stream);
 /* *loss += weight*mean(|pred-tgt|); dpred = weight*sign(pred-tgt)/n
  * (nn.L1Loss, the coordinate term, function.py:155-168) */
 int egn_l1_f32(const float* pred, const float* tgt, long n, float weight,
@@ -370,6 +382,19 @@ int egn_adam_step_f32(float* p, const float* g, float* m, float* v, long n,
 int egn_adam_step_dev_f32(float* p, const float* g, float* m, float* v, long n,
                           const float* lr_dev, float beta1, float beta2,
                           float eps, int* step_dev, void* stream);
+/* torch.optim.Adam(weight_decay) -- coupled L2: g += weight_decay * p before the
+ * moments (libs/optimizer/optimizer.py:19-21); state as egn_adam_step_dev_f32 */
+int egn_adam_l2_step_dev_f32(float* p, const float* g, float* m, float* v,
+                             long n, const float* lr_dev, float beta1,
+                             float beta2, float eps, float weight_decay,
+                             int* step_dev, void* stream);
+/* torch.optim.SGD(momentum, weight_decay), dampening 0, no Nesterov
+ * (libs/optimizer/optimizer.py:23-26): g' = g + wd p; buf = g' on the first step,
+ * momentum*buf + g' after; p -= lr*buf.  buf may be NULL when momentum == 0.
+ * step_dev[0] is incremented first (first step <=> it becomes 1). */
+int egn_sgd_step_dev_f32(float* p, const float* g, float* buf, long n,
+                         const float* lr_dev, float momentum, float weight_decay,
+                         int* step_dev, void* stream);
 
 /* ------------------------------------------------------------------------
  * Programs: a recorded sequence of the launches above with every pointer

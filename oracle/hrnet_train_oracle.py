@@ -50,36 +50,37 @@ def cross_ratio_loss(coords, cr_indices, target_cr=4.0 / 3.0, threshold=0.15, cr
 
 
 def composite_loss(out, target, joints_xy, img_size, w_hm=1.0, w_coor=0.1, w_cr=None, cr_indices=None,
-                   target_cr=4.0 / 3.0, cr_loss_thres=0.15, cr_type='sl1'):
+                   target_cr=4.0 / 3.0, cr_loss_thres=0.15, cr_type='sl1', hm_type='mse', coor_type='l1'):
     """out = (maps [N,K,H,W], coords [N,K,2]); target [N,K,H,W]; joints_xy [N,K,2] in
-    input-image pixels.  w_cr (with cr_indices) adds the cross-ratio term."""
-    total = _composite_supervised(out, target, joints_xy, img_size, w_hm, w_coor)
+    input-image pixels.  w_cr (with cr_indices) adds the cross-ratio term; hm_type / coor_type pick the
+    criteria of the first two terms from loss_dict (function.py:17-20, 61-93)."""
+    total = _composite_supervised(out, target, joints_xy, img_size, w_hm, w_coor, hm_type, coor_type)
     if w_cr is not None and isinstance(out, tuple):
         total = total + cross_ratio_loss(out[1], cr_indices, target_cr, cr_loss_thres, cr_type) * w_cr
     return total
 
 
-def _composite_supervised(out, target, joints_xy, img_size, w_hm, w_coor):
+def _composite_supervised(out, target, joints_xy, img_size, w_hm, w_coor, hm_type='mse', coor_type='l1'):
     maps, coords = out if isinstance(out, tuple) else (out, None)
     n, k = maps.shape[:2]
     pred = maps.reshape(n, k, -1)
     gt = target.reshape(n, k, -1)
     loss = 0
     for j in range(k):                      # function.py:103-111, joint by joint
-        loss = loss + 0.5 * F.mse_loss(pred[:, j], gt[:, j], reduction='mean')
+        loss = loss + 0.5 * _CRIT[hm_type](pred[:, j], gt[:, j], reduction='mean')
     total = (loss / k) * w_hm
     if coords is None or not w_coor:
         return total
     cgt = joints_xy.clone().float()
     cgt[:, :, 0] /= img_size[0]
     cgt[:, :, 1] /= img_size[1]
-    return total + F.l1_loss(coords, cgt, reduction='mean') * w_coor
+    return total + _CRIT[coor_type](coords, cgt, reduction='mean') * w_coor
 
 
 class HRNetTrainOracle(object):
     """state_dict (cloned) + Adam state; ``step`` returns (loss, maps, coords)."""
 
-    def __init__(self, sd, cfgs, lr=1e-3, w_hm=1.0, w_coor=0.1, frozen_prefixes=(), cr=None):
+    def __init__(self, sd, cfgs, lr=1e-3, w_hm=1.0, w_coor=0.1, frozen_prefixes=(), cr=None, optim=None):
         self.sd = {k: v.clone() for k, v in sd.items()}
         self.cfgs = cfgs
         self.w = (w_hm, w_coor)
@@ -89,7 +90,14 @@ class HRNetTrainOracle(object):
                            and not any(k.startswith(p) for p in frozen_prefixes)]
         for k in self.param_keys:
             self.sd[k].requires_grad_(True)
-        self.opt = torch.optim.Adam([self.sd[k] for k in self.param_keys], lr=lr)
+        # optim: keywords of prepare_optim (optimizer.py:8-40): optim_type 'adam' | 'sgd', momentum, weight_decay
+        o = dict(optim or {})
+        params = [self.sd[k] for k in self.param_keys]
+        if o.get('optim_type', 'adam') == 'sgd':
+            self.opt = torch.optim.SGD(params, lr=lr, momentum=o.get('momentum', 0.0),
+                                       weight_decay=o.get('weight_decay', 0.0))
+        else:
+            self.opt = torch.optim.Adam(params, lr=lr, weight_decay=o.get('weight_decay', 0.0))
 
     def step(self, x, target, joints_xy, update=True):
         self.opt.zero_grad()

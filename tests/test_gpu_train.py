@@ -51,6 +51,44 @@ def test_lifter_train_step_vs_reference_iterations():
         np.testing.assert_allclose(got[k].numpy(), v.numpy(), rtol=0, atol=tol, err_msg=k)
 
 
+@pytest.mark.parametrize('leaky,optim', [
+    (True, dict(optim_type='adam', weight_decay=0.0)),
+    (True, dict(optim_type='sgd', momentum=0.9, weight_decay=1e-3)),
+    (False, dict(optim_type='adam', weight_decay=1e-2)),
+])
+def test_lifter_leaky_relu_and_optimizer_variants_vs_oracle(leaky, optim):
+    """FCModel(leaky=True) trains with nn.LeakyReLU() (FCmodel.py:19-22); optimizer.py:8-40 offers SGD with
+    momentum and weight decay for both optimizers: three steps against the CPU oracle."""
+    cfg = configs.tiny_config()
+    cfg['FCModel'].update(dropout=0.0, leaky=leaky)
+    net = FCmodel.get_fc_model(1, cfg, 10, 12)
+    assert net.leaky == leaky
+    sd = synth.synth_state_dict(net.state_dict(), seed=4)
+    net.load_state_dict(sd)
+    net = net.cuda().train()
+    lr = 1e-2 if optim['optim_type'] == 'sgd' else 1e-3
+    num_blocks = len(net.res_blocks)
+    orc = LifterTrainOracle(sd, lr=lr, num_blocks=num_blocks, leaky=leaky, optim=optim)
+    tr = LifterTrainStep(net, lr=lr, **optim)
+    g = torch.Generator().manual_seed(5)
+    for i in range(3):
+        x, y = torch.randn(37, 10, generator=g), torch.randn(37, 12, generator=g)
+        want = orc.step(x, y)
+        loss = tr.step(x.cuda(), y.cuda())
+        assert abs(float(loss.item()) - want) < 5e-5 * abs(want), (i, float(loss.item()), want)
+        if i == 0:
+            named = dict(net.named_parameters())
+            for k, gv in orc.grads().items():
+                if _is_dead_bias(k):
+                    continue
+                np.testing.assert_allclose(named[k].grad.cpu().numpy(), gv.numpy(), rtol=0,
+                                           atol=2e-5 * max(1.0, float(gv.abs().max())), err_msg=k)
+    got = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    for k in orc.param_keys:
+        tol = (3.5 * lr if _is_dead_bias(k) and optim['optim_type'] == 'adam' else 5e-5)
+        np.testing.assert_allclose(got[k].numpy(), orc.sd[k].detach().numpy(), rtol=0, atol=tol, err_msg=k)
+
+
 def test_lifter_gradients_full_size_vs_oracle():
     cfg = configs.w48_config()
     cfg['FCModel']['dropout'] = 0.0

@@ -116,6 +116,48 @@ def test_heatmap_head_vs_oracle():
     assert cos > 0.9999 and gl2 < 1e-2 and med < 5e-3, (gl2, cos, med)
 
 
+@pytest.mark.parametrize('hm_type,coor_type,optim', [
+    ('sl1', 'mse', dict(optim_type='sgd', momentum=0.9, weight_decay=1e-3)),
+    ('l1', 'sl1', dict(optim_type='adam', weight_decay=1e-2)),
+    ('mse', 'l1', dict(optim_type='sgd', momentum=0.0, weight_decay=0.0)),
+])
+def test_loss_criteria_and_optimizers_of_the_config_system_vs_oracle(hm_type, coor_type, optim):
+    """loss_dict (function.py:17-20) for the heat-map and coordinate terms, torch.optim.SGD(momentum,
+    weight_decay) / Adam(weight_decay) (optimizer.py:8-40): first-step loss and gradients, and the
+    parameters after TWO updates (the second SGD step reads the momentum buffer), against the CPU oracle."""
+    cfg = configs.tiny_config('coordinates')
+    net, sd = _tiny_model(cfg, seed=11)
+    gen = torch.Generator().manual_seed(4)
+    xs = [synth.synth_crops(3, 3, 64, 64, seed=20 + i) for i in range(2)]
+    tg = [torch.rand(3, 5, 16, 16, generator=gen) * 3 for _ in range(2)]       # |d| > 1 occurs: both sl1 branches
+    jt = [torch.rand(3, 5, 2, generator=gen) * 64 for _ in range(2)]
+    lr = 1e-2 if optim['optim_type'] == 'sgd' else 1e-3
+    orc = HRNetTrainOracle(sd, cfg, lr=lr, cr=dict(hm_type=hm_type, coor_type=coor_type), optim=optim)
+    tr = HRNetTrainStep(net, lr=lr, hm_type=hm_type, coor_type=coor_type, **optim)
+    tr.allow_wino = False
+    want, _, _ = orc.step(xs[0], tg[0], jt[0], update=False)
+    loss = tr.step(xs[0].cuda(), tg[0].cuda(), jt[0], update=False)
+    assert abs(float(loss.item()) - want) < 2e-5 * abs(want)
+    gl2, cos, med = gradient_agreement(dict(net.named_parameters()), orc.grads())
+    assert cos > 0.9999 and gl2 < 1e-2 and med < 5e-3, (gl2, cos, med)
+    for i in range(2):
+        orc.step(xs[i], tg[i], jt[i])
+        tr.step(xs[i].cuda(), tg[i].cuda(), jt[i])
+    named = dict(net.named_parameters())
+    # the two updates themselves (a ReLU tie resolved the other way moves the gradients below it by ~1e-2
+    # relative, tests/train_checks.py -- the bounds are those of the gradient checks above)
+    un = np.concatenate([(named[k].detach().cpu() - sd[k]).numpy().ravel() for k in orc.param_keys]).astype(np.float64)
+    uo = np.concatenate([(orc.sd[k].detach() - sd[k]).numpy().ravel() for k in orc.param_keys]).astype(np.float64)
+    if optim['optim_type'] == 'sgd':           # linear in the gradients (+ momentum, weight decay)
+        rel = np.linalg.norm(un - uo) / np.linalg.norm(uo)
+        cosu = float(un @ uo / (np.linalg.norm(un) * np.linalg.norm(uo)))
+        assert rel < 2e-2 and cosu > 0.9998, (rel, cosu)
+    else:                                       # Adam: +-lr per step where a gradient is numerically zero
+        d = np.abs(un - uo)
+        assert np.median(d) < 5e-5 and d.max() <= 2.1 * 2 * lr and np.mean(d > lr) < 0.05, \
+            (float(np.median(d)), float(d.max()), float(np.mean(d > lr)))
+
+
 def test_step_with_winograd_forward_and_data_gradient_convs_vs_oracle(monkeypatch):
     """48/96/192/384-channel topology (the widths of W48, one block per branch, 64 x 64 input): with
     EGONET_AMD_WINO=1 every 3x3 stride-1 forward AND data-gradient convolution runs on the fused

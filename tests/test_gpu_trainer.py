@@ -138,7 +138,11 @@ def test_train_runs_the_hc_loop_with_metric_callback_and_snapshot(tmp_path):
     step = trainer.make_step(net33, cfg3)
     assert step.w_cr == 0.01 and step.cr_loss_thres == 0.1 and step.cr_idx.shape == (12, 4)
     assert step.apply_cr_loss is False                               # the trainer switches it on in epoch 2
-    cfg2['heatmapModel']['loss_spec_list'] = ['sl1', 'l1', 'None']
+    cfg2['heatmapModel']['loss_spec_list'] = ['sl1', 'mse', 'None']       # any pair of loss_dict (function.py:17-20)
+    cfg2['heatmapModel']['loss_weight_list'] = [1.0, 0.1, 'None']
+    step2 = trainer.make_step(net, cfg2)
+    assert (step2.hm_crit, step2.coor_crit) == (2, 0)
+    cfg2['heatmapModel']['loss_spec_list'] = ['huber', 'l1', 'None']
     with pytest.raises(NotImplementedError):
         trainer.make_step(net, cfg2)
 
