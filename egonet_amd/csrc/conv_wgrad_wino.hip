@@ -87,12 +87,23 @@ struct WgwSel {
   float sr, tr, sc;
 };
 
-template <int TW, int TNB, int ABL>
+template <int TW, int TNB, int ABL, int S0, int S1>
 __device__ __forceinline__ void wgw_ksteps(const float* __restrict__ sp, int hb, int db, const WgwSel& w, int lane,
                                            int tile, f32x4 (&acc)[2][3][3]) {
   using G = WgwGeom<TW, TNB>;
+  // the ten read bases of the stage (patch rows x columns, dy rows x columns): everything else is an
+  // immediate offset of the ds_read
+  const float* px[2][3];
+  const float* pe[2][2];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
+  for (int r = 0; r < 2; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) px[r][c] = sp + (hb + w.hro[r] + w.hco[c]);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) pe[r][c] = sp + (db + w.ero[r] + w.eco[c]);
+  }
+#pragma unroll
+  for (int s = S0; s < S1; ++s) {
     // K step s: tile row s >> 1; the left / right half of the 16-wide tile, or image s & 1 of the pair
     const int ho = (TNB == 2 ? (s & 1) * G::HPI : 8 * (s & 1)) * G::PXD + 2 * (s >> 1) * G::HW * G::PXD;
     const int eo = (TNB == 2 ? (s & 1) * G::DPI : 8 * (s & 1)) * G::PXD + 2 * (s >> 1) * TW * G::PXD;
@@ -103,14 +114,14 @@ __device__ __forceinline__ void wgw_ksteps(const float* __restrict__ sp, int hb,
       for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-          d[r][c][j] = (ABL & 2) ? (float)(lane + r + c + j + tile) : sp[hb + w.hro[r] + w.hco[c] + ho + 16 * j];
+          d[r][c][j] = (ABL & 2) ? (float)(lane + r + c + j + tile) : px[r][c][ho + 16 * j];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-          e[r][c][j] = (ABL & 2) ? (float)(lane - r + c + j + s) : sp[db + w.ero[r] + w.eco[c] + eo + 16 * j];
+          e[r][c][j] = (ABL & 2) ? (float)(lane - r + c + j + s) : pe[r][c][eo + 16 * j];
     float T[3][3], V[2][3], R[2][3], M[2][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -265,15 +276,17 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino_kernel(WgradArgs a) {
     __builtin_amdgcn_s_barrier();        // everyone's have; everyone is done reading the other stage
     asm volatile("" ::: "memory");
     WGW_CLK()
+    const float* sp = sm + par * (G::STAGE * 4);
+    // the first K step goes out before the next stage's DMA is computed and issued: the matrix pipe
+    // has work while the offsets are formed (all waves pass the barrier together)
+    wgw_ksteps<TW, TNB, ABL, 0, 1>(sp, hb, db, sel, lane, tile, acc);
     if (!(ABL & 1) && tile + 1 < t_end) {
       WGW_OFFS(tile + 1, off)
 #pragma unroll
       for (int k = 0; k < IT; ++k) WGW_ISSUE(k, par ^ 1, off)
     }
-    asm volatile("" ::: "memory");       // the stage's LDS reads stay below the DMA issue
-    __builtin_amdgcn_sched_barrier(0);
-    const float* sp = sm + par * (G::STAGE * 4);
-    wgw_ksteps<TW, TNB, ABL>(sp, hb, db, sel, lane, tile, acc);
+    asm volatile("" ::: "memory");       // the remaining LDS reads stay below the DMA issue
+    wgw_ksteps<TW, TNB, ABL, 1, 8>(sp, hb, db, sel, lane, tile, acc);
     par ^= 1;
     WGW_CLK()
   }
@@ -311,7 +324,8 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino_kernel(WgradArgs a) {
     }
   __syncthreads();
   WGW_CLK()
-  for (int item = wave; item < 81; item += 8) {
+  // 81 items, wave w takes w, w + 8, ...: two at a time so that the LDS round trips overlap
+  auto item_sum = [&](int item) -> f32x4 {
     const int tap = item / 9, e = item - tap * 9;
     const int ta = tap / 3, tb = tap - ta * 3;
     f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -325,8 +339,15 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino_kernel(WgradArgs a) {
         s += g * (tb == 1 ? v0 - v1 : v0 + v1);
       }
     }
-    slab[(tap * 9 + e) * 64] = s;
+    return s;
+  };
+  int item = wave;
+  for (; item + 8 < 81; item += 16) {
+    const f32x4 s0 = item_sum(item), s1 = item_sum(item + 8);
+    slab[item * 64] = s0;
+    slab[(item + 8) * 64] = s1;
   }
+  if (item < 81) slab[item * 64] = item_sum(item);
   if constexpr ((ABL & 32) != 0) {
     __syncthreads();
     WGW_CLK()
