@@ -221,62 +221,64 @@ def train(train_dataset, model, loss_func, optim, sche, cfgs, logger, metric_fun
     dev = step.dev
     x_buffer, y_buffer = [], []
     frozen = False
-    for epoch in range(1, total_epochs + 1):
-        if epoch > 1 and is_hc:
-            step.apply_cr_loss = True                       # trainer.py:168-169: L_cr from the second epoch on
-        model.train()
-        if sche is not None:
-            sche.step()                                     # trainer.py:177, before the epoch like the reference
-        if optim is not None:
-            step.lr = optim.param_groups[0]['lr']
-        loader = get_loader(train_dataset, cfgs, 'training', collate_fn)
-        total_batches, t_epoch = len(loader), time.time()
-        acc = _Acc()
-        for batch_idx, (data, target, weights, meta) in enumerate(loader):
-            data = data.to(dev, non_blocking=True)
-            target = target.to(dev, non_blocking=True)
-            if is_hc:
-                joints = meta['transformed_joints'] if step.w_coor else None
-                loss = step.step(data, target, joints)
-                prediction = (step.last_maps, step.last_coords) if step.last_coords is not None else step.last_maps
-            else:
-                loss = step.step(data, target)
-                prediction = None
-            # the optional metric runs on EVERY batch and accumulates, like the reference
-            # (trainer.py:200-205); its decode is on the device, its result is a host number
-            if metric_func is not None and prediction is not None:
-                avg_acc, cnt, others = metric_func(prediction, meta, cfgs)
-                acc.update(avg_acc, n=cnt, others=others)
-            if not frozen:
-                # everything built so far (model, datasets, the step's packed filters, torch's module
-                # tables: millions of objects) moves to the permanent generation: the full collections
-                # the per-iteration Python objects trigger every ~10 iterations then take < 1 ms
-                # instead of 35 ms of a host that has 1 500 launches per iteration to issue
-                gc.collect()
-                gc.freeze()
-                frozen = True
-            if batch_idx % report_every == 0:               # loss read-back only here
-                lv = float(loss.item())
-                logger.info('Epoch: [%d][%d/%d]  loss %.6f  lr %.2e  %.1f samples/s' % (
-                    epoch, batch_idx, total_batches, lv, step.lr,
-                    (batch_idx + 1) * data.size(0) / max(time.time() - t_epoch, 1e-9)))
-                if acc.count:
-                    logger.info('          metric %.6f (running mean over %d)' % (acc.avg, acc.count))
-                x_buffer.append(total_batches * (epoch - 1) + batch_idx)
-                y_buffer.append(lv)
-            if eval_during and epoch > eval_start and batch_idx and eval_every and batch_idx % eval_every == 0:
-                parallel.broadcast_buffers(model, src=0)    # running statistics follow rank 0 (DataParallel semantics)
-                evaluate_fn(valid_dataset, model, epoch)
-                model.train()
-        if epoch in ts.get('snapshot_epochs', []):
-            parallel.broadcast_buffers(model, src=0)
-            out_dir = cfgs.get('dirs', {}).get('output', '.')
-            path = os.path.join(out_dir, '%s_%d.pth' % (cfgs.get('exp_type', 'model'), epoch))
-            logger.info('=> Snapshot model to {}'.format(path))
-            inner = model.module if hasattr(model, 'module') else model
-            torch.save(inner.state_dict(), path)
-    if frozen:
-        gc.unfreeze()
+    try:
+        for epoch in range(1, total_epochs + 1):
+            if epoch > 1 and is_hc:
+                step.apply_cr_loss = True                       # trainer.py:168-169: L_cr from the second epoch on
+            model.train()
+            if sche is not None:
+                sche.step()                                     # trainer.py:177, before the epoch like the reference
+            if optim is not None:
+                step.lr = optim.param_groups[0]['lr']
+            loader = get_loader(train_dataset, cfgs, 'training', collate_fn)
+            total_batches, t_epoch = len(loader), time.time()
+            acc = _Acc()
+            for batch_idx, (data, target, weights, meta) in enumerate(loader):
+                data = data.to(dev, non_blocking=True)
+                target = target.to(dev, non_blocking=True)
+                if is_hc:
+                    joints = meta['transformed_joints'] if step.w_coor else None
+                    loss = step.step(data, target, joints)
+                    prediction = (step.last_maps, step.last_coords) if step.last_coords is not None else step.last_maps
+                else:
+                    loss = step.step(data, target)
+                    prediction = None
+                # the optional metric runs on EVERY batch and accumulates, like the reference
+                # (trainer.py:200-205); its decode is on the device, its result is a host number
+                if metric_func is not None and prediction is not None:
+                    avg_acc, cnt, others = metric_func(prediction, meta, cfgs)
+                    acc.update(avg_acc, n=cnt, others=others)
+                if not frozen:
+                    # everything built so far (model, datasets, the step's packed filters, torch's module
+                    # tables: millions of objects) moves to the permanent generation: the full collections
+                    # the per-iteration Python objects trigger every ~10 iterations then take < 1 ms
+                    # instead of 35 ms of a host that has 1 500 launches per iteration to issue
+                    gc.collect()
+                    gc.freeze()
+                    frozen = True
+                if batch_idx % report_every == 0:               # loss read-back only here
+                    lv = float(loss.item())
+                    logger.info('Epoch: [%d][%d/%d]  loss %.6f  lr %.2e  %.1f samples/s' % (
+                        epoch, batch_idx, total_batches, lv, step.lr,
+                        (batch_idx + 1) * data.size(0) / max(time.time() - t_epoch, 1e-9)))
+                    if acc.count:
+                        logger.info('          metric %.6f (running mean over %d)' % (acc.avg, acc.count))
+                    x_buffer.append(total_batches * (epoch - 1) + batch_idx)
+                    y_buffer.append(lv)
+                if eval_during and epoch > eval_start and batch_idx and eval_every and batch_idx % eval_every == 0:
+                    parallel.broadcast_buffers(model, src=0)    # running statistics follow rank 0 (DataParallel semantics)
+                    evaluate_fn(valid_dataset, model, epoch)
+                    model.train()
+            if epoch in ts.get('snapshot_epochs', []):
+                parallel.broadcast_buffers(model, src=0)
+                out_dir = cfgs.get('dirs', {}).get('output', '.')
+                path = os.path.join(out_dir, '%s_%d.pth' % (cfgs.get('exp_type', 'model'), epoch))
+                logger.info('=> Snapshot model to {}'.format(path))
+                inner = model.module if hasattr(model, 'module') else model
+                torch.save(inner.state_dict(), path)
+    finally:
+        if frozen:
+            gc.unfreeze()
     logger.info('Training finished.')
     return {'model': model, 'batch_idx': x_buffer, 'loss': y_buffer}
 
