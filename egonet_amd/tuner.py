@@ -148,10 +148,10 @@ def choose(device, args, allow_wino=False):
     tab = _load()
     if key in tab:
         return _pick(tab[key], allow_wino)
+    if not autotune_enabled():
+        return 0               # deterministic: the shipped table or the cost model, whatever was tuned earlier
     if key in _tuned_here:
         return _pick(_tuned_here[key], allow_wino)
-    if not autotune_enabled():
-        return 0
     cfg, times = tune(device, args)
     _tuned_here[key] = {'cfg': cfg, 'ms': {str(k): round(v, 5) for k, v in times.items()}}
     return _pick(_tuned_here[key], allow_wino)

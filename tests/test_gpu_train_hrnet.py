@@ -67,14 +67,16 @@ def test_first_step_gradients_vs_reference():
 
 
 @pytest.mark.parametrize('wino', [False, True])
-def test_two_steps_vs_reference(wino):
+def test_two_steps_vs_reference(wino, monkeypatch):
     """Two optimisation steps against the reference's fixture.  wino=False pins the direct kernels (tight
-    bounds); wino=True lets the tuner put eligible layers (32-multiple widths) on the Winograd kernels:
+    bounds); wino=True (EGONET_AMD_WINO=1) puts every eligible layer (32-multiple widths) on the Winograd kernels:
     the first step agrees as tightly, after it Adam's scale-free update turns the sign of gradients that
     are numerically zero into +-lr moves, so the second loss is only bounded to 2e-3."""
     g = golden('hrnet_train.npz')
     cfg = fixture_cfg(g)
     net, _ = _tiny_model(cfg)
+    if wino:
+        monkeypatch.setenv('EGONET_AMD_WINO', '1')
     tr = HRNetTrainStep(net, lr=1e-3)
     tr.allow_wino = wino
     losses = []
@@ -88,13 +90,17 @@ def test_two_steps_vs_reference(wino):
     # after two Adam steps every entry has moved by ~2e-3 (lr * m/sqrt(v) is scale free):
     # agreement to a few 1e-6 is the rule; an entry whose two gradients nearly cancel
     # amplifies a ReLU-tie difference (tests/train_checks.py) -- those are bounded in number
-    for k in json.loads(str(g['keys'])):
-        d = np.abs(fin[k] - g['p2/' + k])
-        assert np.median(d) < (5e-5 if wino else 5e-6) and np.mean(d > 5e-4) < (0.1 if wino else 0.02), \
-            (k, float(np.median(d)), float(np.mean(d > 5e-4)))
+    ds = [np.abs(fin[k] - g['p2/' + k]).ravel() for k in json.loads(str(g['keys']))]
+    if wino:        # over all sampled tensors together (small tensors scatter: a dozen flipped +-lr entries of 66)
+        d = np.concatenate(ds)
+        assert np.median(d) < 2e-4 and np.mean(d > 5e-4) < 0.1, (float(np.median(d)), float(np.mean(d > 5e-4)))
+    else:
+        for k, d in zip(json.loads(str(g['keys'])), ds):
+            assert np.median(d) < 5e-6 and np.mean(d > 5e-4) < 0.02, (k, float(np.median(d)), float(np.mean(d > 5e-4)))
     for k in ('bn1.running_mean', 'bn1.running_var', 'stage3.0.branches.2.0.bn1.running_var',
               'head2.1.bn2.running_mean'):
-        np.testing.assert_allclose(fin[k], g['p2/' + k], rtol=1e-3, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(fin[k], g['p2/' + k], rtol=5e-3 if wino else 1e-3, atol=5e-4 if wino else 1e-5,
+                                   err_msg=k)
     assert int(fin['bn1.num_batches_tracked']) == 2
 
 
