@@ -58,6 +58,13 @@ class LifterTrainStep(object):
         # parameters / gradients / Adam moments as views of flat buffers: one Adam launch,
         # one all-reduce buffer, step counter and lr on the device (hipGraph-safe)
         self.flat = FlatParams(model.parameters())
+        # every Linear weight as a 1x1 conv filter [out, in, 1, 1] (views of the flat buffer): from the second
+        # step on all forward / data-gradient packs of the iteration are ONE launch (train_hrnet.PackedFilters)
+        from .train_hrnet import PackedFilters
+        self.packs = PackedFilters(p0.device)
+        self.w4 = {}
+        for fc in [u.fc for u in self.units] + [self.final]:
+            self.w4[id(fc.weight)] = fc.weight.detach().view(fc.out_features, fc.in_features, 1, 1)
         self.params = self.flat.params
         self.grads = {id(p): p.grad for p in self.params}
         self._ws = {}
@@ -92,10 +99,16 @@ class LifterTrainStep(object):
         w_src (row-major, ld_w) directly (transpose_w=0) or transposed (1)."""
         L = self.L
         coutp = _round_up(cout, 16)
-        nchunk = (k + 15) // 16
-        wp = self._buf('wp' + tagk, nchunk * 4 * coutp * 4)
-        _lib.check(L.egn_pack_matrix_f32(_lib.ptr(w_src), ld_w, cout, k, transpose_w, _lib.ptr(wp), self._st()),
-                   'pack')
+        w4 = self.w4.get(id(w_src))
+        if w4 is not None and ld_w == w4.shape[1]:
+            # a Linear weight: the 1x1-conv pack (dgrad = the transposed use) -- the same layout as
+            # egn_pack_matrix_f32, packed with all the others in one launch once the set is known
+            wp = self.packs.get(w4, transpose_w, self._st())
+        else:
+            nchunk = (k + 15) // 16
+            wp = self._buf('wp' + tagk, nchunk * 4 * coutp * 4)
+            _lib.check(L.egn_pack_matrix_f32(_lib.ptr(w_src), ld_w, cout, k, transpose_w, _lib.ptr(wp), self._st()),
+                       'pack')
         sc = self.ones
         if shift is None:
             sh = self.zeros
@@ -170,6 +183,7 @@ class LifterTrainStep(object):
         keep = 1.0 / (1.0 - self.p) if self.p > 0 else 1.0
 
         with torch.cuda.device(dev):
+            self.packs.pack_all(st)           # every filter of the iteration, one launch (from the second step on)
             # input rows padded to a multiple of 4 floats
             ld0 = _round_up(self.units[0].inf, 4)
             a = self._buf('a0', B, ld0)
@@ -268,6 +282,7 @@ class LifterTrainStep(object):
                 self.grad_sync(self.flat.grad)
             if update:
                 self.flat.update(self, st)
+            self.packs.finalize()             # first step: the set of filters is known now
             # weights and BatchNorm buffers were written through raw pointers: eval-mode forwards
             # between steps (eval_during, EgoNet.L after fine-tuning) must re-fold them
             invalidate(self.model)

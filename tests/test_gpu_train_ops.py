@@ -54,6 +54,24 @@ def test_pack_matrix_feeds_the_conv_kernel(cout, cin, transpose):
     np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=0, atol=1e-5 * max(1.0, float(want.abs().max())))
 
 
+@pytest.mark.parametrize('cout,cin', [(1024, 66), (96, 1024), (12, 10)])
+def test_linear_weight_as_1x1_filter_packs_like_pack_matrix(cout, cin):
+    """The lifter step packs its Linear weights with the conv filter packer (one batched launch per step):
+    same bits as egn_pack_matrix_f32 for the forward (dgrad 0) and the transposed (dgrad 1) use."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(cout + cin)
+    w = torch.randn(cout, cin, generator=g).cuda()
+    for dgrad in (0, 1):
+        n_out, n_in = (cin, cout) if dgrad else (cout, cin)
+        nfl = L.egn_packed_weight_floats(cout, cin, 1, 1, dgrad)
+        assert nfl == ((n_in + 15) // 16) * 4 * ((n_out + 15) // 16 * 16) * 4
+        a = torch.full((nfl,), 7.0, device='cuda')
+        b = torch.full((nfl,), 9.0, device='cuda')
+        _lib.check(L.egn_pack_conv_weight_f32(_lib.ptr(w), cout, cin, 1, 1, dgrad, _lib.ptr(a), _st()))
+        _lib.check(L.egn_pack_matrix_f32(_lib.ptr(w), cin, n_out, n_in, dgrad, _lib.ptr(b), _st()))
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize('rows,cols', [(4, 12), (16, 128), (250, 96), (4096, 1024)])
 def test_column_reductions(rows, cols):
     L = _lib.lib()
