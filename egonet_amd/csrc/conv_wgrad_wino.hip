@@ -2,7 +2,7 @@
 // form on the fp32 matrix pipe.
 //
 // Reference: the backward of nn.Conv2d inside the training hot loop (libs/trainer/trainer.py:183-209,
-// loss.backward()) for the BasicBlock convs of libs/model/heatmapModel/hrnet.py:68-92 -- 257 of the 306
+// loss.backward()) for the BasicBlock convs of libs/model/heatmapModel/hrnet.py:68-92 -- 232 of the 306
 // weight gradients of HRNet-W48, 5.4 GFLOP each at 32 crops, the largest block of the training step
 // (profiles/: 16.5 ms of 67 ms of kernels with the direct kernel of conv_wgrad.hip at 52 % of the fp32 peak).
 //
@@ -27,7 +27,7 @@
 //     + 8 pad): the four tiles of a K step are two pixels = 112 = 48 mod 64 dwords apart, so the 64 lanes
 //     of a ds_read_b32 fall into four disjoint 16-bank windows -- conflict free.  Filled by LDS-DMA
 //     (buffer_load_dwordx4 ... lds; zero padding = out-of-range lanes), double buffered, one barrier per
-//     stage, the next stage's DMA issued right after it.
+//     stage, the next stage's DMA issued behind the stage's first K step.
 //   * epilogue: dg = G^T dU G.  A wave folds its two columns into the two distinct column values the
 //     three tap columns need, parks them in LDS (one round, 147 KB), and the (tap, element) sums over the
 //     eight waves -- fixed order, coefficients G[i][tap row] = +-{0, 1/2, 1} -- are spread over the waves;
