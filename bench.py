@@ -36,6 +36,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import re
 import sys
 import time
 
@@ -79,12 +80,22 @@ def build_model(head, device):
     return cfg, ego.eval().to(device), hc_sd, l_sd
 
 
-def _symbol(cfg):
+def _symbol(cfg, cout=None):
+    """Kernel symbol of a tile configuration as rocprofv3 prints it (egn_conv_config_name); the 8-wave
+    Winograd kernel is built per co-tile width: NT = 3 (Cout % 48 == 0) or 2."""
     from egonet_amd import _lib
     buf = C.create_string_buffer(128)
     if cfg and _lib.lib().egn_conv_config_name(cfg, buf, 128) == 0:
-        return buf.value.decode()
+        sym = buf.value.decode()
+        if cout is not None and cout % 48 and 'conv_wino8_kernel' in sym:
+            sym = sym.replace(', 3>(', ', 2>(')
+        return sym
     return None
+
+
+def _klass_cout(klass):
+    m = re.search(r'->(\d+)@', klass or '')
+    return int(m.group(1)) if m else None
 
 
 def kernel_tables(prog, ms):
@@ -93,7 +104,8 @@ def kernel_tables(prog, ms):
     for meta, t in zip(prog.meta, ms):
         if meta['kind'] in ('fork', 'join'):
             continue
-        sym = _symbol(meta.get('cfg', 0)) if meta['kind'] == 'conv' else meta['kind'] + '_kernel'
+        sym = _symbol(meta.get('cfg', 0), _klass_cout(meta.get('klass'))) if meta['kind'] == 'conv' \
+            else meta['kind'] + '_kernel'
         for table, key in ((by_class, meta['klass']), (by_symbol, sym)):
             a = table.setdefault(key, dict(name=key, kind=meta['kind'], launches=0, ms=0.0, flops=0.0, bytes=0.0))
             a['launches'] += 1

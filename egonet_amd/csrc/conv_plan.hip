@@ -114,9 +114,11 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (cfg < 1 || cfg > kNumConfigs || !buf || len < 8) return EGN_E_BADARG;
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 5)
-    if ((c.bi & 15) == 4) snprintf(buf, len, "void conv_wino8_kernel<8, 8, 2, 0, 4>(ConvArgs)");
-    else if ((c.bi & 15) == 5) snprintf(buf, len, "void conv_wino8_kernel<8, 16, 1, 0, 4>(ConvArgs)");
-    else if (c.bi & 2) snprintf(buf, len, "void conv_wino8_kernel<%s, %d, 8>(ConvArgs)", (c.bi & 1) ? "8, 8, 4" : "16, 16, 1", c.bi >> 4);
+    // conv_wino8_kernel<TH, TW, TNB, ABL, NW, NT>: the symbol of the 48-channel co-tile build (NT = 3: the W48
+    // widths); layers with Cout % 48 != 0 run the NT = 2 build of the same kernel
+    if ((c.bi & 15) == 4) snprintf(buf, len, "void conv_wino8_kernel<8, 8, 2, 0, 4, 3>(ConvArgs)");
+    else if ((c.bi & 15) == 5) snprintf(buf, len, "void conv_wino8_kernel<8, 16, 1, 0, 4, 3>(ConvArgs)");
+    else if (c.bi & 2) snprintf(buf, len, "void conv_wino8_kernel<%s, %d, 8, 3>(ConvArgs)", (c.bi & 1) ? "8, 8, 4" : "16, 16, 1", c.bi >> 4);
     else snprintf(buf, len, "void conv_wino_kernel<%s, %d>(ConvArgs)", (c.bi & 1) ? "8, 8, 4" : "16, 16, 1", c.bi >> 4);
   else if (c.dma == 4 && c.bi == 2)
     snprintf(buf, len, "conv_c48t_kernel(ConvArgs)");
