@@ -226,7 +226,12 @@ int egn_crop_warp_normalize_u8(const uint8_t* img, int H, int W, int pitch,
  * x [N,H,W,cs_in], dy [N,Ho,Wo,cs_out] NHWC fp32 (pad channels zero), dw in
  * torch's [Cout][Cin][KH][KW] layout.  Split-K over pixel tiles with a
  * deterministic two-pass reduction; ws = scratch of egn_conv2d_wgrad_ws_bytes().
- * KH*KW in {1, 9, 16}.  A Linear is N = rows, H = W = 1. */
+ * KH*KW in {1, 9, 16}.  A Linear is N = rows, H = W = 1.
+ * 3x3 / stride 1 / pad 1 layers with Cin % 48 == 0, Cout % 48 == 0 and unpadded
+ * channel strides run in Winograd F(2x2,3x3) form (csrc/conv_wgrad_wino.hip: same
+ * result to fp32 rounding -- error vs float64 4e-7 of the largest tap, the direct
+ * kernel's 3e-7 -- not bit-identical; the environment switch EGN_WGRAD_WINO=0
+ * keeps the direct kernel).  Either way two launches give the same bits. */
 long egn_conv2d_wgrad_ws_bytes(int N, int H, int W, int Cin, int cs_in, int Cout,
                                int cs_out, int KH, int KW, int stride, int pad);
 int egn_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int H,
