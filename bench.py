@@ -48,13 +48,15 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_HBM_GBPS = 8000.0
-TRAFFIC_JSON = os.path.join(ROOT, 'profiles', 'r2_pmc_traffic.json')
+# committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_r3.sh + tools/pmc_traffic.py), newest first
+TRAFFIC_JSONS = [os.path.join(ROOT, 'profiles', n) for n in ('r3_pmc_traffic.json', 'r2_pmc_traffic.json')]
+WINO_EXECUTED = 16.0 / 36.0       # fused Winograd F(2x2,3x3): multiplies executed per direct-algorithm multiply
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
-    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--steps', type=int, default=50)
     p.add_argument('--warmup', type=int, default=5)
     p.add_argument('--batch', type=int, default=64, help='crops per GPU per step')
     p.add_argument('--head', default='heatmap', choices=['heatmap', 'coordinates'])
@@ -64,6 +66,9 @@ def parse():
     p.add_argument('--no-train', action='store_true', help='skip the training blocks (configs 3 and 4)')
     p.add_argument('--train-batch', type=int, default=32, help='crops per GPU of the train_hc block')
     p.add_argument('--lifter-batch', type=int, default=4096)
+    p.add_argument('--dry-run', action='store_true',
+                   help='launcher / rendezvous / timing-reduction plumbing only (no GPU work): what the CPU test of '
+                        '`--gpus N` runs with EGONET_AMD_DIST_BACKEND=gloo')
     return p.parse_args()
 
 
@@ -98,19 +103,30 @@ def _klass_cout(klass):
     return int(m.group(1)) if m else None
 
 
+def _is_wino(cfg):
+    from egonet_amd import _lib
+    return bool(cfg) and cfg > 0 and _lib.lib().egn_conv_config_kind(cfg) == 1
+
+
 def kernel_tables(prog, ms):
-    """Aggregate per-op hipEvent durations (a) by shape class, (b) by kernel symbol."""
+    """Aggregate per-op hipEvent durations (a) by shape class, (b) by kernel symbol.  `flops` are the
+    ALGORITHMIC (direct-convolution, 2*MAC) flops of SURVEY 8(d); `xflops` the flops the kernel EXECUTES on
+    the matrix pipe -- 16/36 of them for the fused Winograd F(2x2,3x3) kernels."""
     by_class, by_symbol = {}, {}
     for meta, t in zip(prog.meta, ms):
         if meta['kind'] in ('fork', 'join'):
             continue
-        sym = _symbol(meta.get('cfg', 0), _klass_cout(meta.get('klass'))) if meta['kind'] == 'conv' \
+        cfg = meta.get('cfg', 0)
+        sym = _symbol(cfg, _klass_cout(meta.get('klass'))) if meta['kind'] == 'conv' \
             else meta['kind'] + '_kernel'
+        ex = meta['flops'] * (WINO_EXECUTED if meta['kind'] == 'conv' and _is_wino(cfg) else 1.0)
         for table, key in ((by_class, meta['klass']), (by_symbol, sym)):
-            a = table.setdefault(key, dict(name=key, kind=meta['kind'], launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            a = table.setdefault(key, dict(name=key, kind=meta['kind'], launches=0, ms=0.0, flops=0.0, xflops=0.0,
+                                           bytes=0.0))
             a['launches'] += 1
             a['ms'] += float(t)
             a['flops'] += meta['flops']
+            a['xflops'] += ex
             a['bytes'] += meta['bytes']
     out = []
     for table in (by_class, by_symbol):
@@ -119,6 +135,7 @@ def kernel_tables(prog, ms):
         for a in rows:
             a['share'] = a['ms'] / total if total else 0.0
             a['tflops'] = a['flops'] / (a['ms'] * 1e-3) / 1e12 if a['ms'] else 0.0
+            a['executed_tflops'] = a['xflops'] / (a['ms'] * 1e-3) / 1e12 if a['ms'] else 0.0
             a['gbps'] = a['bytes'] / (a['ms'] * 1e-3) / 1e9 if a['ms'] else 0.0
             a['avg_us'] = a['ms'] * 1e3 / a['launches']
         out.append((rows, total))
@@ -126,15 +143,36 @@ def kernel_tables(prog, ms):
 
 
 def measured_traffic(symbol):
-    """HBM bytes per launch of `symbol` from the committed PMC passes (see
-    profiles/README.md: FETCH_SIZE and WRITE_SIZE collected in separate
-    rocprofv3 --pmc runs of this benchmark, FETCH_SIZE doubled for gfx950)."""
-    try:
-        with open(TRAFFIC_JSON) as f:
-            t = json.load(f)
-        return t['kernels'][symbol]['hbm_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        return None
+    """(HBM bytes per launch of `symbol`, source file) from the committed PMC passes (profiles/README.md:
+    FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of bench.py / tools/train_hc_bench.py /
+    tools/train_bench.py, FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md prescribes)."""
+    for path in TRAFFIC_JSONS:
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            return t['kernels'][symbol]['hbm_bytes_per_launch'], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
+def mfma_roofline(symbol, direct_tflops, executed_tflops):
+    """The `roofline` object of an MFMA-bound kernel symbol.  `achieved` / `frac` price the flops the kernel
+    EXECUTES on the fp32 matrix pipe against its dense peak (always <= 1: a roofline fraction); for the fused
+    Winograd kernels, which execute 16 of every 36 direct-algorithm multiplies, the algorithmic
+    (direct-convolution) rate is given beside it as `direct_equivalent_*`."""
+    roof = {'bound': 'mfma', 'kernel': symbol, 'achieved': executed_tflops, 'peak': PEAK_FP32_MFMA_TFLOPS,
+            'unit': 'TFLOP/s', 'frac': executed_tflops / PEAK_FP32_MFMA_TFLOPS,
+            'direct_equivalent_tflops': direct_tflops,
+            'direct_equivalent_x_peak': direct_tflops / PEAK_FP32_MFMA_TFLOPS}
+    if abs(direct_tflops - executed_tflops) > 1e-9 * max(direct_tflops, 1.0):
+        roof['algorithm'] = ('fused Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs and (ci,co) instead of 36; '
+                             'achieved = executed flops, direct_equivalent = SURVEY 8(d) algorithmic flops')
+    traffic, src = measured_traffic(symbol)
+    roof['traffic'] = traffic
+    roof['traffic_source'] = None if traffic is None else \
+        src + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed; not re-measured in this run)'
+    return roof
 
 
 def cpu_baseline(cfg, hc_sd, l_sd, stats, head, seconds):
@@ -221,22 +259,22 @@ def _timed(step, steps, warmup, dev, dist):
 
 
 def _dominant(timing):
-    """(symbol, launches, avg_us, tflops, share of the timed launches) of the kernel symbol with the
-    largest total time among the hipEvent-bracketed conv / GEMM launches of one step."""
+    """`roofline` of the kernel symbol with the largest total time among the hipEvent-bracketed conv / GEMM
+    launches of one step (launches, avg_us, share of the timed launches beside it)."""
     torch.cuda.synchronize()
     by = {}
     for cfg, flops, e0, e1 in timing:
-        a = by.setdefault(_symbol(cfg) or 'cfg%d' % cfg, [0, 0.0, 0.0])
+        a = by.setdefault(_symbol(cfg) or 'cfg%d' % cfg, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += e0.elapsed_time(e1)
         a[2] += flops
+        a[3] += flops * (WINO_EXECUTED if _is_wino(cfg) else 1.0)
     total = sum(a[1] for a in by.values())
-    name, (n, ms, fl) = max(by.items(), key=lambda kv: kv[1][1])
-    tf = fl / (ms * 1e-3) / 1e12
-    return {'bound': 'mfma', 'kernel': name, 'achieved': tf, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': tf / PEAK_FP32_MFMA_TFLOPS, 'launches': n, 'avg_us': ms * 1e3 / n,
-            'share_of_conv_time': ms / total if total else 0.0, 'conv_ms_per_step': total,
-            'traffic': None}
+    name, (n, ms, fl, xfl) = max(by.items(), key=lambda kv: kv[1][1])
+    roof = mfma_roofline(name, fl / (ms * 1e-3) / 1e12, xfl / (ms * 1e-3) / 1e12)
+    roof.update(launches=n, avg_us=ms * 1e3 / n, share_of_conv_time=ms / total if total else 0.0,
+                conv_ms_per_step=total, algorithmic_gflop_per_launch=fl / n / 1e9)
+    return roof
 
 
 def train_hc_block(args, world, rank, dev, dist):
@@ -272,8 +310,7 @@ def train_hc_block(args, world, rank, dev, dist):
         out = {'metric': 'hc_train_crops_per_sec', 'value': crops / sec, 'unit': 'crops/s', 'n_gpus': world,
                'steps': args.steps, 'warmup': max(args.warmup, 2), 'ms_per_step': sec * 1e3, 'scaling': 'weak',
                'dtype': 'f32', 'data': 'synthetic', 'loss': float(loss.item()),
-               'algorithmic_tflops_per_gpu': 3 * GFLOP_FWD_PER_CROP * B / sec / 1e3,
-               'frac_of_fp32_peak': 3 * GFLOP_FWD_PER_CROP * B / sec / 1e3 / PEAK_FP32_MFMA_TFLOPS,
+               'direct_equivalent_tflops_per_gpu': 3 * GFLOP_FWD_PER_CROP * B / sec / 1e3,
                'roofline': roof,
                'config': {'workload': 'configs[3]: train_IGRs HRNet-W48 256x256 fwd+bwd+Adam, composite loss '
                                       '(mse + 0.1 l1), batch=%d crops/GPU' % B, 'global_batch': crops,
@@ -346,12 +383,71 @@ def train_lifter_block(args, dev):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: re-execute this script as N ranks, one per
+    device, under torch.distributed.run (backend nccl = RCCL; the reference's tools/train_IGRs.py:59,111 uses
+    every visible GPU from one process instead).  Returns the launcher's exit code."""
+    import subprocess
+    backend = os.environ.get('EGONET_AMD_DIST_BACKEND', 'nccl')
+    if backend == 'nccl' and not args.dry_run:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write('bench.py: --gpus %d but only %d GPU(s) are visible (set EGONET_AMD_DIST_BACKEND=gloo for '
+                             'a control-flow smoke test with every rank on device 0)\n' % (args.gpus, have))
+            return 2
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC (RCCL across processes on this driver)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank):
+    """No GPU work: process group, barrier, max-over-ranks reduction of a host clock, the JSON line."""
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(os.environ.get('EGONET_AMD_DIST_BACKEND', 'gloo'))
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * args.steps)
+    dt = time.perf_counter() - t0
+    ranks = 1
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        ranks = dist.get_world_size()
+    if rank == 0:
+        print(json.dumps({'metric': 'crops/sec (256x256, heatmap+decode+lift)', 'value': 0.0, 'unit': 'crops/s',
+                          'n_gpus': world, 'ranks': ranks, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': dt / args.steps * 1e3, 'dry_run': True}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and rank == 0:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started %d rank(s); reporting n_gpus = %d\n'
+                         % (args.gpus, world, world))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     dist = None
+    backend = 'none'
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -360,6 +456,9 @@ def main():
         backend = os.environ.get('EGONET_AMD_DIST_BACKEND', 'nccl')
         if backend != 'nccl':
             local = 0
+        elif torch.cuda.device_count() <= local:
+            raise RuntimeError('rank %d: LOCAL_RANK %d but only %d GPU(s) visible' % (rank, local,
+                                                                                     torch.cuda.device_count()))
         torch.cuda.set_device(local)
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local))
@@ -422,30 +521,22 @@ def main():
         (rows, total_ms), (syms, _) = kernel_tables(prog, ms)
         dom = syms[0]
         mfma_bound = dom['flops'] > 0 and dom['flops'] / max(dom['bytes'], 1) > 20
-        traffic = measured_traffic(dom['name'])
         if mfma_bound:
-            roof = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': dom['tflops'],
-                    'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': dom['tflops'] / PEAK_FP32_MFMA_TFLOPS}
-            if 'wino' in dom['name']:
-                # `achieved` is priced in ALGORITHMIC flops of the direct convolution (2*MAC), as the
-                # contract asks; the fused Winograd F(2x2,3x3) kernel EXECUTES 16/36 of them on the matrix pipe,
-                # which is how the fraction can exceed 1 -- the executed figures are given beside it
-                roof.update(algorithm='fused Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs and (ci,co) instead of 36',
-                            executed_tflops=dom['tflops'] * 16.0 / 36.0,
-                            executed_frac=dom['tflops'] * 16.0 / 36.0 / PEAK_FP32_MFMA_TFLOPS)
+            roof = mfma_roofline(dom['name'], dom['tflops'], dom['executed_tflops'])
         else:
+            traffic, src = measured_traffic(dom['name'])
             roof = {'bound': 'hbm', 'kernel': dom['name'], 'achieved': dom['gbps'], 'peak': PEAK_HBM_GBPS,
-                    'unit': 'GB/s', 'frac': dom['gbps'] / PEAK_HBM_GBPS}
-        roof.update(traffic=traffic, traffic_source='profiles/r2_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
-                    'this benchmark, committed; not re-measured in this run)' if traffic is not None else None,
-                    launches=dom['launches'], avg_us=dom['avg_us'], time_share=dom['share'],
+                    'unit': 'GB/s', 'frac': dom['gbps'] / PEAK_HBM_GBPS, 'traffic': traffic,
+                    'traffic_source': None if traffic is None else src + ' (committed rocprofv3 --pmc passes)'}
+        roof.update(launches=dom['launches'], avg_us=dom['avg_us'], time_share=dom['share'],
                     algorithmic_gflop_per_launch=dom['flops'] / dom['launches'] / 1e9,
                     algorithmic_mb_per_launch=dom['bytes'] / dom['launches'] / 1e6)
         conv_flops = sum(a['flops'] for a in rows)
+        conv_xflops = sum(a['xflops'] for a in rows)
 
         def slim(a):
             return {k: (round(v, 4) if isinstance(v, float) else v) for k, v in a.items()
-                    if k in ('name', 'launches', 'ms', 'share', 'tflops', 'gbps', 'avg_us')}
+                    if k in ('name', 'launches', 'ms', 'share', 'tflops', 'executed_tflops', 'gbps', 'avg_us')}
         value = world * B * args.steps / dt
         result = {
             'metric': 'crops/sec (256x256, heatmap+decode+lift)', 'value': value, 'unit': 'crops/s',
@@ -456,11 +547,13 @@ def main():
                                    '%s decode + affine + FC lifter + pose solve' % (B, args.head, decode),
                        'global_batch': world * B, 'weights': 'synthetic (egonet_amd.synth, seeded per key)',
                        'parallelism': 'replicas x%d, crops sharded by rank, no collective' % world,
+                       'ranks': dist.get_world_size() if dist else 1, 'backend': backend,
                        'launch_lanes': int(eng.lanes)},
             'roofline': roof,
             'backbone': {'ms_sum_of_kernels': total_ms, 'gflop_per_crop': conv_flops / B / 1e9,
-                         'tflops_overall': conv_flops / (total_ms * 1e-3) / 1e12,
-                         'frac_of_fp32_peak': conv_flops / (total_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                         'direct_equivalent_tflops_overall': conv_flops / (total_ms * 1e-3) / 1e12,
+                         'executed_tflops_overall': conv_xflops / (total_ms * 1e-3) / 1e12,
+                         'executed_frac_of_fp32_peak': conv_xflops / (total_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                          'launches': int(sum(a['launches'] for a in rows)), 'arena_mb': prog.arena_bytes / 2 ** 20,
                          'weights_mb': prog.weight_bytes / 2 ** 20},
             'kernel_symbols': [slim(a) for a in syms[:8]],

@@ -105,6 +105,7 @@ SIGNATURES = {
     'egn_program_capture': (_i, [_p, _p]),
     'egn_program_replay': (_i, [_p, _p]),
     'egn_launch_count': (C.c_long, []),
+    'egn_direct_conv_count': (C.c_long, []),
     'egn_program_op_info': (_i, [_p, _i, C.POINTER(_i), C.POINTER(_d), C.POINTER(_d), C.c_char_p, _i]),
 }
 

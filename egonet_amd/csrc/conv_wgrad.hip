@@ -27,6 +27,8 @@
 #include "egn_internal.h"
 #include "conv_common.h"
 #include "conv_wgrad.h"
+#include <atomic>
+extern std::atomic<long> g_egn_direct_convs;   // program.hip
 
 
 // J = channels per lane and operand (4: 64-wide tiles, ds_read_b128; 3: 48-wide
@@ -434,6 +436,7 @@ extern "C" int egn_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, 
                                     int cs_in, int Cout, int cs_out, int KH, int KW, int stride, int pad, void* ws,
                                     long ws_bytes, void* stream) {
   if (!x || !dy || !dw || !ws) return EGN_E_BADARG;
+  g_egn_direct_convs.fetch_add(1, std::memory_order_relaxed);
   WgradArgs a = {};
   a.x = x; a.dy = dy; a.part = (float*)ws;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.cs_in = cs_in; a.Cout = Cout; a.cs_out = cs_out;

@@ -37,10 +37,17 @@ static int fill_conv_args(ConvArgs& a, const float* x, const float* wpack, const
   return 0;
 }
 
+// convolution-class launches issued through the direct entry points (egn_conv2d_f32,
+// egn_conv2d_bnstats_f32, egn_conv2d_wgrad_f32) since the library was loaded: the training tape and the
+// autograd bridge do not go through programs, this is their "ran on this library's kernels" proof
+std::atomic<long> g_egn_direct_convs{0};
+extern "C" long egn_direct_conv_count(void) { return g_egn_direct_convs.load(std::memory_order_relaxed); }
+
 extern "C" int egn_conv2d_f32(const float* x, const float* wpack, const float* scale, const float* shift,
                               const float* res, float* y, int N, int H, int W, int Cin, int cs_in, int Cout,
                               int cs_out, int KH, int KW, int stride, int pad, int act, int out_nchw,
                               int cfg, void* stream) {
+  g_egn_direct_convs.fetch_add(1, std::memory_order_relaxed);
   ConvArgs a;
   int rc = fill_conv_args(a, x, wpack, scale, shift, res, y, N, H, W, Cin, cs_in, Cout, cs_out, KH, KW,
                           stride, pad, act, out_nchw);
@@ -69,6 +76,7 @@ extern "C" int egn_conv2d_bnstats_f32(const float* x, const float* wpack, const 
                                       float* y, int N, int H, int W, int Cin, int cs_in, int Cout, int cs_out,
                                       int KH, int KW, int stride, int pad, int cfg, double* partials,
                                       long partial_rows, void* stream) {
+  g_egn_direct_convs.fetch_add(1, std::memory_order_relaxed);
   ConvArgs a;
   int rc = fill_conv_args(a, x, wpack, ones, zeros, nullptr, y, N, H, W, Cin, cs_in, Cout, cs_out, KH, KW, stride,
                           pad, EGN_ACT_NONE, 0);

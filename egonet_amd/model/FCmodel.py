@@ -62,10 +62,29 @@ class FCModel(nn.Module):
             nn.init.kaiming_normal_(self.w2.weight.data)
         self._engine = None
 
+    hip_eval = True          # eval-mode CUDA forwards run the HIP program
+
     def _hip_ok(self, x):
-        # eval mode + CUDA input: always the HIP program, whatever the autograd mode
-        # (the reference evaluates with grad enabled, libs/trainer/trainer.py:421)
-        return x.is_cuda and not self.training
+        # eval mode + CUDA input: the HIP program, whatever the autograd mode (the reference evaluates with
+        # grad enabled, libs/trainer/trainer.py:421) -- unless the caller asks for a graph: an input that
+        # requires a gradient, or ``model.hip_eval = False``
+        return x.is_cuda and not self.training and self.hip_eval and not (torch.is_grad_enabled() and x.requires_grad)
+
+    def _native_autograd_ok(self, x):
+        # train mode under autograd (the reference's hot loop, libs/trainer/trainer.py:183-209, unchanged):
+        # one autograd node on the native kernels (egonet_amd.autograd.LifterAutograd)
+        import os
+        return (x.is_cuda and self.training and torch.is_grad_enabled() and not x.requires_grad and x.shape[0] > 1
+                and os.environ.get('EGONET_AMD_AUTOGRAD', '1') != '0'
+                and all(p.requires_grad for p in self.parameters()))
+
+    def _autograd_bridge(self):
+        from egonet_amd import autograd
+        b = self.__dict__.get('_bridge')
+        if b is None or b.model is not self:
+            b = autograd.LifterAutograd(self)
+            self.__dict__['_bridge'] = b
+        return b
 
     def train(self, mode=True):
         if mode:                 # the weights are about to change: drop programs and packed blobs
@@ -85,6 +104,8 @@ class FCModel(nn.Module):
     def forward(self, x):
         if self._hip_ok(x):
             return self._hip_engine().forward(x)
+        if self._native_autograd_ok(x):
+            return self._autograd_bridge()(x)
         return self.w2(self.get_representation(x))
 
     def get_representation(self, x):
@@ -95,6 +116,7 @@ class FCModel(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._engine = None
+        self.__dict__.pop('_bridge', None)
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):

@@ -242,17 +242,43 @@ class PoseHighResolutionNet(nn.Module):
 
     # -- execution ---------------------------------------------------------
     def forward(self, x):
-        """Eval mode + CUDA input: ALWAYS the HIP program, whatever the autograd mode -- the
-        reference's validation loop calls ``model.eval(); model(data)`` with grad enabled
-        (libs/trainer/trainer.py:421) and ``EgoNet.get_keypoints`` has no ``no_grad`` of its own
-        (libs/model/egonet.py:434).  The outputs are plain tensors (inference: no autograd
-        graph).  There is no torch/MIOpen route for an eval-mode CUDA tensor.
-        Training mode: the module graph under torch autograd (the reference's API allows
-        ``model(data)`` + ``loss.backward()``); the native training step of this package
-        (egonet_amd.train_hrnet) does not go through here.  CPU tensors: torch on the CPU."""
-        if x.is_cuda and not self.training:
-            return self._hip_engine().forward(x)
+        """CUDA input: the native HIP kernels, in both modes.
+
+        Eval mode: the recorded inference program, whatever the autograd mode -- the reference's validation
+        loop calls ``model.eval(); model(data)`` with grad enabled (libs/trainer/trainer.py:421) and
+        ``EgoNet.get_keypoints`` has no ``no_grad`` of its own (libs/model/egonet.py:434).  The outputs are
+        plain tensors (no autograd graph); a caller that wants to differentiate an eval-mode forward gives
+        an input with ``requires_grad`` (saliency) or sets ``model.hip_eval = False`` (frozen-BatchNorm
+        fine-tuning through the module graph) and gets the torch graph.
+        Train mode under autograd -- the reference's hot loop ``model(data); loss.backward(); optim.step()``
+        (libs/trainer/trainer.py:183-209), unchanged: ONE autograd node whose forward / backward are the
+        native train-mode tape (egonet_amd.autograd.HRNetAutograd); torch owns loss and optimiser.
+        ``EGONET_AMD_AUTOGRAD=0``, an input that requires a gradient, heads the tape does not train
+        (pixel shuffle / angle regression) and train mode WITHOUT autograd (``get_model_summary``) run the
+        module graph in torch.  CPU tensors: torch on the CPU (the reference's CPU path)."""
+        if x.is_cuda:
+            wants_input_grad = torch.is_grad_enabled() and x.requires_grad
+            if not self.training:
+                if self.hip_eval and not wants_input_grad:
+                    return self._hip_engine().forward(x)
+            elif torch.is_grad_enabled() and not wants_input_grad and self._native_autograd_ok():
+                return self._autograd_bridge()(x)
         return self._torch_forward(x)
+
+    hip_eval = True          # eval-mode CUDA forwards run the HIP program (see forward)
+
+    def _native_autograd_ok(self):
+        return (os.environ.get('EGONET_AMD_AUTOGRAD', '1') != '0' and not self.pixel_shuffle
+                and self.head_type in ('coordinates', 'heatmap')
+                and any(p.requires_grad for p in self.parameters()))
+
+    def _autograd_bridge(self):
+        from egonet_amd import autograd
+        b = self.__dict__.get('_bridge')
+        if b is None or b.model is not self:        # (an nn.DataParallel replica builds its own, like _hip_engine)
+            b = autograd.HRNetAutograd(self)
+            self.__dict__['_bridge'] = b
+        return b
 
     def train(self, mode=True):
         if mode:                 # the weights are about to change: drop programs and packed blobs
@@ -331,6 +357,7 @@ class PoseHighResolutionNet(nn.Module):
 
     def _apply(self, fn, *a, **k):       # .cuda()/.to()/.float(): packed weights are stale
         self._engine = None
+        self.__dict__.pop('_bridge', None)
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):

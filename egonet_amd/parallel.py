@@ -108,29 +108,57 @@ class GradBuckets(object):
                 off += n
 
 
+class _SliceLayout(object):
+    """Which slices of the flat gradient each parameter overlaps, and how many parameters each slice waits
+    for -- a property of (FlatGradSync.bucket, FlatParams layout): computed ONCE and copied per step (it
+    used to be rebuilt every iteration: O(parameters x slices) of Python inside the step's launch loop)."""
+
+    def __init__(self, sync, flat_params):
+        numel = flat_params.grad.numel()
+        self.key = (sync.bucket, numel, len(flat_params.params))
+        self.slices = sync.slices(numel)
+        self.spans = {}
+        self.waiting = [0] * len(self.slices)
+        bounds = [lo for lo, _ in self.slices]         # descending starts: slice i covers [bounds[i], bounds[i-1])
+        for p, off in zip(flat_params.params, flat_params.offsets):
+            end = off + p.numel()
+            hit = [i for i, (lo, hi) in enumerate(self.slices) if off < hi and end > lo]
+            self.spans[id(p)] = tuple(hit)
+            for i in hit:
+                self.waiting[i] += 1
+        del bounds
+
+
 class _SyncSession(object):
     """One backward pass of ``FlatGradSync.begin``: tracks which slices of the flat gradient are
-    final and launches their all-reduce while the rest of the backward still runs."""
+    final and launches their all-reduce while the rest of the backward still runs.
 
-    def __init__(self, sync, flat_params, main_stream, side_stream):
+    A parameter's gradient is final when every backward closure that writes it has reported it.  By
+    default that is ONE report per parameter (HRNet / the lifter: every weight belongs to one layer);
+    ``report_counts`` ({id(param): n}) declares parameters written by several closures (shared weights).  A
+    report for a parameter whose slice is already in flight -- the gradient would be reduced while it is
+    still being written -- raises instead of corrupting the step."""
+
+    def __init__(self, sync, flat_params, main_stream, side_stream, report_counts=None):
         self.sync, self.flat = sync, flat_params
         self.grad = flat_params.grad
         self.world = dist.get_world_size(sync.group)
         self.main, self.side = main_stream, side_stream
         self.cuda = self.grad.is_cuda
-        self.slices = sync.slices(self.grad.numel())
-        # number of parameters overlapping each slice that still wait for their gradient
-        self.spans = {}
-        self.waiting = [0] * len(self.slices)
-        for p, off in zip(flat_params.params, flat_params.offsets):
-            hit = [i for i, (lo, hi) in enumerate(self.slices) if off < hi and off + p.numel() > lo]
-            self.spans[id(p)] = hit
-            for i in hit:
-                self.waiting[i] += 1
+        lay = sync.layout(flat_params)
+        self.slices = lay.slices
+        self.spans = lay.spans                         # read-only; per-step state is `left` / `waiting`
+        self.waiting = list(lay.waiting)
+        self.left = {}                                 # id(param) -> reports still expected
+        if report_counts:
+            for pid, n in report_counts.items():
+                if n > 1 and pid in self.spans:
+                    self.left[pid] = n
+        self.reported = set()
         self.launched = [False] * len(self.slices)
         self.works = []
         if self.cuda and sync.comm_stream is None:
-            sync.comm_stream = torch.cuda.Stream(device=self.grad.device)
+            sync.comm_stream = torch.cuda.Stream(device=self.grad.device, priority=sync.comm_priority)
 
     def _launch(self, i):
         lo, hi = self.slices[i]
@@ -141,9 +169,9 @@ class _SyncSession(object):
             return
         comm = self.sync.comm_stream
         # the slice is final once everything issued so far on the backward's streams has run
-        for st in (self.main, self.side):
+        for k, st in enumerate((self.main, self.side)):
             if st is not None:
-                ev = torch.cuda.Event()
+                ev = self.sync.event(i, k)
                 ev.record(st)
                 comm.wait_event(ev)
         with torch.cuda.stream(comm):
@@ -153,7 +181,21 @@ class _SyncSession(object):
     def done(self, params):
         """The kernels that write the gradients of ``params`` have been issued."""
         for p in params:
-            for i in self.spans.pop(id(p), ()):
+            pid = id(p)
+            span = self.spans.get(pid)
+            if span is None:                       # not a trainable parameter of the flat buffer (frozen)
+                continue
+            if pid in self.reported:
+                raise RuntimeError('FlatGradSync: a backward closure reported a parameter (%s) whose gradient was '
+                                   'already declared final -- its slice of the flat gradient may be in flight.  '
+                                   'Declare parameters written by several closures with report_counts, or set '
+                                   'EGONET_AMD_GRAD_OVERLAP=0.' % (tuple(p.shape),))
+            n = self.left.get(pid, 1) - 1
+            if n > 0:
+                self.left[pid] = n
+                continue
+            self.reported.add(pid)
+            for i in span:
                 self.waiting[i] -= 1
                 if self.waiting[i] == 0 and not self.launched[i]:
                     self._launch(i)
@@ -183,23 +225,60 @@ class FlatGradSync(object):
         layers first), so the collectives of the late layers run under the MFMA work of the early
         ones and only the first layers' slice is exposed.  The order in which slices become final
         is a property of the model, identical on every rank, so the collectives match up.
+        ``EGONET_AMD_GRAD_OVERLAP=0`` makes ``begin`` return None: the steps then fall back to the
+        first form (one exchange after the backward) -- the switch to pull if the overlapped path
+        misbehaves on a new fabric.
     Replaces the per-step parameter broadcast + output gather of ``torch.nn.DataParallel``
     (tools/train_IGRs.py:59) by the one exchange step data parallelism needs.
     xGMI is point to point: 32 MB slices keep every ring step well above the
     latency floor without serialising the whole 256 MB HRNet gradient.
+
+    The communication stream is created with HIGH priority (``comm_priority=-1``;
+    ``EGONET_AMD_COMM_PRIORITY`` overrides): an RCCL ring kernel occupies a few CUs per channel, the
+    backward's MFMA kernels fill all 256 -- at equal priority a collective that becomes ready in the
+    middle of the backward only starts when a compute kernel drains; with priority its workgroups are
+    dispatched as soon as CUs free up and the exchange really runs under the backward.  RCCL settings this
+    path is written for (none are set by the package): ``NCCL_MIN_NCHANNELS`` / ``NCCL_MAX_NCHANNELS`` left
+    at their defaults (ring over the 7 xGMI links of a fully connected 8-GPU node), ``HSA_ENABLE_IPC_MODE_LEGACY=0``
+    (dmabuf IPC, required by this driver), ``RCCL_MSCCL_ENABLE`` untouched; ``tools/scale_check.sh`` prints the
+    exposed (non-overlapped) all-reduce time so that a regression of the overlap is visible.
     """
 
-    def __init__(self, bucket_mb=32.0, group=None):
+    def __init__(self, bucket_mb=32.0, group=None, comm_priority=None):
+        import os
         self.group = group
         self.bucket = max(1, int(bucket_mb * 2 ** 20) // 4)
         self.comm_stream = None
+        if comm_priority is None:
+            comm_priority = int(os.environ.get('EGONET_AMD_COMM_PRIORITY', '-1'))
+        self.comm_priority = comm_priority
+        self.overlap = os.environ.get('EGONET_AMD_GRAD_OVERLAP', '1') != '0'
+        self._layout = None
+        self._events = {}
 
     def active(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
-    def begin(self, flat_params, main_stream=None, side_stream=None):
-        """-> session (see the class docstring), or None when there is nothing to reduce."""
-        return _SyncSession(self, flat_params, main_stream, side_stream) if self.active() else None
+    def layout(self, flat_params):
+        key = (self.bucket, flat_params.grad.numel(), len(flat_params.params))
+        if self._layout is None or self._layout.key != key or self._layout_owner is not flat_params:
+            self._layout = _SliceLayout(self, flat_params)
+            self._layout_owner = flat_params
+        return self._layout
+
+    def event(self, i, k):
+        """Re-used event (slice i, stream k): a slice launches once per step, after last step's wait."""
+        ev = self._events.get((i, k))
+        if ev is None:
+            ev = self._events[(i, k)] = torch.cuda.Event()
+        return ev
+
+    def begin(self, flat_params, main_stream=None, side_stream=None, report_counts=None):
+        """-> session (see the class docstring), or None when there is nothing to reduce / the overlap is
+        switched off (the caller then runs ``sync(flat.grad)`` after the backward)."""
+        if not (self.active() and self.overlap):
+            return None
+        return _SyncSession(self, flat_params, main_stream, side_stream, report_counts)
 
     def slices(self, numel):
         out, hi = [], numel

@@ -318,7 +318,7 @@ class _Tape(object):
             self.side.wait_event(ev)
             self.side_keep.append((xd, dy))
             st = self.side_st
-        _lib.check(L.egn_conv2d_wgrad_f32(_lib.ptr(xd), _lib.ptr(dy), _lib.ptr(weight.grad), x.n, x.h, x.w, cin, x.cs,
+        _lib.check(L.egn_conv2d_wgrad_f32(_lib.ptr(xd), _lib.ptr(dy), _lib.ptr(self.o.grad_of(weight)), x.n, x.h, x.w, cin, x.cs,
                                           cout, cs_out, kh, kw, stride, pad, _lib.ptr(ws), ws.numel() * 4, st),
                    'wgrad')
 
@@ -450,7 +450,7 @@ class _Tape(object):
                 elif act != ACT_NONE:
                     raise NotImplementedError('activation %d without BatchNorm' % act)
                 if bias is not None and bias.requires_grad:
-                    _lib.check(L.egn_colsum_f32(_lib.ptr(dy), rows, cout, z.cs, _lib.ptr(bias.grad),
+                    _lib.check(L.egn_colsum_f32(_lib.ptr(dy), rows, cout, z.cs, _lib.ptr(self.o.grad_of(bias)),
                                                 _lib.ptr(self.o.col_ws), self.st), 'bias grad')
                 if weight.requires_grad:
                     self._wgrad(x, xd, dy, z.cs, weight, stride, pad)
@@ -489,8 +489,8 @@ class _Tape(object):
             dy = self._take_grad(y)
             if dy is None:
                 return
-            dbeta = bn.bias.grad if bn.bias.requires_grad else self._empty(cout)
-            dgamma = bn.weight.grad if bn.weight.requires_grad else self._empty(cout)
+            dbeta = self.o.grad_of(bn.bias) if bn.bias.requires_grad else self._empty(cout)
+            dgamma = self.o.grad_of(bn.weight) if bn.weight.requires_grad else self._empty(cout)
             _lib.check(L.egn_bn_bwd_sums_f32(_lib.ptr(dy), _lib.ptr(zd), None, 1.0, _lib.ptr(mean), _lib.ptr(istd),
                                              _lib.ptr(bn.weight), _lib.ptr(bn.bias), relu, _lib.ptr(rd), rows, cout,
                                              z.cs, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(self.o.col_ws),
@@ -545,7 +545,54 @@ class _Tape(object):
         return y
 
 
-class HRNetTrainStep(object):
+class TapeOwner(object):
+    """What a ``_Tape`` needs from the object that drives it: the library, scratch vectors, the packed-filter
+    cache, the weight-gradient side stream and workspace, the kernel-family switches, and ``grad_of(param)`` =
+    the tensor a parameter's gradient kernels write.  Two owners: ``HRNetTrainStep`` (the whole iteration
+    natively, gradients in one flat buffer) and ``egonet_amd.autograd.HRNetAutograd`` (forward / backward of a
+    ``torch.autograd.Function``: torch owns loss and optimiser)."""
+
+    def _init_tape_owner(self, model):
+        p0 = next(model.parameters())
+        if not p0.is_cuda:
+            raise ValueError('%s needs the model on a GPU' % type(self).__name__)
+        if model.head_type not in ('coordinates', 'heatmap') or model.pixel_shuffle:
+            raise NotImplementedError('native training: head_type %r pixel_shuffle %r'
+                                      % (model.head_type, model.pixel_shuffle))
+        self.model = model
+        self.dev = p0.device
+        self.L = _lib.lib()
+        widest = max(p.shape[0] for p in model.parameters()) + 32
+        self.ones = torch.ones(_round_up(widest, 16), dtype=torch.float32, device=self.dev)
+        self.zeros = torch.zeros(_round_up(widest, 16), dtype=torch.float32, device=self.dev)
+        self.col_ws = torch.zeros(self.L.egn_colreduce_ws_bytes(widest) // 4, dtype=torch.float32, device=self.dev)
+        self._wgrad_ws = None
+        # weight gradients on a second stream (EGONET_AMD_WGRAD_STREAM=0: everything on one stream)
+        self.wgrad_stream = torch.cuda.Stream(device=self.dev) \
+            if os.environ.get('EGONET_AMD_WGRAD_STREAM', '1') != '0' else None
+        self.walker = HRNetEngine(model)
+        self.packs = PackedFilters(self.dev)
+        self.debug_hook = None        # tests/train_debug.py: per-layer checks of the BatchNorm backward
+        self.timing = None            # bench.py: a list collects (cfg, flops, start, end) per conv launch
+        # 3x3 stride-1 forward / data-gradient convolutions may run on the fused Winograd kernels
+        # (csrc/conv_wino.hip) where they measured faster (EGONET_AMD_TRAIN_WINO=0: direct kernels only)
+        self.allow_wino = os.environ.get('EGONET_AMD_TRAIN_WINO', '1') != '0'
+        self.fuse_bn_stats = os.environ.get('EGONET_AMD_FUSE_BN_STATS', '1') != '0'
+        self.fuse_grad_add = os.environ.get('EGONET_AMD_FUSE_GRAD_ADD', '1') != '0'
+
+    def grad_of(self, p):
+        return p.grad
+
+    def wgrad_ws(self, nbytes):
+        if self._wgrad_ws is None or self._wgrad_ws.numel() * 4 < nbytes:
+            # allocated in the pool of the stream that uses it: when it has to grow, the old block is
+            # only handed to later work of that same stream
+            with torch.cuda.stream(self.wgrad_stream if self.wgrad_stream is not None
+                                   else torch.cuda.current_stream(self.dev)):
+                self._wgrad_ws = torch.empty(nbytes // 4 + 1024, dtype=torch.float32, device=self.dev)
+        return self._wgrad_ws
+
+class HRNetTrainStep(TapeOwner):
     """``step(images, target, joints_xy)`` = one iteration of trainer.py:183-209."""
 
     CR_CRITERIA = {'mse': 0, 'l1': 1, 'sl1': 2}      # loss_dict, function.py:17-20
@@ -553,17 +600,10 @@ class HRNetTrainStep(object):
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, w_hm=1.0, w_coor=0.1, grad_sync=None,
                  sigma=1, w_cr=None, cr_type='sl1', cr_indices=None, target_cr=4.0 / 3.0, cr_loss_thres=0.15,
                  hm_type='mse', coor_type='l1', optim_type='adam', momentum=0.0, weight_decay=0.0):
+        self._init_tape_owner(model)
         p0 = next(model.parameters())
-        if not p0.is_cuda:
-            raise ValueError('HRNetTrainStep needs the model on a GPU')
-        if model.head_type not in ('coordinates', 'heatmap') or model.pixel_shuffle:
-            raise NotImplementedError('native training: head_type %r pixel_shuffle %r'
-                                      % (model.head_type, model.pixel_shuffle))
         if model.head_type == 'heatmap' and w_coor:
             raise NotImplementedError("the 'heatmap' head trains with the heat-map term only (w_coor=0)")
-        self.model = model
-        self.dev = p0.device
-        self.L = _lib.lib()
         self.lr, self.betas, self.eps = lr, betas, eps
         if optim_type not in ('adam', 'sgd'):
             raise NotImplementedError('optimizer %r (optimizer.py:8-40 knows adam and sgd)' % (optim_type,))
@@ -593,34 +633,8 @@ class HRNetTrainStep(object):
         self.sigma = sigma           # heatmapModel.sigma: targets drawn on the device when step(target=None)
         self.last_target_weight = None
         self.flat = FlatParams(model.parameters())
-        widest = max(p.shape[0] for p in model.parameters()) + 32
-        self.ones = torch.ones(_round_up(widest, 16), dtype=torch.float32, device=self.dev)
-        self.zeros = torch.zeros(_round_up(widest, 16), dtype=torch.float32, device=self.dev)
-        self.col_ws = torch.zeros(self.L.egn_colreduce_ws_bytes(widest) // 4, dtype=torch.float32, device=self.dev)
-        self._wgrad_ws = None
-        # weight gradients on a second stream (EGONET_AMD_WGRAD_STREAM=0: everything on one stream)
-        self.wgrad_stream = torch.cuda.Stream(device=self.dev) \
-            if os.environ.get('EGONET_AMD_WGRAD_STREAM', '1') != '0' else None
         self.loss_dev = torch.zeros(1, dtype=torch.float64, device=self.dev)
-        self.walker = HRNetEngine(model)
-        self.packs = PackedFilters(self.dev)
         self.last_maps = self.last_coords = None
-        self.debug_hook = None        # tests/train_debug.py: per-layer checks of the BatchNorm backward
-        self.timing = None            # bench.py: a list collects (cfg, flops, start, end) per conv launch
-        # 3x3 stride-1 forward / data-gradient convolutions may run on the fused Winograd kernels
-        # (csrc/conv_wino.hip) where they measured faster (EGONET_AMD_TRAIN_WINO=0: direct kernels only)
-        self.allow_wino = os.environ.get('EGONET_AMD_TRAIN_WINO', '1') != '0'
-        self.fuse_bn_stats = os.environ.get('EGONET_AMD_FUSE_BN_STATS', '1') != '0'
-        self.fuse_grad_add = os.environ.get('EGONET_AMD_FUSE_GRAD_ADD', '1') != '0'
-
-    def wgrad_ws(self, nbytes):
-        if self._wgrad_ws is None or self._wgrad_ws.numel() * 4 < nbytes:
-            # allocated in the pool of the stream that uses it: when it has to grow, the old block is
-            # only handed to later work of that same stream
-            with torch.cuda.stream(self.wgrad_stream if self.wgrad_stream is not None
-                                   else torch.cuda.current_stream(self.dev)):
-                self._wgrad_ws = torch.empty(nbytes // 4 + 1024, dtype=torch.float32, device=self.dev)
-        return self._wgrad_ws
 
     @torch.no_grad()
     def step(self, images, target, joints_xy=None, update=True, joints_vis=None):
@@ -713,8 +727,15 @@ class HRNetTrainStep(object):
             tape._accum(aug, da)
             # the gradient all-reduce of a slice of the flat buffer starts (on a communication
             # stream) as soon as every parameter in it has its gradient kernels issued
-            sess = self.grad_sync.begin(self.flat, torch.cuda.current_stream(self.dev), self.wgrad_stream) \
-                if hasattr(self.grad_sync, 'begin') else None
+            sess = None
+            if hasattr(self.grad_sync, 'begin'):
+                # a parameter written by several closures (shared weights) is final after its LAST report
+                counts = {}
+                for fn in tape.back:
+                    for q in getattr(fn, 'params', ()):
+                        counts[id(q)] = counts.get(id(q), 0) + 1
+                sess = self.grad_sync.begin(self.flat, torch.cuda.current_stream(self.dev), self.wgrad_stream,
+                                            report_counts=counts)
             for fn in reversed(tape.back):
                 fn()
                 if sess is not None:

@@ -80,6 +80,7 @@ class LifterTrainStep(object):
         self.wgrad_stream = torch.cuda.Stream(device=self.dev) \
             if os.environ.get('EGONET_AMD_WGRAD_STREAM', '1') != '0' else None
         self._side_used = False
+        self._side_keep = []
         self.timing = None            # bench.py: a list collects (cfg, flops, start, end) per GEMM launch
 
     # -- helpers -----------------------------------------------------------
@@ -134,7 +135,7 @@ class LifterTrainStep(object):
             tm.append((cfg, 2.0 * rows * k * cout, e0, e1))
         return out
 
-    def _wgrad(self, a, ld_a, inf, dz, ld_dz, outf, rows, grad_w):
+    def _wgrad(self, a, ld_a, inf, dz, ld_dz, outf, rows, grad_w, keep=None):
         """grad_w[outf, inf] = dz^T a on the split-K MFMA weight-gradient kernel
         (both operands are read as they lie, row-major)."""
         L = self.L
@@ -151,6 +152,8 @@ class LifterTrainStep(object):
             self.wgrad_stream.wait_event(ev)
             st = C.c_void_p(self.wgrad_stream.cuda_stream)
             self._side_used = True
+            if keep is not None:           # freshly allocated operands: alive until the side stream is joined
+                self._side_keep.append(keep)
         _lib.check(L.egn_conv2d_wgrad_f32(_lib.ptr(a), _lib.ptr(dz), _lib.ptr(grad_w), rows, 1, 1, inf, ld_a, outf,
                                           ld_dz, 1, 1, 1, 0, _lib.ptr(ws), ws.numel() * 4, st), 'wgrad')
 
@@ -160,6 +163,7 @@ class LifterTrainStep(object):
             ev.record(self.wgrad_stream)
             torch.cuda.current_stream(self.dev).wait_event(ev)
             self._side_used = False
+        self._side_keep = []
 
     # -- the step -----------------------------------------------------------
     @torch.no_grad()
@@ -171,111 +175,141 @@ class LifterTrainStep(object):
         with _gc_paused():
             return self._step(x, target, update)
 
-    def _step(self, x, target, update):
+    def grad_of(self, p):
+        return self.grads[id(p)]
+
+    def _forward(self, x, fresh=False):
+        """Train-mode forward (FCmodel.py:92-105 with BatchNorm1d on batch statistics and dropout).  Returns
+        (pred [B, out], saved) -- ``saved`` is what ``_backward`` needs.  ``fresh``: every activation in a new
+        allocation (the autograd bridge: a second forward must not overwrite what a pending backward reads)
+        instead of this object's named buffers."""
         L, dev = self.L, self.dev
         B = x.shape[0]              # any size: the reference's DataLoader has no drop_last (trainer.py:113-125)
         if B < 2:
             raise ValueError('BatchNorm1d needs more than one sample per batch in training mode')
         x = x.contiguous().float()
-        target = target.contiguous().float()
-        ws = self._buf('colws', L.egn_colreduce_ws_bytes(1024 + 16) // 4)
         st = self._st()
         keep = 1.0 / (1.0 - self.p) if self.p > 0 else 1.0
 
+        def buf(name, *shape):
+            if fresh:
+                return torch.empty(*shape, dtype=torch.float32, device=dev)
+            return self._buf(name, *shape)
+        ws = self._buf('colws', L.egn_colreduce_ws_bytes(1024 + 16) // 4)
+        self.packs.pack_all(st)           # every filter of the iteration, one launch (from the second step on)
+        # input rows padded to a multiple of 4 floats
+        ld0 = _round_up(self.units[0].inf, 4)
+        a = buf('a0', B, ld0)
+        _lib.check(L.egn_nchw_to_nhwc_f32(_lib.ptr(x), _lib.ptr(a), B, self.units[0].inf, 1, 1, ld0, st))
+        saved = []
+        ld_a = ld0
+        block_in = None
+        for ui, u in enumerate(self.units):
+            z = buf('z%d' % ui, B, u.outf)
+            self._gemm(a, B, u.inf, ld_a, u.fc.weight, u.inf, u.outf, 0, z, shift=u.fc.bias, tagk='f%d' % ui)
+            mean = buf('mean%d' % ui, u.outf)
+            istd = buf('istd%d' % ui, u.outf)
+            varu = buf('varu%d' % ui, u.outf)
+            mom = u.bn.momentum if u.bn.momentum is not None else 0.1
+            _lib.check(L.egn_bn_stats_f32(_lib.ptr(z), B, u.outf, u.outf, u.bn.eps, _lib.ptr(mean), _lib.ptr(istd),
+                                          _lib.ptr(varu), _lib.ptr(u.bn.running_mean),
+                                          _lib.ptr(u.bn.running_var), mom, _lib.ptr(ws), st), 'bn_stats')
+            mask = None
+            if self.p > 0:
+                mask = buf('mask%d' % ui, B, u.outf)
+                mask.bernoulli_(1.0 - self.p)          # keep mask (0/1), one launch, capture-aware RNG
+            y = buf('y%d' % ui, B, u.outf)
+            _lib.check(L.egn_bn_act_fwd_f32(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(u.bn.weight),
+                                            _lib.ptr(u.bn.bias), _lib.ptr(mask), keep, self.act, None, _lib.ptr(y), B,
+                                            u.outf, u.outf, st), 'bn_act_fwd')
+            saved.append((a, ld_a, z, mean, istd, mask))
+            if ui == 0:
+                block_in = y
+                a = y
+            elif ui % 2 == 1:          # first unit of a residual block
+                a = y
+            else:                      # second unit: out = block_in + y   (FCmodel.py:33-43)
+                out = buf('blk%d' % ui, B, u.outf)
+                _lib.check(L.egn_add_f32(_lib.ptr(block_in), _lib.ptr(y), _lib.ptr(out), B * u.outf, st))
+                block_in = out
+                a = out
+            ld_a = u.outf
+        torch._foreach_add_([u.bn.num_batches_tracked for u in self.units], 1)
+        feat = a
+        nf = self.final.in_features
+        no = self.final.out_features
+        pred = buf('pred', B, no)
+        self._gemm(feat, B, nf, nf, self.final.weight, nf, no, 0, pred, shift=self.final.bias, tagk='fo')
+        return pred, (B, saved, feat, keep, fresh)
+
+    def _backward(self, ctx, dpred, sess=None):
+        """Backward of ``_forward`` from the gradient of the prediction; parameter gradients go to
+        ``grad_of(param)`` (overwritten, not accumulated)."""
+        L, dev = self.L, self.dev
+        B, saved, feat, keep, fresh = ctx
+        st = self._st()
+        g = self.grad_of
+        nf, no = self.final.in_features, self.final.out_features
+
+        def buf(name, *shape):
+            if fresh:
+                return torch.empty(*shape, dtype=torch.float32, device=dev)
+            return self._buf(name, *shape)
+        ws = self._buf('colws', L.egn_colreduce_ws_bytes(1024 + 16) // 4)
+        self._wgrad(feat, nf, nf, dpred, no, no, B, g(self.final.weight))
+        _lib.check(L.egn_colsum_f32(_lib.ptr(dpred), B, no, no, _lib.ptr(g(self.final.bias)), _lib.ptr(ws), st))
+        if sess is not None:
+            sess.done([self.final.weight, self.final.bias])
+        dy = buf('dy_top', B, nf)
+        self._gemm(dpred, B, no, no, self.final.weight, nf, nf, 1, dy, tagk='do')
+
+        d_block_out = dy              # gradient w.r.t. the output of the current residual block
+        for ui in range(len(self.units) - 1, -1, -1):
+            u = self.units[ui]
+            a_in, ld_in, z, mean, istd, mask = saved[ui]
+            if ui == 0 or ui % 2 == 0:
+                d_y = d_block_out     # unit 0 and the second unit of a block see the block-output gradient
+            dbeta, dgamma = g(u.bn.bias), g(u.bn.weight)
+            _lib.check(L.egn_bn_bwd_sums_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
+                                             _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), self.act, None,
+                                             B, u.outf, u.outf, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(ws),
+                                             st), 'bn_bwd_sums')
+            dz = buf('dz%d' % ui, B, u.outf)     # per unit: the side stream reads it until the join
+            _lib.check(L.egn_bn_bwd_dz_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
+                                           _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), self.act, None,
+                                           _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(dz), None, B, u.outf,
+                                           u.outf, st), 'bn_bwd_dz')
+            self._wgrad(a_in, ld_in, u.inf, dz, u.outf, u.outf, B, g(u.fc.weight), keep=(a_in, dz) if fresh else None)
+            _lib.check(L.egn_colsum_f32(_lib.ptr(dz), B, u.outf, u.outf, _lib.ptr(g(u.fc.bias)), _lib.ptr(ws), st))
+            if sess is not None:
+                sess.done([u.fc.weight, u.fc.bias, u.bn.weight, u.bn.bias])
+            if ui == 0:
+                break
+            da = buf('da%d' % (ui % 2), B, u.inf)
+            self._gemm(dz, B, u.outf, u.outf, u.fc.weight, u.inf, u.inf, 1, da, tagk='d')
+            if ui % 2 == 0:            # second unit of a block: continue into the first unit
+                d_y = da
+            else:                      # first unit: block input gradient = skip path + branch path
+                nxt = buf('dblk%d' % ((ui // 2) % 2), B, u.inf)
+                _lib.check(L.egn_add_f32(_lib.ptr(d_block_out), _lib.ptr(da), _lib.ptr(nxt), B * u.inf, st))
+                d_block_out = nxt
+        self._join_side()
+
+    def _step(self, x, target, update):
+        L, dev = self.L, self.dev
+        target = target.contiguous().float()
         with torch.cuda.device(dev):
-            self.packs.pack_all(st)           # every filter of the iteration, one launch (from the second step on)
-            # input rows padded to a multiple of 4 floats
-            ld0 = _round_up(self.units[0].inf, 4)
-            a = self._buf('a0', B, ld0)
-            _lib.check(L.egn_nchw_to_nhwc_f32(_lib.ptr(x), _lib.ptr(a), B, self.units[0].inf, 1, 1, ld0, st))
-            saved = []
-            ld_a = ld0
-            block_in = None
-            for ui, u in enumerate(self.units):
-                z = self._buf('z%d' % ui, B, u.outf)
-                self._gemm(a, B, u.inf, ld_a, u.fc.weight, u.inf, u.outf, 0, z, shift=u.fc.bias, tagk='f%d' % ui)
-                mean = self._buf('mean%d' % ui, u.outf)
-                istd = self._buf('istd%d' % ui, u.outf)
-                varu = self._buf('varu%d' % ui, u.outf)
-                mom = u.bn.momentum if u.bn.momentum is not None else 0.1
-                _lib.check(L.egn_bn_stats_f32(_lib.ptr(z), B, u.outf, u.outf, u.bn.eps, _lib.ptr(mean), _lib.ptr(istd),
-                                              _lib.ptr(varu), _lib.ptr(u.bn.running_mean),
-                                              _lib.ptr(u.bn.running_var), mom, _lib.ptr(ws), st), 'bn_stats')
-                mask = None
-                if self.p > 0:
-                    mask = self._buf('mask%d' % ui, B, u.outf)
-                    mask.bernoulli_(1.0 - self.p)          # keep mask (0/1), one launch, capture-aware RNG
-                y = self._buf('y%d' % ui, B, u.outf)
-                _lib.check(L.egn_bn_act_fwd_f32(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(u.bn.weight),
-                                                _lib.ptr(u.bn.bias), _lib.ptr(mask), keep, self.act, None, _lib.ptr(y), B,
-                                                u.outf, u.outf, st), 'bn_act_fwd')
-                saved.append((a, ld_a, z, mean, istd, mask))
-                if ui == 0:
-                    block_in = y
-                    a = y
-                elif ui % 2 == 1:          # first unit of a residual block
-                    a = y
-                else:                      # second unit: out = block_in + y   (FCmodel.py:33-43)
-                    out = self._buf('blk%d' % ui, B, u.outf)
-                    _lib.check(L.egn_add_f32(_lib.ptr(block_in), _lib.ptr(y), _lib.ptr(out), B * u.outf, st))
-                    block_in = out
-                    a = out
-                ld_a = u.outf
-            torch._foreach_add_([u.bn.num_batches_tracked for u in self.units], 1)
-            feat = a
-            nf = self.final.in_features
-            no = self.final.out_features
-            pred = self._buf('pred', B, no)
-            self._gemm(feat, B, nf, nf, self.final.weight, nf, no, 0, pred, shift=self.final.bias, tagk='fo')
+            st = self._st()
+            pred, ctx = self._forward(x)
+            B, no = ctx[0], self.final.out_features
             # loss + gradient of the prediction
             self.loss_dev.zero_()
             dpred = self._buf('dpred', B, no)
             _lib.check(L.egn_mse_f32(_lib.ptr(pred), _lib.ptr(target), B, no, no, no, 1.0, 0, _lib.ptr(dpred),
                                      _lib.ptr(self.loss_dev), st), 'mse')
-
-            # ---- backward ----
-            g = self.grads
             sess = self.grad_sync.begin(self.flat, torch.cuda.current_stream(dev), self.wgrad_stream) \
                 if hasattr(self.grad_sync, 'begin') else None
-            self._wgrad(feat, nf, nf, dpred, no, no, B, g[id(self.final.weight)])
-            _lib.check(L.egn_colsum_f32(_lib.ptr(dpred), B, no, no, _lib.ptr(g[id(self.final.bias)]), _lib.ptr(ws), st))
-            if sess is not None:
-                sess.done([self.final.weight, self.final.bias])
-            dy = self._buf('dy_top', B, nf)
-            self._gemm(dpred, B, no, no, self.final.weight, nf, nf, 1, dy, tagk='do')
-
-            d_block_out = dy              # gradient w.r.t. the output of the current residual block
-            for ui in range(len(self.units) - 1, -1, -1):
-                u = self.units[ui]
-                a_in, ld_in, z, mean, istd, mask = saved[ui]
-                if ui == 0 or ui % 2 == 0:
-                    d_y = d_block_out     # unit 0 and the second unit of a block see the block-output gradient
-                dbeta, dgamma = g[id(u.bn.bias)], g[id(u.bn.weight)]
-                _lib.check(L.egn_bn_bwd_sums_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
-                                                 _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), self.act, None,
-                                                 B, u.outf, u.outf, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(ws),
-                                                 st), 'bn_bwd_sums')
-                dz = self._buf('dz%d' % ui, B, u.outf)     # per unit: the side stream reads it until the join
-                _lib.check(L.egn_bn_bwd_dz_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
-                                               _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), self.act, None,
-                                               _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(dz), None, B, u.outf,
-                                               u.outf, st), 'bn_bwd_dz')
-                self._wgrad(a_in, ld_in, u.inf, dz, u.outf, u.outf, B, g[id(u.fc.weight)])
-                _lib.check(L.egn_colsum_f32(_lib.ptr(dz), B, u.outf, u.outf, _lib.ptr(g[id(u.fc.bias)]), _lib.ptr(ws), st))
-                if sess is not None:
-                    sess.done([u.fc.weight, u.fc.bias, u.bn.weight, u.bn.bias])
-                if ui == 0:
-                    break
-                da = self._buf('da%d' % (ui % 2), B, u.inf)
-                self._gemm(dz, B, u.outf, u.outf, u.fc.weight, u.inf, u.inf, 1, da, tagk='d')
-                if ui % 2 == 0:            # second unit of a block: continue into the first unit
-                    d_y = da
-                else:                      # first unit: block input gradient = skip path + branch path
-                    nxt = self._buf('dblk%d' % ((ui // 2) % 2), B, u.inf)
-                    _lib.check(L.egn_add_f32(_lib.ptr(d_block_out), _lib.ptr(da), _lib.ptr(nxt), B * u.inf, st))
-                    d_block_out = nxt
-
-            self._join_side()
+            self._backward(ctx, dpred, sess)
             if sess is not None:
                 sess.finish()
             elif self.grad_sync is not None:

@@ -56,11 +56,30 @@ def prepare_optim(model, cfgs):
     return optim, sche
 
 
+def _rank():
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def _barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
 def _optim_kwargs(optim, cfgs):
     """optimizer family / momentum / weight decay of the native update, from the torch optimizer object
     ``prepare_optim`` made (or, without one, from cfgs['optimizer'])."""
     if optim is not None:
         g = optim.param_groups[0]
+        # the native update is ONE launch over one flat buffer with one set of hyper-parameters: parameter
+        # groups that differ (per-group weight decay / momentum / betas) cannot be collapsed silently
+        keys = ('momentum', 'weight_decay', 'betas', 'eps', 'dampening', 'nesterov', 'amsgrad')
+        for other in optim.param_groups[1:]:
+            diff = [k for k in keys if other.get(k) != g.get(k)]
+            if diff:
+                raise NotImplementedError('native update: param_groups with different %s (one flat buffer, one '
+                                          'set of hyper-parameters)' % ', '.join(diff))
         if isinstance(optim, torch.optim.SGD):
             if g.get('dampening', 0) or g.get('nesterov', False):
                 raise NotImplementedError('SGD with dampening / Nesterov momentum')
@@ -267,15 +286,23 @@ def train(train_dataset, model, loss_func, optim, sche, cfgs, logger, metric_fun
                     y_buffer.append(lv)
                 if eval_during and epoch > eval_start and batch_idx and eval_every and batch_idx % eval_every == 0:
                     parallel.broadcast_buffers(model, src=0)    # running statistics follow rank 0 (DataParallel semantics)
-                    evaluate_fn(valid_dataset, model, epoch)
+                    # every rank holds the same weights and (now) buffers: rank 0 evaluates the validation set
+                    # (ts['eval_all_ranks'] restores one evaluation per rank), the others wait at the barrier
+                    if _rank() == 0 or ts.get('eval_all_ranks', False):
+                        evaluate_fn(valid_dataset, model, epoch)
+                    _barrier()
                     model.train()
             if epoch in ts.get('snapshot_epochs', []):
                 parallel.broadcast_buffers(model, src=0)
                 out_dir = cfgs.get('dirs', {}).get('output', '.')
                 path = os.path.join(out_dir, '%s_%d.pth' % (cfgs.get('exp_type', 'model'), epoch))
-                logger.info('=> Snapshot model to {}'.format(path))
-                inner = model.module if hasattr(model, 'module') else model
-                torch.save(inner.state_dict(), path)
+                if _rank() == 0:       # one writer: concurrent truncating writers can leave a torn checkpoint
+                    logger.info('=> Snapshot model to {}'.format(path))
+                    inner = model.module if hasattr(model, 'module') else model
+                    tmp = path + '.tmp'
+                    torch.save(inner.state_dict(), tmp)
+                    os.replace(tmp, path)
+                _barrier()             # nobody reads / resumes from the file before it is complete
     finally:
         if frozen:
             gc.unfreeze()

@@ -458,6 +458,11 @@ int egn_program_replay(egn_program* p, void* stream);
  * since the library was loaded (process wide, all devices).  Test hook: a caller
  * can prove that a forward went through this library's kernels. */
 long egn_launch_count(void);
+/* number of convolution-class launches issued through the DIRECT entry points (egn_conv2d_f32,
+ * egn_conv2d_bnstats_f32, egn_conv2d_wgrad_f32) since the library was loaded: the training tape and the
+ * torch.autograd bridge (egonet_amd/autograd.py; replaces the MIOpen convolutions torch would run for
+ * libs/trainer/trainer.py:191-197) do not go through programs -- this is their proof. */
+long egn_direct_conv_count(void);
 /* per-op metadata for reports */
 int egn_program_op_info(const egn_program* p, int i, int* kind, double* flops,
                         double* bytes, char* tag, int tag_len);

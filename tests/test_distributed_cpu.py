@@ -206,3 +206,67 @@ def test_flat_gradient_sync_is_a_noop_without_a_process_group():
     parallel.FlatGradSync()(flat)
     assert torch.equal(flat, torch.ones(10))
     assert parallel.FlatGradSync().begin(None) is None
+
+
+def _guard_worker(rank, world, port, q):
+    """The session's contract: a parameter reported twice raises instead of reducing a slice that
+    is still being written; ``report_counts`` declares parameters written by several closures; the layout of
+    slices is computed once per (sync, FlatParams) pair; EGONET_AMD_GRAD_OVERLAP=0 switches the sessions off."""
+    from egonet_amd.train_hrnet import FlatParams
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    cfg = configs.tiny_config()
+    net = FCmodel.get_fc_model(1, cfg, 10, 12)
+    flat = FlatParams(net.parameters())
+    sync = parallel.FlatGradSync(bucket_mb=4 * 3000 / 2 ** 20)
+    out = {}
+    # (1) double report
+    sess = sync.begin(flat)
+    lay = sync._layout
+    p_last = flat.params[-1]
+    sess.done([p_last])
+    try:
+        sess.done([p_last])
+        out['double'] = 'no error'
+    except RuntimeError as e:
+        out['double'] = 'raised' if 'already declared final' in str(e) else str(e)
+    sess.finish()
+    # (2) a parameter written by two closures: final after its SECOND report
+    flat.grad.fill_(float(rank + 1))
+    sess = sync.begin(flat, report_counts={id(p_last): 2})
+    assert sync._layout is lay                       # same layout object: not rebuilt per step
+    w0 = sum(sess.waiting)
+    sess.done([p_last])
+    out['after_first'] = w0 - sum(sess.waiting)       # still waiting for the second writer
+    sess.done([p_last])
+    out['after_second'] = w0 - sum(sess.waiting)      # now final in every slice it overlaps
+    sess.finish()
+    out['mean'] = float(flat.grad.min()), float(flat.grad.max())
+    # (3) the switch
+    os.environ['EGONET_AMD_GRAD_OVERLAP'] = '0'
+    off = parallel.FlatGradSync(bucket_mb=1.0)
+    out['off'] = off.begin(flat) is None
+    flat.grad.fill_(float(rank + 1))
+    off(flat.grad)                                   # the fallback the steps take then
+    out['off_mean'] = float(flat.grad.min()), float(flat.grad.max())
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_session_guards_and_overlap_switch():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_guard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out['double'] == 'raised'
+    assert out['after_first'] == 0 and out['after_second'] >= 1
+    assert out['mean'] == (1.5, 1.5)
+    assert out['off'] is True and out['off_mean'] == (1.5, 1.5)

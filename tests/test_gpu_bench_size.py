@@ -1,0 +1,132 @@
+"""Whole-program parity AT THE SIZES bench.py TIMES.
+
+``tuned/gfx950.json`` is keyed by the batch size, so a 4-crop fixture runs a different selection of tile
+configurations than the 64-crop bench step.  These two tests run the bench's own configurations -- the shipped
+table, EGONET_AMD_AUTOTUNE=0 -- against the CPU oracle:
+
+  (i)  BASELINE configs[1]: HRNet-W48 'heatmap' head, 64 crops, forward + fused soft-arg-max decode
+       (reference libs/model/heatmapModel/hrnet.py:563-614, libs/common/img_proc.py:678-707);
+  (ii) BASELINE configs[3] per GPU: HRNet-W48 'coordinates', 32 crops, one native training step
+       (libs/trainer/trainer.py:183-209), every weight-gradient / data-gradient / BatchNorm-backward launch
+       re-computed in float64 from the tensors it consumed (rocBLAS dgemm per tap on the GPU:
+       tests/train_checks.py), with the default (Winograd) kernel families.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from egonet_amd import configs, synth, _lib
+from egonet_amd.model.heatmapModel import hrnet as hip_hrnet
+from oracle import hrnet_oracle, decode_oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(autouse=True)
+def _shipped_table_only(monkeypatch):
+    monkeypatch.setenv('EGONET_AMD_AUTOTUNE', '0')
+    monkeypatch.delenv('EGONET_AMD_WINO', raising=False)
+    monkeypatch.delenv('EGONET_AMD_TRAIN_WINO', raising=False)
+
+
+def _symbols(prog):
+    import bench
+    out = {}
+    for m in prog.meta:
+        if m['kind'] == 'conv':
+            out.setdefault(bench._symbol(m['cfg'], bench._klass_cout(m['klass'])), 0)
+            out[bench._symbol(m['cfg'], bench._klass_cout(m['klass']))] += 1
+    return out
+
+
+def test_w48_forward_and_decode_at_bench_batch_64_vs_oracle():
+    cfg = configs.w48_config('heatmap')
+    net = hip_hrnet.get_pose_net(cfg, is_train=False)
+    sd = synth.synth_state_dict(net.state_dict(), seed=1)          # the bench's weights (bench.build_model)
+    net.load_state_dict(sd)
+    net = net.eval().cuda()
+    x = synth.synth_crops(64, 3, 256, 256, seed=100)               # the bench's rank-0 crops
+    eng = net._hip_engine()
+    maps_d, (xy, mx, idx) = eng.forward(x.cuda(), decode_mode=1)
+    prog = eng.program(x.cuda(), 1)
+    torch.cuda.synchronize()
+    # every conv of the program has a measured table entry (cfg > 0): this IS the bench's selection
+    cfgs_ = [m['cfg'] for m in prog.meta if m['kind'] == 'conv']
+    missing = [m['klass'] for m in prog.meta if m['kind'] == 'conv' and m['cfg'] <= 0]
+    print('conv launches: %d, shapes left to the cost model (not in tuned/gfx950.json): %s' % (len(cfgs_), sorted(set(missing))))
+    assert len(cfgs_) > 300 and len(missing) <= 12
+    syms = _symbols(prog)
+    wino = {s: n for s, n in syms.items() if 'wino' in s}
+    assert sum(wino.values()) >= 200, syms                         # the 3x3 s1 layers run the Winograd family
+    # ... and it is what the committed bench line of this round reports
+    lines = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r3_bench_n1*.json')))
+    if lines:
+        with open(lines[-1]) as f:
+            rep = json.load(f)
+        for k in rep['kernel_symbols']:
+            if 'conv' in k['name']:
+                assert k['name'] in syms and syms[k['name']] == k['launches'], (k, syms)
+        assert rep['roofline']['kernel'] in syms
+
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    want = hrnet_oracle.hrnet_forward(sd, cfg, x).numpy()
+    maps = maps_d.cpu().numpy()
+    assert maps.shape == want.shape == (64, 33, 64, 64)
+    np.testing.assert_allclose(maps, want, rtol=0, atol=5e-4)
+    # arg-max indices: bit exact.  Where the ORACLE's own two largest values are closer than fp32 noise of
+    # a 300-layer network (1e-4 on maps spanning +-20) the index is not defined by the mathematics; such
+    # maps must still pick one of the tied maxima, and there may be at most a handful of them
+    widx, wmax = decode_oracle.argmax_index(want)
+    got_idx = idx.cpu().numpy().astype(np.int64)
+    differ = np.argwhere(got_idx != widx)
+    flat = want.reshape(64, 33, -1)
+    for n, k in differ:
+        assert flat[n, k, got_idx[n, k]] >= wmax[n, k, 0] - 1e-4, (n, k, flat[n, k, got_idx[n, k]], wmax[n, k, 0])
+    assert len(differ) <= 3, len(differ)
+    print('arg-max: %d of %d maps exact, %d oracle ties' % (64 * 33 - len(differ), 64 * 33, len(differ)))
+    np.testing.assert_allclose(mx.cpu().numpy(), wmax, rtol=0, atol=5e-4)
+    sxy, _ = decode_oracle.soft_arg_max(want)
+    np.testing.assert_allclose(xy.cpu().numpy(), sxy, rtol=0, atol=1e-3)
+
+
+def test_w48_training_step_at_bench_batch_32_vs_oracle():
+    from egonet_amd.train_hrnet import HRNetTrainStep
+    from oracle.hrnet_train_oracle import HRNetTrainOracle
+    from train_checks import LayerChecks
+    B = 32
+    cfg = configs.w48_config('coordinates')
+    net = hip_hrnet.get_pose_net(cfg, is_train=False)
+    sd = synth.synth_state_dict(net.state_dict(), seed=1)
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(100)
+    x = synth.synth_crops(B, 3, 256, 256, seed=50)                 # bench.train_hc_block, rank 0
+    tgt = torch.rand(B, 33, 64, 64, generator=g)
+    jt = torch.rand(B, 33, 2, generator=g) * 256
+    net = net.cuda().train()
+    tr = HRNetTrainStep(net, lr=1e-3)
+    assert tr.allow_wino and tr.fuse_bn_stats and tr.fuse_grad_add       # the bench's defaults
+    tr.timing = []
+    with LayerChecks(tr, device='cuda') as chk:
+        loss = tr.step(x.cuda(), tgt.cuda(), jt, update=False)
+    torch.cuda.synchronize()
+    L = _lib.lib()
+    kinds = [L.egn_conv_config_kind(c) if c > 0 else -9 for (c, _, _, _) in tr.timing]
+    print('conv launches of the step: %d, left to the cost model: %d' % (len(kinds), sum(1 for k in kinds if k == -9)))
+    assert sum(1 for k in kinds if k == 1) >= 400, 'the 3x3 s1 forward / data-gradient convs run the Winograd family'
+    assert len(chk.wgrad) == 306 and len(chk.dgrad) == 305 and len(chk.bn) >= 300
+    worst = chk.worst()
+    print('launch-local worst relative errors at B=32:', worst)
+    assert worst['wgrad'] < 5e-6 and worst['dgrad'] < 2e-5 and worst['bn'] < 5e-6, worst
+
+    torch.set_num_threads(max(torch.get_num_threads(), 16))
+    orc = HRNetTrainOracle(sd, cfg, lr=1e-3)
+    want_loss, want_maps, want_coords = orc.step(x, tgt, jt, update=False)
+    assert abs(float(loss.item()) - want_loss) < 5e-5 * abs(want_loss), (float(loss.item()), want_loss)
+    np.testing.assert_allclose(tr.last_coords.cpu().numpy(), want_coords.numpy(), rtol=0, atol=2e-4)
+    np.testing.assert_allclose(tr.last_maps.cpu().numpy(), want_maps.numpy(), rtol=0,
+                               atol=1e-3 * float(want_maps.abs().max()))

@@ -23,16 +23,53 @@ def rel(got, want):
     return float(np.abs(got - want).max()) / max(float(np.abs(want).max()), 1e-30)
 
 
-def _nchw(t, n, h, w, cs, c):
-    return t.view(n, h, w, cs)[..., :c].permute(0, 3, 1, 2).double().cpu()
+def _nchw(t, n, h, w, cs, c, device='cpu'):
+    return t.view(n, h, w, cs)[..., :c].permute(0, 3, 1, 2).double().to(device)
+
+
+def wgrad_ref64(x, dy, kh, kw, stride, pad):
+    """dW[co,ci,ky,kx] = sum_{n,y,x} dy[n,co,y,x] * xpad[n,ci,s*y+ky,s*x+kx] in float64, one matrix product per
+    tap -- on a GPU that is rocBLAS dgemm, an implementation independent of this package's kernels (and of
+    MIOpen), fast enough to check every launch of a 32-crop W48 step."""
+    xp = F.pad(x, (pad, pad, pad, pad))
+    n, co, ho, wo = dy.shape
+    ci = x.shape[1]
+    dyf = dy.permute(1, 0, 2, 3).reshape(co, -1)
+    out = torch.empty(co, ci, kh, kw, dtype=torch.float64, device=x.device)
+    for ky in range(kh):
+        for kx in range(kw):
+            xs = xp[:, :, ky:ky + stride * (ho - 1) + 1:stride, kx:kx + stride * (wo - 1) + 1:stride]
+            out[:, :, ky, kx] = dyf @ xs.permute(1, 0, 2, 3).reshape(ci, -1).t()
+    return out
+
+
+def dgrad_ref64(dy, w, stride, pad, h, wd):
+    """dx[n,ci,s*y+ky-p,s*x+kx-p] += sum_co dy[n,co,y,x] * W[co,ci,ky,kx] in float64, one matrix product per tap."""
+    n, co, ho, wo = dy.shape
+    ci, kh, kw = w.shape[1], w.shape[2], w.shape[3]
+    dxp = torch.zeros(n, ci, h + 2 * pad, wd + 2 * pad, dtype=torch.float64, device=dy.device)
+    dyf = dy.permute(0, 2, 3, 1).reshape(-1, co)
+    for ky in range(kh):
+        for kx in range(kw):
+            t = (dyf @ w[:, :, ky, kx]).view(n, ho, wo, ci).permute(0, 3, 1, 2)
+            dxp[:, :, ky:ky + stride * (ho - 1) + 1:stride, kx:kx + stride * (wo - 1) + 1:stride] += t
+    return dxp[:, :, pad:pad + h, pad:pad + wd]
+
+
+def _rel_t(got, want):
+    return float((got - want).abs().max()) / max(float(want.abs().max()), 1e-30)
 
 
 class LayerChecks(object):
     """Context manager: wraps the tape's wgrad / dgrad launches and the BatchNorm
     backward hook of an ``HRNetTrainStep``; collects relative errors."""
 
-    def __init__(self, trainer):
+    def __init__(self, trainer, device='cpu'):
+        """``device='cuda'``: the float64 recomputation runs on the GPU as per-tap matrix products
+        (``wgrad_ref64`` / ``dgrad_ref64``: rocBLAS dgemm) instead of torch's CPU convolution autograd --
+        what makes the check affordable at the bench's 32 crops."""
         self.tr = trainer
+        self.device = device
         self.wgrad, self.dgrad, self.bn = [], [], []
 
     def __enter__(self):
@@ -47,11 +84,16 @@ class LayerChecks(object):
             torch.cuda.synchronize()           # the launch may be on the trainer's side stream
             cout, cin, kh, kw = weight.shape
             ho, wo = (x.h + 2 * pad - kh) // stride + 1, (x.w + 2 * pad - kw) // stride + 1
+            if me.device != 'cpu':
+                want = wgrad_ref64(_nchw(xd, x.n, x.h, x.w, x.cs, cin, me.device),
+                                   _nchw(dy, x.n, ho, wo, cs_out, cout, me.device), kh, kw, stride, pad)
+                me.wgrad.append((_rel_t(tape.o.grad_of(weight).double(), want), (x.n, x.h, x.w, cin, cout, kh, stride)))
+                return
             wt = torch.zeros(cout, cin, kh, kw, dtype=torch.float64, requires_grad=True)
             with torch.enable_grad():
                 F.conv2d(_nchw(xd, x.n, x.h, x.w, x.cs, cin), wt, None, stride, pad).backward(
                     _nchw(dy, x.n, ho, wo, cs_out, cout))
-            me.wgrad.append((rel(weight.grad.double().cpu().numpy(), wt.grad.numpy()),
+            me.wgrad.append((rel(tape.o.grad_of(weight).double().cpu().numpy(), wt.grad.numpy()),
                              (x.n, x.h, x.w, cin, cout, kh, stride)))
 
         def dgrad(tape, dy, ho, wo, cs_out, weight, stride, pad, x, into=None):
@@ -62,6 +104,13 @@ class LayerChecks(object):
                 assert dx.data_ptr() == into.data_ptr()
                 dx = dx - before
             cout, cin, kh, kw = weight.shape
+            if me.device != 'cpu':
+                want = dgrad_ref64(_nchw(dy, x.n, ho, wo, cs_out, cout, me.device),
+                                   weight.detach().double().to(me.device), stride, pad, x.h, x.w)
+                e = _rel_t(_nchw(dx, x.n, x.h, x.w, x.cs, cin, me.device), want)
+                padmax = float(dx.view(x.n, x.h, x.w, x.cs)[..., cin:].abs().max()) if x.cs > cin else 0.0
+                me.dgrad.append((max(e, padmax), (x.n, x.h, x.w, cin, cout, kh, stride)))
+                return into if into is not None else dx
             xs = torch.zeros(x.n, cin, x.h, x.w, dtype=torch.float64, requires_grad=True)
             with torch.enable_grad():
                 F.conv2d(xs, weight.detach().double().cpu(), None, stride, pad).backward(
@@ -84,22 +133,24 @@ class LayerChecks(object):
     def _bn_hook(self, d):
         rows, cols, ld = d['rows'], d['cols'], d['ld']
 
+        dev = self.device
+
         def v(t):
-            return t.view(rows, ld)[:, :cols].double().cpu()
+            return t.view(rows, ld)[:, :cols].double().to(dev)
         z, dy = v(d['z']), v(d['dy'])
-        mean, istd = d['mean'].double().cpu(), d['istd'].double().cpu()
-        gm, bt = d['bn'].weight.detach().double().cpu(), d['bn'].bias.detach().double().cpu()
+        mean, istd = d['mean'].double().to(dev), d['istd'].double().to(dev)
+        gm, bt = d['bn'].weight.detach().double().to(dev), d['bn'].bias.detach().double().to(dev)
         xhat = (z - mean) * istd
         pre = gm * xhat + bt + (v(d['res']) if d['res'] is not None else 0)
         dpre = dy * (pre > 0) if d['relu'] else dy
         dbeta, dgamma = dpre.sum(0), (dpre * xhat).sum(0)
         dz = gm * istd * (dpre - dbeta / rows - xhat * dgamma / rows)
-        errs = [rel(v(d['dz']).numpy(), dz.numpy()),
-                rel(d['dbeta'].double().cpu().numpy(), dbeta.numpy()),
-                rel(d['dgamma'].double().cpu().numpy(), dgamma.numpy()),
-                rel(v(d['dres']).numpy(), dpre.numpy()) if d['dres'] is not None else 0.0,
-                rel(mean.numpy(), z.mean(0).numpy()),
-                rel(istd.numpy(), (z.var(0, unbiased=False) + d['bn'].eps).rsqrt().numpy())]
+        errs = [_rel_t(v(d['dz']), dz),
+                _rel_t(d['dbeta'].double().to(dev), dbeta),
+                _rel_t(d['dgamma'].double().to(dev), dgamma),
+                _rel_t(v(d['dres']), dpre) if d['dres'] is not None else 0.0,
+                _rel_t(mean, z.mean(0)),
+                _rel_t(istd, (z.var(0, unbiased=False) + d['bn'].eps).rsqrt())]
         self.bn.append((max(errs), d['tag'], (rows, cols, ld), errs))
         if self._prev_hook is not None:
             self._prev_hook(d)
