@@ -89,6 +89,8 @@ def _symbol(cfg, cout=None):
     """Kernel symbol of a tile configuration as rocprofv3 prints it (egn_conv_config_name); the 8-wave
     Winograd kernel is built per co-tile width: NT = 3 (Cout % 48 == 0) or 2."""
     from egonet_amd import _lib
+    if cfg and cfg < 0:        # the dense GEMM kernels of csrc/gemm.hip (forms NT / NN / TN), not a conv tile config
+        return 'gemm_kernel<%s> (csrc/gemm.hip)' % {-1: 'NT', -2: 'NN', -3: 'TN'}.get(cfg, '?')
     buf = C.create_string_buffer(128)
     if cfg and _lib.lib().egn_conv_config_name(cfg, buf, 128) == 0:
         sym = buf.value.decode()

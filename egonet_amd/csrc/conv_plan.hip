@@ -84,6 +84,7 @@ static const ConvConfig kConfigs[] = {
     {55, 8, 1, 1, 3, 4, 0x32, 5},
     {56, 4, 1, 1, 3, 4, 4, 5},     // frequency-halves kernel with 4 waves on two 8 x 8 images (32 tiles per block)
     {57, 4, 1, 1, 3, 4, 5, 5},     // ... on an 8 x 16 pixel tile of one image
+    {58, 8, 1, 1, 3, 4, 0x42, 5},  // 51 with s_memtime stamps (tools/wino_clk.py; `res` = the stamp buffer)
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 

@@ -511,6 +511,18 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
   float4* sU = smem;                  // [2][USL]
   float4* sH = smem + 2 * USL;  // [2][BUF]
   double* sS = reinterpret_cast<double*>(smem + 2 * USL + 2 * BUF);  // [NW][2][CO_T] BatchNorm partial sums
+  // ABL & 32 (tools/wino_clk.py only): s_memtime stamps of every wave's lane 0 -- kept in LDS, copied to the
+  // buffer passed as `res` at the end of the kernel (no residual then), so the vmcnt bookkeeping is untouched
+  unsigned long long* sT = reinterpret_cast<unsigned long long*>(sS + NW * 2 * CO_T);   // [NW][W8_NTK]
+  constexpr int W8_NTK = 48;
+  int ntk = 0;
+#define W8_CLK()                                                                     \
+  {                                                                                  \
+    if constexpr ((ABL & 32) != 0) {                                                 \
+      if (lane == 0 && ntk < W8_NTK) sT[wave * W8_NTK + ntk] = __builtin_readcyclecounter(); \
+      ++ntk;                                                                         \
+    }                                                                                \
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -609,8 +621,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
   bool first = true;
 
   const float act_lo = (a.act & EGN_ACT_MASK) == EGN_ACT_RELU ? 0.f : -__builtin_inff();
-  const bool has_res = a.res != nullptr;
+  const bool has_res = (ABL & 32) ? false : a.res != nullptr;
   const unsigned rowpitch = (unsigned)(a.Wo * Co) * 4u, colpitch = (unsigned)Co * 4u;
+  W8_CLK()   // 0: kernel start (prologue DMA issued)
 
   for (; w < nwork; w += gridDim.x) {
     int tile_n = 0, ct_n = 0;
@@ -650,12 +663,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
     for (int c = 0; c < nchunk; ++c) {
       const bool last = c + 1 == nchunk;
       asm volatile("" ::: "memory");
+      W8_CLK()   // step top
       if constexpr (!(ABL & 8)) {
         if (c == 0 && !first) __builtin_amdgcn_s_waitcnt(0x4078);  // vmcnt(24): all but the last item's stores
         else __builtin_amdgcn_s_waitcnt(0x0070);                   // vmcnt(0)
+        if constexpr ((ABL & 32) != 0) { asm volatile("" ::: "memory"); W8_CLK() asm volatile("" ::: "memory"); }  // own DMA landed
         __builtin_amdgcn_s_barrier();
       }
       asm volatile("" ::: "memory");
+      W8_CLK()   // past the barrier
       first = false;
       const bool nx_issue = !(ABL & 1) && (!last || more);
       const int nx_ct = last ? ct_n : ct, nx_ch = last ? 0 : c + 1;
@@ -748,6 +764,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
       par ^= 1;
     }
 
+    W8_CLK()   // K loop done
     // ---- output transform: this wave's frequency rows, then the exchange with the partner wave ----
     float keep[NT][4][2], send[NT][4][2];
 #pragma unroll
@@ -800,6 +817,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
         }
       }
     }
+    W8_CLK()   // exchange done
     float st1[NT], st2[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) st1[nt] = st2[nt] = 0.f;
@@ -835,8 +853,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
         }
       }
     }
+    W8_CLK()   // stores issued
     tile = tile_n;
     ct = ct_n;
+  }
+  if constexpr ((ABL & 32) != 0) {
+    __syncthreads();
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res)) +
+                              (size_t)blockIdx.x * (NW * W8_NTK + 1);
+    for (int e = tid; e < NW * W8_NTK; e += NTH) out[1 + e] = sT[e];
+    if (tid == 0) out[0] = (unsigned long long)ntk;
   }
   if (a.stats != nullptr) {
     // one partial row per block: [2][Cout] doubles, the block's 48 columns = its waves' sums in wave
@@ -856,6 +882,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
 #undef W8_ITEM
 #undef W8_DOFF
 #undef W8_PIECE
+#undef W8_CLK
 }
 
 template <int TH, int TW, int TNB, int ABL = 0>
@@ -941,7 +968,8 @@ size_t egn_conv_wino_lds_bytes(int variant, int cout) {
   if (v == 5) halo = EGN_CKQ * WinoGeom<8, 16, 1>::PLANE;
   const int cot = v >= 2 && egn_wino_cot(cout) ? egn_wino_cot(cout) : WN_CO;   // the 4-wave kernel: 48 only
   const size_t stats = v >= 2 ? (size_t)((v == 4 || v == 5) ? 4 : 8) * 2 * cot * sizeof(double) : 0;
-  return (2 * (size_t)(16 * EGN_CKQ * cot) + 2 * halo) * 16 + stats;
+  const size_t stamps = (variant >> 4) == 4 && v >= 2 ? 8 * 48 * sizeof(unsigned long long) : 0;   // ABL & 32 builds
+  return (2 * (size_t)(16 * EGN_CKQ * cot) + 2 * halo) * 16 + stats + stamps;
 }
 int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t stream) {
   const int act = a.act & EGN_ACT_MASK;
@@ -955,6 +983,7 @@ int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t
     case 0x12: return wino8_launch<16, 16, 1, 16>(a, lds, stream);
     case 0x22: return wino8_launch<16, 16, 1, 7>(a, lds, stream);
     case 0x32: return wino8_launch<16, 16, 1, 3>(a, lds, stream);
+    case 0x42: return wino8_launch<16, 16, 1, 32>(a, lds, stream);   // timeline stamps (tools/wino_clk.py)
     case 0x10: return wino_launch<16, 16, 1, 15>(a, lds, stream);
     case 0x20: return wino_launch<16, 16, 1, 7>(a, lds, stream);
     case 0x30: return wino_launch<16, 16, 1, 3>(a, lds, stream);

@@ -37,6 +37,12 @@ class _Unit(object):
 
 
 class LifterTrainStep(object):
+    # dense layers on csrc/gemm.hip where the shape allows (EGONET_AMD_GEMM=0: the conv-kernel route everywhere);
+    # tile variant per form (NT, NN, TN), the fastest of tools/gemm_probe.py on 4096 x 1024 x 1024 [MI355X r3]:
+    # NT 128x128 8 waves 2 stages 69 us, NN 128x128 8 waves 68 us, TN 128x128 4 waves split-K 4 74.5 us
+    use_gemm = os.environ.get('EGONET_AMD_GEMM', '1') != '0'
+    gemm_variant = [int(v) for v in os.environ.get('EGONET_AMD_GEMM_VARIANTS', '3,0,1').split(',')]
+
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, dropout=None, grad_sync=None,
                  optim_type='adam', momentum=0.0, weight_decay=0.0):
         p0 = next(model.parameters())
@@ -99,6 +105,20 @@ class LifterTrainStep(object):
         """out[rows, cout] (contiguous) = a[rows, :k] @ W^T + shift, W[co][ci] taken from
         w_src (row-major, ld_w) directly (transpose_w=0) or transposed (1)."""
         L = self.L
+        form = 1 if transpose_w else 0
+        if self.use_gemm and L.egn_gemm_supported(form, rows, cout, k, ld_a, ld_w, cout):
+            # the dense fp32-MFMA GEMM (csrc/gemm.hip): operands as they lie, no packed filter
+            tm = self.timing
+            if tm is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream(self.dev))
+            _lib.check(L.egn_gemm_f32(form, _lib.ptr(a), _lib.ptr(w_src), _lib.ptr(out),
+                                      _lib.ptr(shift.detach()) if shift is not None else None, rows, cout, k, ld_a, ld_w,
+                                      cout, self.gemm_variant[form], None, 0, self._st()), 'gemm')
+            if tm is not None:
+                e1.record(torch.cuda.current_stream(self.dev))
+                tm.append((-(form + 1), 2.0 * rows * k * cout, e0, e1))
+            return out
         coutp = _round_up(cout, 16)
         w4 = self.w4.get(id(w_src))
         if w4 is not None and ld_w == w4.shape[1]:
@@ -139,10 +159,12 @@ class LifterTrainStep(object):
         """grad_w[outf, inf] = dz^T a on the split-K MFMA weight-gradient kernel
         (both operands are read as they lie, row-major)."""
         L = self.L
-        need = L.egn_conv2d_wgrad_ws_bytes(rows, 1, 1, inf, ld_a, outf, ld_dz, 1, 1, 1, 0)
+        gemm = self.use_gemm and L.egn_gemm_supported(2, outf, inf, rows, ld_dz, ld_a, inf)
+        need = L.egn_gemm_ws_bytes(2, outf, inf, rows) if gemm else \
+            L.egn_conv2d_wgrad_ws_bytes(rows, 1, 1, inf, ld_a, outf, ld_dz, 1, 1, 1, 0)
         if need < 0:
             raise _lib.EgonetHipError('wgrad: unsupported shape')
-        ws = self._buf('wgrad_ws', max(need // 4, self._wgrad_floats))
+        ws = self._buf('wgrad_ws', max(need // 4, self._wgrad_floats, 4))
         self._wgrad_floats = ws.numel()
         st = self._st()
         if self.wgrad_stream is not None:
@@ -154,6 +176,10 @@ class LifterTrainStep(object):
             self._side_used = True
             if keep is not None:           # freshly allocated operands: alive until the side stream is joined
                 self._side_keep.append(keep)
+        if gemm:          # dW[out][in] = dz^T a: both operands as they lie (M-contiguous), split along the batch
+            _lib.check(L.egn_gemm_f32(2, _lib.ptr(dz), _lib.ptr(a), _lib.ptr(grad_w), None, outf, inf, rows, ld_dz, ld_a,
+                                      inf, self.gemm_variant[2], _lib.ptr(ws), ws.numel() * 4, st), 'wgrad gemm')
+            return
         _lib.check(L.egn_conv2d_wgrad_f32(_lib.ptr(a), _lib.ptr(dz), _lib.ptr(grad_w), rows, 1, 1, inf, ld_a, outf,
                                           ld_dz, 1, 1, 1, 0, _lib.ptr(ws), ws.numel() * 4, st), 'wgrad')
 

@@ -242,6 +242,20 @@ int egn_conv2d_wgrad_f32(const float* x, const float* dy, float* dw, int N, int 
  * transpose 0: W[co][ci] = src[co*ld+ci]; 1: W[co][ci] = src[ci*ld+co] */
 int egn_pack_matrix_f32(const float* src, int ld, int cout, int cin,
                         int transpose, float* dst, void* stream);
+/* Dense fp32 GEMM on the matrix pipe (csrc/gemm.hip) for the lifter's nn.Linear layers -- reference
+ * libs/model/FCmodel.py:33-43, 92-105 (forward) and what torch autograd derives from them in
+ * libs/trainer/trainer.py:191-197 (data / weight gradients); operands are read as they lie, nothing is packed:
+ *   form 0 "NT"  C[M][N] = A[M][K] . B[N][K]^T (+ bias[N])     z  = a W^T + b
+ *   form 1 "NN"  C[M][N] = A[M][K] . B[K][N]                   da = dz W
+ *   form 2 "TN"  C[M][N] = A[K][M]^T . B[K][N]                 dW = dz^T a   (split along K, fixed-order reduction;
+ *                                                              `ws` of egn_gemm_ws_bytes bytes)
+ * Row-major with leading dimensions lda / ldb / ldc (floats, multiples of 4).  egn_gemm_supported() = 1 for the
+ * shapes the kernels take (M, N multiples of 128, K of 32); the callers keep the conv-kernel route for the rest.
+ * variant 0 = default tile configuration of the form (others: tools/gemm_probe.py). */
+int egn_gemm_supported(int form, int M, int N, int K, int lda, int ldb, int ldc);
+long egn_gemm_ws_bytes(int form, int M, int N, int K);
+int egn_gemm_f32(int form, const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
+                 int lda, int ldb, int ldc, int variant, void* ws, long ws_bytes, void* stream);
 /* dst[c][r] = src[r][c]; dst columns R..ld_dst-1 are zeroed */
 int egn_transpose_f32(const float* src, int R, int C, int ld_src, float* dst,
                       int ld_dst, void* stream);

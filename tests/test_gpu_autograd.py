@@ -65,7 +65,7 @@ def test_reference_training_loop_on_the_native_tape_hrnet(head):
         loss.backward()
         if it == 0:
             n_launch = L.egn_direct_conv_count() - c0
-            assert n_launch > 150, n_launch                  # forward + data-gradient + weight-gradient convs
+            assert n_launch > 120, n_launch                  # forward + data-gradient + weight-gradient convs
             maps = prediction[0] if isinstance(prediction, tuple) else prediction
             assert maps.grad_fn is not None and 'HRNetFn' in type(maps.grad_fn).__name__
             np.testing.assert_allclose(maps.detach().cpu().numpy(), want_maps.numpy(), rtol=0, atol=2e-4)

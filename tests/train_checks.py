@@ -141,14 +141,38 @@ class LayerChecks(object):
         mean, istd = d['mean'].double().to(dev), d['istd'].double().to(dev)
         gm, bt = d['bn'].weight.detach().double().to(dev), d['bn'].bias.detach().double().to(dev)
         xhat = (z - mean) * istd
-        pre = gm * xhat + bt + (v(d['res']) if d['res'] is not None else 0)
+        res = v(d['res']) if d['res'] is not None else None
+        pre = gm * xhat + bt + (res if res is not None else 0)
+        # ReLU ties: a pre-activation within fp32 rounding of 0 (the kernel forms it in fp32, this check in
+        # float64) gets gate 1 in one and 0 in the other -- at 32 crops a layer has millions of elements and a
+        # few of them tie.  Those elements are compared with EITHER gate; what their |dy| can move the column
+        # sums by is added to the sums' bound.
+        tie = None
+        if d['relu']:
+            mag = (gm * xhat).abs() + bt.abs() + (res.abs() if res is not None else 0)
+            tie = pre.abs() <= 4e-7 * mag
         dpre = dy * (pre > 0) if d['relu'] else dy
         dbeta, dgamma = dpre.sum(0), (dpre * xhat).sum(0)
         dz = gm * istd * (dpre - dbeta / rows - xhat * dgamma / rows)
-        errs = [_rel_t(v(d['dz']), dz),
-                _rel_t(d['dbeta'].double().to(dev), dbeta),
-                _rel_t(d['dgamma'].double().to(dev), dgamma),
-                _rel_t(v(d['dres']), dpre) if d['dres'] is not None else 0.0,
+
+        def elem(got, want, alt=None):
+            diff = (got - want).abs()
+            if tie is not None and alt is not None:
+                diff = torch.where(tie, torch.minimum(diff, (got - alt).abs()), diff)
+            return float(diff.max()) / max(float(want.abs().max()), 1e-30)
+        slack_b = slack_g = 0.0
+        dz_alt = dres_alt = None
+        if tie is not None and bool(tie.any()):
+            slack_b = float((dy.abs() * tie).sum(0).max()) / max(float(dbeta.abs().max()), 1e-30)
+            slack_g = float(((dy * xhat).abs() * tie).sum(0).max()) / max(float(dgamma.abs().max()), 1e-30)
+            dpre_alt = torch.where(tie, dy - dpre, dpre)            # the other gate on the tied elements
+            dz_alt = gm * istd * (dpre_alt - dbeta / rows - xhat * dgamma / rows)
+            dres_alt = dpre_alt
+        self.ties = getattr(self, 'ties', 0) + (int(tie.sum()) if tie is not None else 0)
+        errs = [max(elem(v(d['dz']), dz, dz_alt) - (slack_b + slack_g), 0.0),
+                max(_rel_t(d['dbeta'].double().to(dev), dbeta) - slack_b, 0.0),
+                max(_rel_t(d['dgamma'].double().to(dev), dgamma) - slack_g, 0.0),
+                elem(v(d['dres']), dpre, dres_alt) if d['dres'] is not None else 0.0,
                 _rel_t(mean, z.mean(0)),
                 _rel_t(istd, (z.var(0, unbiased=False) + d['bn'].eps).rsqrt())]
         self.bn.append((max(errs), d['tag'], (rows, cols, ld), errs))
