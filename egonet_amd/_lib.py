@@ -66,6 +66,12 @@ SIGNATURES = {
     'egn_bn_act_fwd_f32': (_i, [_p, _p, _p, _p, _p, _p, C.c_float, _i, _p, _p, _i, _i, _i, _p]),
     'egn_bn_bwd_sums_f32': (_i, [_p, _p, _p, C.c_float, _p, _p, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p]),
     'egn_bn_bwd_dz_f32': (_i, [_p, _p, _p, C.c_float, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
+    'egn_bn_act_fwd_drop_f32': (_i, [_p, _p, _p, _p, _p, C.c_float, C.c_ulonglong, _p, _i, _i, _p, _p, _i, _i, _i, _p]),
+    'egn_bn_bwd_sums_drop_f32': (_i, [_p, _p, C.c_float, C.c_ulonglong, _p, _i, _p, _p, _p, _p, _i, _p, _i, _i, _i, _p, _p,
+                                      _p, _p]),
+    'egn_bn_bwd_dz_drop_f32': (_i, [_p, _p, C.c_float, C.c_ulonglong, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p, _i,
+                                    _i, _i, _p]),
+    'egn_dropout_mask_f32': (_i, [_p, C.c_long, C.c_float, C.c_ulonglong, _p, _i, _p]),
     'egn_add_f32': (_i, [_p, _p, _p, C.c_long, _p]),
     'egn_mse_f32': (_i, [_p, _p, _i, _i, _i, _i, C.c_float, _i, _p, _p, _p]),
     'egn_l1_f32': (_i, [_p, _p, C.c_long, C.c_float, _p, _p, _p]),

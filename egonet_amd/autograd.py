@@ -185,6 +185,12 @@ class LifterAutograd(LifterTrainStep):
         self._side_keep = []
         self.timing = None
         self._grads = None
+        # in-kernel dropout: forward and backward of one call share (seed, unit, counter value); the counter is a
+        # device tensor bumped once per forward -- a backward runs before the next forward of the reference's
+        # loop; with several forwards in flight (test: two forwards, two backwards) the masks are torch tensors
+        self.drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.drop_step = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._pending = 0
 
     @property
     def p(self):                      # the module's dropout probability, live (nn.Dropout.p may be edited)
@@ -211,6 +217,11 @@ class LifterAutograd(LifterTrainStep):
             if w4 is None or w4.data_ptr() != fc.weight.data_ptr():
                 self.w4[id(fc.weight)] = fc.weight.detach().view(fc.out_features, fc.in_features, 1, 1)
         with _gc_paused(), torch.cuda.device(self.dev):
+            # the counter value must still be this forward's when its backward runs: only one forward may be pending
+            self.rng_dropout = LifterTrainStep.rng_dropout and self._pending == 0
+            if self.rng_dropout:
+                self.drop_step.add_(1)
+            self._pending += 1
             pred, saved = self._forward(x, fresh=True)
             invalidate(self.model)
         return pred, saved
@@ -228,6 +239,7 @@ class LifterAutograd(LifterTrainStep):
                 views.append(v)
                 off += sz
             self._backward(saved, gout.contiguous().float())
+            self._pending = max(0, self._pending - 1)
             self.packs.finalize()
             self._grads = None
         return views

@@ -85,6 +85,11 @@ static const ConvConfig kConfigs[] = {
     {56, 4, 1, 1, 3, 4, 4, 5},     // frequency-halves kernel with 4 waves on two 8 x 8 images (32 tiles per block)
     {57, 4, 1, 1, 3, 4, 5, 5},     // ... on an 8 x 16 pixel tile of one image
     {58, 8, 1, 1, 3, 4, 0x42, 5},  // 51 with s_memtime stamps (tools/wino_clk.py; `res` = the stamp buffer)
+    {59, 8, 1, 1, 3, 4, 6, 5},     // conv_wino9_kernel (half the VALU instructions of 51 / 52 / 56 / 57): 16 x 16 tile
+    {60, 8, 1, 1, 3, 4, 7, 5},     // ... four 8 x 8 images
+    {61, 4, 1, 1, 3, 4, 8, 5},     // ... two 8 x 8 images, 4 waves
+    {62, 4, 1, 1, 3, 4, 9, 5},     // ... 8 x 16 pixel tile, 4 waves
+    {63, 8, 1, 1, 3, 4, 0x46, 5},  // 59 with s_memtime stamps (tools/wino_clk.py)
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -117,7 +122,11 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (c.dma == 5)
     // conv_wino8_kernel<TH, TW, TNB, ABL, NW, NT>: the symbol of the 48-channel co-tile build (NT = 3: the W48
     // widths); layers with Cout % 48 != 0 run the NT = 2 build of the same kernel
-    if ((c.bi & 15) == 4) snprintf(buf, len, "void conv_wino8_kernel<8, 8, 2, 0, 4, 3>(ConvArgs)");
+    if ((c.bi & 15) >= 6) {
+      static const char* geo9[4] = {"16, 16, 1, 8", "8, 8, 4, 8", "8, 8, 2, 4", "8, 16, 1, 4"};
+      snprintf(buf, len, "void conv_wino9_kernel<%s, 3>(ConvArgs)", geo9[(c.bi & 15) - 6]);
+    }
+    else if ((c.bi & 15) == 4) snprintf(buf, len, "void conv_wino8_kernel<8, 8, 2, 0, 4, 3>(ConvArgs)");
     else if ((c.bi & 15) == 5) snprintf(buf, len, "void conv_wino8_kernel<8, 16, 1, 0, 4, 3>(ConvArgs)");
     else if (c.bi & 2) snprintf(buf, len, "void conv_wino8_kernel<%s, %d, 8, 3>(ConvArgs)", (c.bi & 1) ? "8, 8, 4" : "16, 16, 1", c.bi >> 4);
     else snprintf(buf, len, "void conv_wino_kernel<%s, %d>(ConvArgs)", (c.bi & 1) ? "8, 8, 4" : "16, 16, 1", c.bi >> 4);
@@ -166,9 +175,10 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
       return false;
     // co-tile 48 (4- and 8-wave kernels) or 32 (8-wave kernels only): egn_wino_cot in conv_wino.hip
     if (a.Cout % 48 != 0 && !(a.Cout % 32 == 0 && (cf.bi & 15) >= 2)) return false;
-    if ((cf.bi & 15) == 4) { a.TH = 8; a.TW = 8; a.TNB = 2; }
-    else if ((cf.bi & 15) == 5) { a.TH = 8; a.TW = 16; a.TNB = 1; }
-    else if ((cf.bi & 15) == 1 || (cf.bi & 15) == 3) { a.TH = 8; a.TW = 8; a.TNB = 4; }
+    const int geo = (cf.bi & 15) >= 6 ? (cf.bi & 15) - 4 : (cf.bi & 15);   // 6..9: conv_wino9_kernel on 2..5's tiles
+    if (geo == 4) { a.TH = 8; a.TW = 8; a.TNB = 2; }
+    else if (geo == 5) { a.TH = 8; a.TW = 16; a.TNB = 1; }
+    else if (geo == 1 || geo == 3) { a.TH = 8; a.TW = 8; a.TNB = 4; }
     else { a.TH = 16; a.TW = 16; a.TNB = 1; }
     if (a.TH == 8 && a.TW == 8 && (a.Ho > 8 || a.Wo > 8)) return false;   // the batched variant is for the 8 x 8 maps
     a.HH = a.TH + 2; a.HW = a.TW + 2;

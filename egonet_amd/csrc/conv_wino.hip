@@ -885,6 +885,438 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino8_kernel(ConvArgs a) {
 #undef W8_CLK
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv_wino9_kernel -- conv_wino8_kernel with the VALU instruction count cut in half [round 3].
+//
+// What round 3 measured (profiles/r3_mfma_tax.txt, a hand-written v_mfma_f32_16x16x4_f32 stream with
+// companions): beside fp32 MFMAs a ds_read_b128, an LDS-DMA piece, a global load and an s_barrier cost
+// ~0-3 cycles of matrix-pipe time each -- but every plain VALU instruction costs 5-10 (one wave per SIMD) /
+// 3-6 (two) cycles: the fp32 MFMA executes on the SIMD's fp32 FMA lanes, a VALU instruction of either wave
+// takes issue slots away from it.  conv_wino8_kernel issues 3.2 VALU instructions per MFMA on the 48-channel
+// layers (928 per item, 288 MFMAs; ISA count) of which 1.4 are arithmetic the algorithm needs; its timeline
+// (profiles/r3_wino8_timeline_before.txt) shows a K step at 7 300-7 500 cycles for 6 144 of MFMA issue and
+// 20 % of an item in the head / exchange / epilogue phases.  This kernel keeps the data flow and removes
+// instructions:
+//   * item index arithmetic on the SCALAR unit: divisions by multiply-high with launcher-provided
+//     multipliers on readfirstlane'd values; per-lane halo / output offsets = uniform base + a per-lane
+//     relative offset computed once per kernel, validity by unsigned compares (6 VALU per offset);
+//   * ONE instruction stream for both frequency halves: wave fh = 1 owns its two frequency rows in swapped
+//     order (row 3, row 2), the patch rows each role reads are per-wave LDS offsets, the one sign that
+//     differs is a wave-uniform multiplier in a v_fma -- no branches, no register shuffles (the branchy
+//     form cost 29 v_mov per K step), `keep = t0 + t1`, `send = t1` for both;
+//   * transforms as single v_add / v_sub / v_fma through asm wrappers: the compiler's SLP pass packed them
+//     into v_pk_add_f32, which costs more than two plain adds beside MFMAs (MI355X_MICROARCH.md);
+//   * the next stage's DMA pieces all go out in the first quarter of a K step (they cost nothing to issue;
+//     spread over the step the last ones had no time to land before the barrier).
+// Same LDS layout, same filter packing (the U rows of wave fh = 1 are read in swapped order), same
+// exchange, same BatchNorm statistics, same results bit for bit as conv_wino8_kernel.
+__device__ __forceinline__ float wn_add(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float wn_sub(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float wn_fma(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float wn_fma_s(float s, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(s), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float wn_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x4 wn_sub4(f32x4 a, f32x4 b) { return f32x4{wn_sub(a[0], b[0]), wn_sub(a[1], b[1]), wn_sub(a[2], b[2]), wn_sub(a[3], b[3])}; }
+__device__ __forceinline__ f32x4 wn_add4(f32x4 a, f32x4 b) { return f32x4{wn_add(a[0], b[0]), wn_add(a[1], b[1]), wn_add(a[2], b[2]), wn_add(a[3], b[3])}; }
+__device__ __forceinline__ f32x4 wn_fma4_s(float s, f32x4 b, f32x4 c) { return f32x4{wn_fma_s(s, b[0], c[0]), wn_fma_s(s, b[1], c[1]), wn_fma_s(s, b[2], c[2]), wn_fma_s(s, b[3], c[3])}; }
+__device__ __forceinline__ unsigned wn_udiv(unsigned x, unsigned magic) { return magic ? __umulhi(x, magic) : x; }
+
+template <int TH, int TW, int TNB, int NW = 8, int NT = 3, int CLK = 0>
+__global__ __launch_bounds__(64 * NW, 2) void conv_wino9_kernel(ConvArgs a) {
+  constexpr int CO_T = 16 * NT;
+  constexpr int USL = 16 * EGN_CKQ * CO_T;
+  using G = WinoGeom<TH, TW, TNB>;
+  constexpr int NTH = 64 * NW;
+  constexpr int MTILES = NW / 2;
+  static_assert(TNB * (TH / 2) * (TW / 2) == 16 * MTILES, "one m-tile per wave pair");
+  constexpr int SLOTS = EGN_CKQ * G::PLANE;
+  constexpr int IT = (SLOTS + NTH - 1) / NTH;
+  constexpr int BUF = SLOTS;
+  constexpr int UIT = USL / NTH;
+  constexpr int NPIECE = IT + UIT;
+  static_assert(SLOTS % 64 == 0 && USL % NTH == 0, "whole-wave DMA pieces");
+  static_assert(NW * 2 * NT * 64 <= USL, "the partial exchange fits in one U stage buffer");
+  extern __shared__ float4 smem[];
+  float4* sU = smem;
+  float4* sH = smem + 2 * USL;
+  double* sS = reinterpret_cast<double*>(smem + 2 * USL + 2 * BUF);
+  // CLK (tools/wino_clk.py only): s_memtime stamps like conv_wino8_kernel's ABL & 32 build, `res` = the stamp buffer
+  unsigned long long* sT = reinterpret_cast<unsigned long long*>(sS + NW * 2 * CO_T);
+  constexpr int W9_NTK = 48;
+  int ntk = 0;
+#define W9_CLK()                                                                     \
+  {                                                                                  \
+    if constexpr (CLK != 0) {                                                        \
+      if (lane == 0 && ntk < W9_NTK) sT[wave * W9_NTK + ntk] = __builtin_readcyclecounter(); \
+      ++ntk;                                                                         \
+    }                                                                                \
+  }
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = wave % MTILES;
+  const int fh = wave / MTILES;
+  const int li = lane & 15;
+  const int kq = lane >> 4;
+  const float sigma = fh == 0 ? 1.f : -1.f;     // wave-uniform sign of the one term that differs between the halves
+
+  const int C = a.Cin, Co = a.Cout;
+  const int nct = Co / CO_T;
+  const int nchunk = a.nchunk;
+
+  const unsigned long long xaddr = reinterpret_cast<unsigned long long>(a.x);
+  const unsigned long long uaddr = reinterpret_cast<unsigned long long>(a.w);
+  const u32x4 rxv = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu,
+                     (unsigned)((size_t)a.N * a.H * a.W * C * 4), 0x00020000u};
+  const u32x4 ruv = {(unsigned)uaddr, (unsigned)(uaddr >> 32) & 0xffffu,
+                     (unsigned)((size_t)nct * nchunk * USL * 16), 0x00020000u};
+  const unsigned out_bytes = (unsigned)((size_t)a.N * a.Ho * a.Wo * Co * 4);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, out_bytes, 0x00020000);
+
+  // ---- per-lane, item-independent: halo slot -> (image, hy, hx) and its byte offset relative to the tile's
+  // origin pixel (n0, iy0, ix0); the tile origin is a wave-uniform base added per item
+  int hyx[IT];        // hy << 16 | hx, -1 = pad slot
+  int hb[IT];         // image within the tile batch (TNB > 1)
+  int hrel[IT];       // ((hb * H + hy) * W + hx) * C * 4 + quad * 16
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int e = it * NTH + tid;
+    const int q = e / G::PLANE;
+    const int m = (e < SLOTS && q < EGN_CKQ) ? G::decode(e - q * G::PLANE) : -1;
+    const int b_ = m >> 16, y_ = (m >> 8) & 255, x_ = m & 255;
+    hyx[it] = m < 0 ? -1 : ((y_ << 16) | x_);
+    hb[it] = m < 0 ? 0 : b_;
+    hrel[it] = m < 0 ? 0 : ((b_ * a.H + y_) * a.W + x_) * C * 4 + q * 16;
+  }
+  // patch rows of this lane's tile; roles (X, Y, Z, W): ta = X - Y, tb = Z + sigma * W
+  //   fh = 0 (rows 0, 1):  T0 = d0 - d2,  T1 = d1 + d2      X = 0, Y = 2, Z = 1, W = 2
+  //   fh = 1 (rows 3, 2):  T3 = d1 - d3,  T2 = d2 - d1      first row = T3: X = 1, Y = 3;  second = T2 = d2 + (-1) d1: Z = 2, W = 1
+  int prow[4];
+  {
+    int pr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pr[r] = kq * G::PLANE + G::patch_base(mt, li, r >> 1) + r * G::ROFF;
+    prow[0] = fh == 0 ? pr[0] : pr[1];
+    prow[1] = fh == 0 ? pr[2] : pr[3];
+    prow[2] = fh == 0 ? pr[1] : pr[2];
+    prow[3] = fh == 0 ? pr[2] : pr[1];
+  }
+  // this wave's two frequency rows in U: first = row (fh ? 3 : 0), second = row (fh ? 2 : 1)
+  const int urow0 = (fh == 0 ? 0 : 3) * 4, urow1 = (fh == 0 ? 1 : 2) * 4;
+  // output pixels of this lane: 4 tiles (MFMA result rows 4kq + r), output row a = fh of each
+  int oyx[4], ob[4], orel[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int og = G::out_tile(mt, 4 * kq + r);
+    const int b_ = og >> 16, y_ = 2 * ((og >> 8) & 255) + fh, x_ = 2 * (og & 255);
+    oyx[r] = (y_ << 16) | x_;
+    ob[r] = b_;
+    orel[r] = (((b_ * a.Ho + y_) * a.Wo + x_) * Co + li) * 4;
+  }
+
+  const int tiles_xy = a.tiles_x * a.tiles_y;
+  const int ntile = tiles_xy * ((a.N + TNB - 1) / TNB);
+  const int nwork = ((ntile + 7) >> 3) * nct * 8;
+  const int gsz = __builtin_amdgcn_readfirstlane((int)gridDim.x);
+
+  // wave-uniform item decode (scalar unit): w -> (tile, ct) -> (tb, ty, tx)
+#define W9_ITEM(Wi, TILE_, CT_, TB_, TY_, TX_)                                   \
+  {                                                                              \
+    const unsigned wi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(Wi));    \
+    const unsigned x_ = wi_ & 7u, q_ = wi_ >> 3;                                 \
+    const unsigned qq_ = wn_udiv(q_, a.mg_nct);                                  \
+    TILE_ = (int)(qq_ * 8u + x_);                                                \
+    CT_ = (int)(q_ - qq_ * (unsigned)nct);                                       \
+    const unsigned tb_ = wn_udiv((unsigned)TILE_, a.mg_txy);                     \
+    const unsigned r_ = (unsigned)TILE_ - tb_ * (unsigned)tiles_xy;              \
+    const unsigned ty_ = wn_udiv(r_, a.mg_tx);                                   \
+    TB_ = (int)tb_; TY_ = (int)ty_; TX_ = (int)(r_ - ty_ * (unsigned)a.tiles_x); \
+  }
+  // halo DMA byte offsets (chunk 0) of a tile: uniform base + per-lane relative offset; pad slots and
+  // out-of-image pixels get the OOB offset (the DMA writes zeros there = the convolution's zero padding)
+#define W9_DOFF(TILE_, TB_, TY_, TX_, OUT)                                                                   \
+  {                                                                                                          \
+    const int n0_ = (TB_)*TNB, iy0_ = (TY_)*TH - 1, ix0_ = (TX_)*TW - 1;                                     \
+    const int base_ = ((n0_ * a.H + iy0_) * a.W + ix0_) * C * 4;                                             \
+    const bool tok_ = (TILE_) < ntile;                                                                       \
+    _Pragma("unroll") for (int it = 0; it < IT; ++it) {                                                      \
+      const unsigned iy_ = (unsigned)(iy0_ + (hyx[it] >> 16)), ix_ = (unsigned)(ix0_ + (hyx[it] & 0xffff));  \
+      bool in_ = tok_ && hyx[it] >= 0 && iy_ < (unsigned)a.H && ix_ < (unsigned)a.W;                         \
+      if (TNB > 1) in_ = in_ && (n0_ + hb[it]) < a.N;                                                        \
+      OUT[it] = in_ ? (unsigned)(base_ + hrel[it]) : EGN_OOB;                                                \
+    }                                                                                                        \
+  }
+#define W9_PIECE(K, P, OFF, CT, CH)                                                                  \
+  {                                                                                                  \
+    if ((K) < IT) {                                                                                  \
+      if ((K)*NTH + wave * 64 < SLOTS)                                                               \
+        wino_dma16(rxv, wino_lds_addr(sH + (P)*BUF + wave * 64) + (K)*NTH * 16, OFF[(K) < IT ? (K) : 0], \
+                   (unsigned)(CH)*64u);                                                              \
+    } else {                                                                                         \
+      wino_dma16(ruv, wino_lds_addr(sU + (P)*USL + wave * 64) + ((K)-IT) * NTH * 16, (unsigned)tid * 16u, \
+                 (unsigned)(((CT)*nchunk + (CH)) * USL) * 16u + ((K)-IT) * NTH * 16);                \
+    }                                                                                                \
+  }
+
+  int w = blockIdx.x;
+  int tile = 0, ct = 0, tb = 0, ty = 0, tx = 0;
+  W9_ITEM(w, tile, ct, tb, ty, tx)
+  const int ct_block = ct;
+  if (a.stats != nullptr) {
+    for (int e = lane; e < 2 * CO_T; e += 64) sS[wave * 2 * CO_T + e] = 0.0;
+  }
+  unsigned doff[IT];
+  W9_DOFF(tile, tb, ty, tx, doff)
+  if (w < nwork) {
+#pragma unroll
+    for (int k_ = 0; k_ < NPIECE; ++k_) W9_PIECE(k_, 0, doff, ct, 0)
+  }
+  int par = 0;
+  bool first = true;
+
+  const float act_lo = (a.act & EGN_ACT_MASK) == EGN_ACT_RELU ? 0.f : -__builtin_inff();
+  const bool has_res = CLK ? false : a.res != nullptr;
+  const unsigned rowpitch = (unsigned)(a.Wo * Co) * 4u, colpitch = (unsigned)Co * 4u;
+  (void)rowpitch;
+  W9_CLK()
+
+  for (; w < nwork; w += gsz) {
+    int tile_n = 0, ct_n = 0, tb_n = 0, ty_n = 0, tx_n = 0;
+    W9_ITEM(w + gsz, tile_n, ct_n, tb_n, ty_n, tx_n)
+    const bool more = (w + gsz) < nwork;
+    unsigned doff_n[IT];
+    W9_DOFF(tile_n, tb_n, ty_n, tx_n, doff_n)
+    unsigned voff[4];
+    {
+      const int n0_ = tb * TNB, oy0_ = ty * TH, ox0_ = tx * TW;
+      const int base_ = (((n0_ * a.Ho + oy0_) * a.Wo + ox0_) * Co + ct * CO_T) * 4;
+      const bool tok_ = tile < ntile;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned oy_ = (unsigned)(oy0_ + (oyx[r] >> 16)), ox_ = (unsigned)(ox0_ + (oyx[r] & 0xffff));
+        bool in_ = tok_ && oy_ < (unsigned)a.Ho && ox_ < (unsigned)a.Wo;
+        if (TNB > 1) in_ = in_ && (n0_ + ob[r]) < a.N;
+        voff[r] = in_ ? (unsigned)(base_ + orel[r]) : EGN_OOB;
+      }
+    }
+    float sc[NT], sh[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      sc[nt] = a.scale[ct * CO_T + nt * 16 + li];
+      sh[nt] = a.shift[ct * CO_T + nt * 16 + li];
+    }
+
+    f32x4 acc[8][NT];
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float rv[4][2][NT];
+
+    for (int c = 0; c < nchunk; ++c) {
+      const bool last = c + 1 == nchunk;
+      asm volatile("" ::: "memory");
+      W9_CLK()
+      if (c == 0 && !first) __builtin_amdgcn_s_waitcnt(0x4078);  // vmcnt(24): all but the last item's stores
+      else __builtin_amdgcn_s_waitcnt(0x0070);                   // vmcnt(0)
+      if constexpr (CLK != 0) { asm volatile("" ::: "memory"); W9_CLK() asm volatile("" ::: "memory"); }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      W9_CLK()
+      first = false;
+      const bool nx_issue = !last || more;
+      const int nx_ct = last ? ct_n : ct, nx_ch = last ? 0 : c + 1;
+      if (last) {        // from here on the pieces belong to the next item's first stage
+#pragma unroll
+        for (int it = 0; it < IT; ++it) doff[it] = doff_n[it];
+      }
+#define W9_NEXT(K)                                         \
+  {                                                        \
+    __builtin_amdgcn_sched_barrier(0x0106);                \
+    if (nx_issue) W9_PIECE(K, par ^ 1, doff, nx_ct, nx_ch) \
+    __builtin_amdgcn_sched_barrier(0x0106);                \
+  }
+      // ---- this wave's two rows of V = B^T d B: ta = X - Y, tb = Z + sigma W, then the column transform.
+      // Plain arithmetic (the file is built with -fno-slp-vectorize: v_pk_add_f32 costs more than two adds
+      // beside MFMAs): the scheduler sinks each V row to its first use, so the MFMAs of row 0 start while row
+      // 1 is still being formed -- asm wrappers pinned all 64 instructions in front of the first MFMA.
+      const float4* hb_ = sH + par * BUF;
+      f32x4 V[8];
+      constexpr int TOPP = 2;                                   // DMA pieces issued at the top of a K step ...
+      constexpr int PERF = (NPIECE - TOPP + 7) / 8;             // ... and after each of the 8 frequencies
+      static_assert(NPIECE <= TOPP + 8 * PERF, "every DMA piece has a slot");
+      {
+        f32x4 dx[4], dy[4], ta[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          dx[cc] = *reinterpret_cast<const f32x4*>(&hb_[prow[0] + cc]);
+          dy[cc] = *reinterpret_cast<const f32x4*>(&hb_[prow[1] + cc]);
+        }
+        W9_NEXT(0) W9_NEXT(1)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) ta[cc] = dx[cc] - dy[cc];
+        V[0] = ta[0] - ta[2]; V[1] = ta[1] + ta[2]; V[2] = ta[2] - ta[1]; V[3] = ta[1] - ta[3];
+      }
+      // (the second row's patch reads stay behind the first row's arithmetic: 32 fewer live registers)
+      asm volatile("" ::: "memory");
+      {
+        f32x4 dz[4], dw[4], tb_[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          dz[cc] = *reinterpret_cast<const f32x4*>(&hb_[prow[2] + cc]);
+          dw[cc] = *reinterpret_cast<const f32x4*>(&hb_[prow[3] + cc]);
+        }
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) tb_[cc] = sigma * dw[cc] + dz[cc];
+        V[4] = tb_[0] - tb_[2]; V[5] = tb_[1] + tb_[2]; V[6] = tb_[2] - tb_[1]; V[7] = tb_[1] - tb_[3];
+      }
+
+      // ---- 8 frequencies x NT co sub-tiles x 4 k-steps ----
+      const float4* ub0 = sU + par * USL + (urow0 * EGN_CKQ + kq) * CO_T + li;
+      const float4* ub1 = sU + par * USL + (urow1 * EGN_CKQ + kq) * CO_T + li;
+      f32x4 bf[2][NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *reinterpret_cast<const f32x4*>(&ub0[nt * 16]);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        if (f + 1 < 8) {
+          const float4* un = (f + 1 < 4 ? ub0 : ub1) + ((f + 1) & 3) * EGN_CKQ * CO_T;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bf[(f + 1) & 1][nt] = *reinterpret_cast<const f32x4*>(&un[nt * 16]);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[f][s], bf[f & 1][nt][s], acc[f][nt], 0, 0, 0);
+#pragma unroll
+        for (int k_ = 0; k_ < PERF; ++k_)
+          if (TOPP + f * PERF + k_ < NPIECE) W9_NEXT(TOPP + f * PERF + k_)
+      }
+#undef W9_NEXT
+      if (last) {
+        asm volatile("" ::: "memory");  // program order DMA -> residual loads (the vmcnt(24) above counts on it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned ro = has_res ? voff[r] : EGN_OOB;
+#pragma unroll
+          for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) rv[r][pb][nt] = wino_load4(rr, ro, pb * colpitch + nt * 64u);
+        }
+      }
+      par ^= 1;
+    }
+
+    W9_CLK()
+    // ---- output transform: t of the wave's first / second frequency row; keep = t0 + t1, send = t1 ----
+    float keep[NT][4][2], send[NT][4][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t00 = acc[0][nt][r] + acc[1][nt][r] + acc[2][nt][r];
+        const float t10 = acc[4][nt][r] + acc[5][nt][r] + acc[6][nt][r];
+        const float t01 = acc[1][nt][r] - acc[2][nt][r] - acc[3][nt][r];
+        const float t11 = acc[5][nt][r] - acc[6][nt][r] - acc[7][nt][r];
+        keep[nt][r][0] = t00 + t10;
+        keep[nt][r][1] = t01 + t11;
+        send[nt][r][0] = t10;
+        send[nt][r][1] = t11;
+      }
+    {
+      float4* xch = sU + (par ^ 1) * USL;
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int k4 = 0; k4 < 2 * NT; ++k4) {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int idx = k4 * 4 + e;
+          v[e] = send[idx >> 3][(idx >> 1) & 3][idx & 1];
+        }
+        *reinterpret_cast<f32x4*>(&xch[(wave * 2 * NT + k4) * 64 + lane]) = v;
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // fh = 0: Y0 = (t0 + t1) + t2 = keep + recv;  fh = 1: Y1 = t1 - (t2 + t3) = recv - keep = sigma * keep + recv
+#pragma unroll
+      for (int k4 = 0; k4 < 2 * NT; ++k4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&xch[((wave ^ MTILES) * 2 * NT + k4) * 64 + lane]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int idx = k4 * 4 + e;
+          keep[idx >> 3][(idx >> 1) & 3][idx & 1] = sigma * keep[idx >> 3][(idx >> 1) & 3][idx & 1] + v[e];
+        }
+      }
+    }
+    W9_CLK()
+    float st1[NT], st2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) st1[nt] = st2[nt] = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+          float v = fmaxf(keep[nt][r][pb] * sc[nt] + sh[nt] + rv[r][pb][nt], act_lo);
+          wino_store4(ry, voff[r], pb * colpitch + nt * 64u, v);
+          if (a.stats != nullptr && voff[r] != EGN_OOB) { st1[nt] += v; st2[nt] += v * v; }
+        }
+    if (a.stats != nullptr) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        st1[nt] += __shfl_xor(st1[nt], 16);
+        st1[nt] += __shfl_xor(st1[nt], 32);
+        st2[nt] += __shfl_xor(st2[nt], 16);
+        st2[nt] += __shfl_xor(st2[nt], 32);
+      }
+      if (kq == 0) {
+        double* srow = sS + wave * 2 * CO_T + li;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          srow[nt * 16] += (double)st1[nt];
+          srow[CO_T + nt * 16] += (double)st2[nt];
+        }
+      }
+    }
+    W9_CLK()
+    tile = tile_n; ct = ct_n; tb = tb_n; ty = ty_n; tx = tx_n;
+  }
+  if constexpr (CLK != 0) {
+    __syncthreads();
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res)) +
+                              (size_t)blockIdx.x * (NW * W9_NTK + 1);
+    for (int e = tid; e < NW * W9_NTK; e += NTH) out[1 + e] = sT[e];
+    if (tid == 0) out[0] = (unsigned long long)ntk;
+  }
+  if (a.stats != nullptr) {
+    __syncthreads();
+    double* row = a.stats + (size_t)blockIdx.x * 2 * Co;
+    for (int e = tid; e < 2 * Co; e += NTH) {
+      const int which = e / Co, c = e - which * Co;
+      const int cl = c - ct_block * CO_T;
+      double v = 0.0;
+      if (cl >= 0 && cl < CO_T) {
+        for (int k = 0; k < NW; ++k) v += sS[(k * 2 + which) * CO_T + cl];
+      }
+      row[e] = v;
+    }
+  }
+#undef W9_ITEM
+#undef W9_DOFF
+#undef W9_PIECE
+#undef W9_CLK
+}
+
 template <int TH, int TW, int TNB, int ABL = 0>
 static int wino_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
   static bool raised[EGN_MAX_DEVICES];
@@ -950,10 +1382,34 @@ static int wino8_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
   return EGN_E_BADARG;
 }
 
+static unsigned wino_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+
+template <int TH, int TW, int TNB, int NW, int NT, int CLK = 0>
+static int wino9_launch_nt(ConvArgs a, size_t lds, hipStream_t stream) {
+  static bool raised[EGN_MAX_DEVICES];
+  if (egn_first_use_on_device(raised)) {
+    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino9_kernel<TH, TW, TNB, NW, NT, CLK>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+  }
+  a.mg_nct = wino_magic(a.Cout / (16 * NT));
+  a.mg_txy = wino_magic(a.tiles_x * a.tiles_y);
+  a.mg_tx = wino_magic(a.tiles_x);
+  const int grid = wino8_grid(a, TNB);
+  hipLaunchKernelGGL((conv_wino9_kernel<TH, TW, TNB, NW, NT, CLK>), dim3(grid), dim3(64 * NW), lds, stream, a);
+  return (int)hipGetLastError();
+}
+template <int TH, int TW, int TNB, int NW = 8>
+static int wino9_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
+  if (egn_wino_cot(a.Cout) == 48) return wino9_launch_nt<TH, TW, TNB, NW, 3>(a, lds, stream);
+  if (egn_wino_cot(a.Cout) == 32) return wino9_launch_nt<TH, TW, TNB, NW, 2>(a, lds, stream);
+  return EGN_E_BADARG;
+}
+
 // rows of the BatchNorm partial table a launch writes (0 = this variant has no fused statistics)
 int egn_conv_wino_stats_rows(const ConvArgs& a, int variant) {
-  const int v = variant & 15;
+  int v = variant & 15;
   if ((variant >> 4) || v < 2) return 0;
+  if (v >= 6) v -= 4;              // variants 6..9 = conv_wino9_kernel on the geometries of 2..5
   const int tnb = v == 3 ? 4 : (v == 4 ? 2 : 1);
   return wino8_grid(a, tnb);       // one partial row per block
 }
@@ -961,14 +1417,15 @@ int egn_conv_wino_stats_rows(const ConvArgs& a, int variant) {
 // variant 0: 16 x 16 pixel tile of one image; variant 1: four 8 x 8 images (the 8 x 8 maps);
 // variants 2 / 3: the same two geometries on the 8-wave kernel; variant 4: two 8 x 8 images, 4 waves
 size_t egn_conv_wino_lds_bytes(int variant, int cout) {
-  const int v = variant & 15;
+  int v = variant & 15;
+  if (v >= 6) v -= 4;              // conv_wino9_kernel: the LDS image of conv_wino8_kernel
   size_t halo = (v & 1) ? WinoDims<8, 8, 4>::BUF : WinoDims<16, 16, 1>::BUF;
   if (v >= 2) halo = (v & 1) ? EGN_CKQ * WinoGeom<8, 8, 4>::PLANE : EGN_CKQ * WinoGeom<16, 16, 1>::PLANE;
   if (v == 4) halo = EGN_CKQ * WinoGeom<8, 8, 2>::PLANE;
   if (v == 5) halo = EGN_CKQ * WinoGeom<8, 16, 1>::PLANE;
   const int cot = v >= 2 && egn_wino_cot(cout) ? egn_wino_cot(cout) : WN_CO;   // the 4-wave kernel: 48 only
   const size_t stats = v >= 2 ? (size_t)((v == 4 || v == 5) ? 4 : 8) * 2 * cot * sizeof(double) : 0;
-  const size_t stamps = (variant >> 4) == 4 && v >= 2 ? 8 * 48 * sizeof(unsigned long long) : 0;   // ABL & 32 builds
+  const size_t stamps = (variant >> 4) == 4 && v >= 2 ? 8 * 48 * sizeof(unsigned long long) : 0;   // stamp builds
   return (2 * (size_t)(16 * EGN_CKQ * cot) + 2 * halo) * 16 + stats + stamps;
 }
 int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t stream) {
@@ -980,10 +1437,15 @@ int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t
     case 3: return wino8_launch<8, 8, 4>(a, lds, stream);
     case 4: return wino8_launch<8, 8, 2, 0, 4>(a, lds, stream);
     case 5: return wino8_launch<8, 16, 1, 0, 4>(a, lds, stream);
+    case 6: return wino9_launch<16, 16, 1>(a, lds, stream);
+    case 7: return wino9_launch<8, 8, 4>(a, lds, stream);
+    case 8: return wino9_launch<8, 8, 2, 4>(a, lds, stream);
+    case 9: return wino9_launch<8, 16, 1, 4>(a, lds, stream);
     case 0x12: return wino8_launch<16, 16, 1, 16>(a, lds, stream);
     case 0x22: return wino8_launch<16, 16, 1, 7>(a, lds, stream);
     case 0x32: return wino8_launch<16, 16, 1, 3>(a, lds, stream);
     case 0x42: return wino8_launch<16, 16, 1, 32>(a, lds, stream);   // timeline stamps (tools/wino_clk.py)
+    case 0x46: return egn_wino_cot(a.Cout) == 48 ? wino9_launch_nt<16, 16, 1, 8, 3, 1>(a, lds, stream) : EGN_E_BADARG;
     case 0x10: return wino_launch<16, 16, 1, 15>(a, lds, stream);
     case 0x20: return wino_launch<16, 16, 1, 7>(a, lds, stream);
     case 0x30: return wino_launch<16, 16, 1, 3>(a, lds, stream);

@@ -45,6 +45,9 @@ struct ConvArgs {
   // training: per-(tile, wave) partial column sums of the stored outputs, [row][2][Cout] doubles
   // (sum, sum of squares), written by the kernels that support it (conv_wino8_kernel); NULL = off
   double* stats;
+  // conv_wino9_kernel: multipliers ceil(2^32 / d) for the item index divisions by nct, tiles_x * tiles_y and
+  // tiles_x (0 = the divisor is 1), set by its launcher -- the divisions run on the scalar unit
+  unsigned mg_nct, mg_txy, mg_tx;
 };
 
 struct ConvConfig {

@@ -98,7 +98,41 @@ extern "C" int egn_transpose_f32(const float* src, int R, int C, int ld_src, flo
 //   mode 2: BN backward sums    : s1[c] = sum dpre, s2[c] = sum dpre * xhat
 //           dpre = dy * (mask? mask*keep_scale : 1) * gate,  gate = (gamma*xhat + beta + res > 0) or 1
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// Dropout keep masks drawn IN the kernels (FCmodel.py:24, 38-41: nn.Dropout(p) after every ReLU of the lifter):
+// Philox4x32-10 (Salmon et al., SC'11) keyed by the seed, counter = (float4 group index, layer, *step).  The
+// forward kernel and the two backward kernels of a unit regenerate the same mask from the same arguments, so no
+// mask tensor exists and no RNG kernel runs inside the step; `step` is read from device memory (hipGraph-safe:
+// the optimizer's step counter).  element kept  <=>  its 32-bit draw >= p * 2^32.
+// ---------------------------------------------------------------------------
+struct DropArgs {
+  unsigned thresh;           // p * 2^32 (0 = no RNG dropout)
+  unsigned seed_lo, seed_hi;
+  unsigned layer;
+  const int* step;
+};
+
+__device__ __forceinline__ void egn_philox4(unsigned k0, unsigned k1, unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                            unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+// keep mask (0 / 1) of float4 group e4
+__device__ __forceinline__ void egn_drop_mask4(const DropArgs& d, unsigned step, size_t e4, float (&m)[4]) {
+  unsigned r[4];
+  egn_philox4(d.seed_lo, d.seed_hi, (unsigned)e4, (unsigned)(e4 >> 32), d.layer, step, r);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) m[k] = r[k] >= d.thresh ? 1.f : 0.f;
+}
+
 struct ColArgs {
+  DropArgs drop;       // mode 2: keep mask drawn in the kernel when mask == NULL and drop.thresh != 0
   const float* a;      // z (mode 1, 2) or the matrix to sum (mode 0)
   const float* dy;     // mode 2
   const float* mask;   // mode 2, optional dropout keep mask (0/1)
@@ -146,6 +180,8 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(ColArgs p, doubl
     }
     float f0[4] = {0, 0, 0, 0}, f1[4] = {0, 0, 0, 0};
     int cnt = 0;
+    const bool rng = p.mode == 2 && !p.mask && p.drop.thresh != 0;
+    const unsigned dstep = rng ? (unsigned)*p.drop.step : 0u;
     // four rows per round: their loads are issued together (one block per CU and a chain
     // of dependent round trips otherwise -- the kernel is latency bound, not bandwidth bound)
     for (int r = r_lo + rl; r < r_hi; r += 4 * RL) {
@@ -177,6 +213,12 @@ __global__ __launch_bounds__(256) void colreduce_partial_kernel(ColArgs p, doubl
           if (p.mask) {
             d[0] *= m4[u].x * p.keep_scale; d[1] *= m4[u].y * p.keep_scale;
             d[2] *= m4[u].z * p.keep_scale; d[3] *= m4[u].w * p.keep_scale;
+          } else if (rng) {
+            float mk[4];
+            const int rr = r + u * RL;
+            egn_drop_mask4(p.drop, dstep, ((size_t)(rr < r_hi ? rr : r) * p.ld + c0) / 4, mk);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d[k] *= mk[k] * p.keep_scale;
           }
           float rs[4] = {0.f, 0.f, 0.f, 0.f};
           if (p.res) { rs[0] = r4[u].x; rs[1] = r4[u].y; rs[2] = r4[u].z; rs[3] = r4[u].w; }
@@ -320,7 +362,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ beta,
                                                          const float* __restrict__ mask, float keep_scale, int relu,
                                                          const float* __restrict__ res, float* __restrict__ y,
-                                                         int rows, int cols, int ld) {
+                                                         int rows, int cols, int ld, DropArgs drop) {
   // a thread keeps ONE float4 column group for all its rows, so the per-channel
   // parameters are loaded once into registers; a block covers up to 256 column groups
   // and 256 / groups rows per step: consecutive lanes read consecutive 16-byte pieces of
@@ -342,6 +384,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     pg[k] = ok[k] ? gamma[c] : 0.f;
     pb[k] = ok[k] ? beta[c] : 0.f;
   }
+  const bool rng = !mask && drop.thresh != 0;
+  const unsigned dstep = rng ? (unsigned)*drop.step : 0u;
   for (int r = blockIdx.x * rpi + r_local; r < rows; r += gridDim.x * rpi) {
     const size_t e = (size_t)r * ld4 + c4;
     const float4 v = reinterpret_cast<const float4*>(z)[e];
@@ -349,7 +393,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     float out[4];
     float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
     if (mask) mk = reinterpret_cast<const float4*>(mask)[e];
-    const float mka[4] = {mk.x, mk.y, mk.z, mk.w};
+    float mka[4] = {mk.x, mk.y, mk.z, mk.w};
+    if (rng) egn_drop_mask4(drop, dstep, e, mka);
     float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (res) rv = reinterpret_cast<const float4*>(res)[e];
     const float ra[4] = {rv.x, rv.y, rv.z, rv.w};
@@ -360,7 +405,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
         o = pg[k] * ((in[k] - pm[k]) * pi[k]) + pb[k] + ra[k];
         if (relu == 2) o = o > 0.f ? o : 0.01f * o;   // nn.LeakyReLU() default slope (FCmodel.py:19-22)
         else if (relu) o = fmaxf(o, 0.f);
-        if (mask) o *= mka[k] * keep_scale;
+        if (mask || rng) o *= mka[k] * keep_scale;
       }
       out[k] = o;
     }
@@ -378,12 +423,35 @@ static dim3 rowstream_grid(int rows, int ld) {
   return dim3(gx, gy);
 }
 
+static DropArgs make_drop(float p, unsigned long long seed, const int* step, int layer) {
+  DropArgs d = {};
+  if (p > 0.f && step) {
+    const double t = (double)p * 4294967296.0;
+    d.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+    if (d.thresh == 0) d.thresh = 1;
+    d.seed_lo = (unsigned)seed; d.seed_hi = (unsigned)(seed >> 32);
+    d.layer = (unsigned)layer; d.step = step;
+  }
+  return d;
+}
+
 extern "C" int egn_bn_act_fwd_f32(const float* z, const float* mean, const float* invstd, const float* gamma,
                                   const float* beta, const float* mask, float keep_scale, int relu,
                                   const float* res, float* y, int rows, int cols, int ld, void* stream) {
   if (rows <= 0 || cols <= 0 || ld % 4 || ld < cols) return EGN_E_BADARG;
   hipLaunchKernelGGL(bn_act_fwd_kernel, rowstream_grid(rows, ld), dim3(256), 0, (hipStream_t)stream, z, mean, invstd,
-                     gamma, beta, mask, keep_scale, relu, res, y, rows, cols, ld);
+                     gamma, beta, mask, keep_scale, relu, res, y, rows, cols, ld, DropArgs{});
+  return (int)hipGetLastError();
+}
+// ... with the dropout keep mask drawn in the kernel (Philox on (seed; element, layer, *step_dev)); keep_scale = 1/(1-p)
+extern "C" int egn_bn_act_fwd_drop_f32(const float* z, const float* mean, const float* invstd, const float* gamma,
+                                       const float* beta, float p, unsigned long long seed, const int* step_dev,
+                                       int layer, int relu, const float* res, float* y, int rows, int cols, int ld,
+                                       void* stream) {
+  if (rows <= 0 || cols <= 0 || ld % 4 || ld < cols || !(p >= 0.f && p < 1.f) || (p > 0.f && !step_dev)) return EGN_E_BADARG;
+  hipLaunchKernelGGL(bn_act_fwd_kernel, rowstream_grid(rows, ld), dim3(256), 0, (hipStream_t)stream, z, mean, invstd,
+                     gamma, beta, (const float*)nullptr, 1.0f / (1.0f - p), relu, res, y, rows, cols, ld,
+                     make_drop(p, seed, step_dev, layer));
   return (int)hipGetLastError();
 }
 
@@ -399,6 +467,20 @@ extern "C" int egn_bn_bwd_sums_f32(const float* dy, const float* z, const float*
   return launch_col(p, (double*)ws, stream);
 }
 
+extern "C" int egn_bn_bwd_sums_drop_f32(const float* dy, const float* z, float p, unsigned long long seed,
+                                        const int* step_dev, int layer, const float* mean, const float* invstd,
+                                        const float* gamma, const float* beta, int relu, const float* res, int rows,
+                                        int cols, int ld, float* dbeta, float* dgamma, void* ws, void* stream) {
+  if (!(p >= 0.f && p < 1.f) || (p > 0.f && !step_dev)) return EGN_E_BADARG;
+  ColArgs q = {};
+  q.drop = make_drop(p, seed, step_dev, layer);
+  q.res = res;
+  q.a = z; q.dy = dy; q.keep_scale = 1.0f / (1.0f - p); q.mean = mean; q.invstd = invstd;
+  q.gamma = gamma; q.beta = beta; q.relu = relu; q.out0 = dbeta; q.out1 = dgamma;
+  q.rows = rows; q.cols = cols; q.ld = ld; q.mode = 2;
+  return launch_col(q, (double*)ws, stream);
+}
+
 // dz = gamma * invstd * (dpre - dbeta/rows - xhat * dgamma/rows)   (batch-stat BN backward)
 __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                         const float* __restrict__ mask, float keep_scale,
@@ -409,7 +491,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict_
                                                         const float* __restrict__ res,
                                                         const float* __restrict__ dbeta,
                                                         const float* __restrict__ dgamma, float* __restrict__ dz,
-                                                        float* __restrict__ dres, int rows, int cols, int ld) {
+                                                        float* __restrict__ dres, int rows, int cols, int ld,
+                                                        DropArgs drop) {
   // same row-streaming thread mapping as bn_act_fwd_kernel: per-channel values in registers
   const int ld4 = ld / 4;
   const float inv_rows = 1.0f / (float)rows;
@@ -431,6 +514,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict_
     pdb[k] = ok[k] ? dbeta[c] : 0.f;
     pdg[k] = ok[k] ? dgamma[c] : 0.f;
   }
+  const bool rng = !mask && drop.thresh != 0;
+  const unsigned dstep = rng ? (unsigned)*drop.step : 0u;
   for (int r = blockIdx.x * rpi + r_local; r < rows; r += gridDim.x * rpi) {
     const size_t e = (size_t)r * ld4 + c4;
     const float4 zv = reinterpret_cast<const float4*>(z)[e];
@@ -439,7 +524,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict_
     if (mask) mk = reinterpret_cast<const float4*>(mask)[e];
     const float zi[4] = {zv.x, zv.y, zv.z, zv.w};
     const float di[4] = {dv.x, dv.y, dv.z, dv.w};
-    const float mi[4] = {mk.x, mk.y, mk.z, mk.w};
+    float mi[4] = {mk.x, mk.y, mk.z, mk.w};
+    if (rng) egn_drop_mask4(drop, dstep, e, mi);
     float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (res) rv = reinterpret_cast<const float4*>(res)[e];
     const float ri[4] = {rv.x, rv.y, rv.z, rv.w};
@@ -450,7 +536,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dz_kernel(const float* __restrict_
       if (ok[k]) {
         const float xhat = (zi[k] - pm[k]) * pi[k];
         d = di[k];
-        if (mask) d *= mi[k] * keep_scale;
+        if (mask || rng) d *= mi[k] * keep_scale;
         if (relu && !(pg[k] * xhat + pb[k] + ri[k] > 0.f)) d = relu == 2 ? 0.01f * d : 0.f;
         o = pg[k] * pi[k] * (d - pdb[k] * inv_rows - xhat * pdg[k] * inv_rows);
       }
@@ -468,7 +554,35 @@ extern "C" int egn_bn_bwd_dz_f32(const float* dy, const float* z, const float* m
                                  float* dres, int rows, int cols, int ld, void* stream) {
   if (rows <= 0 || cols <= 0 || ld % 4 || ld < cols) return EGN_E_BADARG;
   hipLaunchKernelGGL(bn_bwd_dz_kernel, rowstream_grid(rows, ld), dim3(256), 0, (hipStream_t)stream, dy, z, mask,
-                     keep_scale, mean, invstd, gamma, beta, relu, res, dbeta, dgamma, dz, dres, rows, cols, ld);
+                     keep_scale, mean, invstd, gamma, beta, relu, res, dbeta, dgamma, dz, dres, rows, cols, ld,
+                     DropArgs{});
+  return (int)hipGetLastError();
+}
+extern "C" int egn_bn_bwd_dz_drop_f32(const float* dy, const float* z, float p, unsigned long long seed,
+                                      const int* step_dev, int layer, const float* mean, const float* invstd,
+                                      const float* gamma, const float* beta, int relu, const float* res,
+                                      const float* dbeta, const float* dgamma, float* dz, float* dres, int rows,
+                                      int cols, int ld, void* stream) {
+  if (rows <= 0 || cols <= 0 || ld % 4 || ld < cols || !(p >= 0.f && p < 1.f) || (p > 0.f && !step_dev)) return EGN_E_BADARG;
+  hipLaunchKernelGGL(bn_bwd_dz_kernel, rowstream_grid(rows, ld), dim3(256), 0, (hipStream_t)stream, dy, z,
+                     (const float*)nullptr, 1.0f / (1.0f - p), mean, invstd, gamma, beta, relu, res, dbeta, dgamma, dz,
+                     dres, rows, cols, ld, make_drop(p, seed, step_dev, layer));
+  return (int)hipGetLastError();
+}
+// the keep mask the *_drop_* kernels draw, written out (tests; tools): mask[rows][ld] of 0 / 1
+__global__ __launch_bounds__(256) void drop_mask_kernel(float4* __restrict__ mask, size_t n4, DropArgs drop) {
+  const unsigned dstep = (unsigned)*drop.step;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (size_t)gridDim.x * blockDim.x) {
+    float m[4];
+    egn_drop_mask4(drop, dstep, e, m);
+    mask[e] = make_float4(m[0], m[1], m[2], m[3]);
+  }
+}
+extern "C" int egn_dropout_mask_f32(float* mask, long n, float p, unsigned long long seed, const int* step_dev, int layer,
+                                    void* stream) {
+  if (!mask || n <= 0 || n % 4 || !(p > 0.f && p < 1.f) || !step_dev) return EGN_E_BADARG;
+  hipLaunchKernelGGL(drop_mask_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<float4*>(mask), (size_t)(n / 4), make_drop(p, seed, step_dev, layer));
   return (int)hipGetLastError();
 }
 

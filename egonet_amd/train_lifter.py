@@ -40,6 +40,9 @@ class LifterTrainStep(object):
     # dense layers on csrc/gemm.hip where the shape allows (EGONET_AMD_GEMM=0: the conv-kernel route everywhere);
     # tile variant per form (NT, NN, TN), the fastest of tools/gemm_probe.py on 4096 x 1024 x 1024 [MI355X r3]:
     # NT 128x128 8 waves 2 stages 69 us, NN 128x128 8 waves 68 us, TN 128x128 4 waves split-K 4 74.5 us
+    # dropout keep masks drawn inside the BatchNorm / ReLU kernels (EGONET_AMD_RNG_DROPOUT=0: a torch-generated mask
+    # tensor per unit, the round-2 route)
+    rng_dropout = os.environ.get('EGONET_AMD_RNG_DROPOUT', '1') != '0'
     use_gemm = os.environ.get('EGONET_AMD_GEMM', '1') != '0'
     gemm_variant = [int(v) for v in os.environ.get('EGONET_AMD_GEMM_VARIANTS', '3,0,1').split(',')]
 
@@ -64,6 +67,10 @@ class LifterTrainStep(object):
         # parameters / gradients / Adam moments as views of flat buffers: one Adam launch,
         # one all-reduce buffer, step counter and lr on the device (hipGraph-safe)
         self.flat = FlatParams(model.parameters())
+        # in-kernel dropout: the seed comes from torch's generator at construction (torch.manual_seed makes a run
+        # reproducible), the per-iteration counter is the optimizer's device-resident step counter
+        self.drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        self.drop_step = self.flat.step_dev
         # every Linear weight as a 1x1 conv filter [out, in, 1, 1] (views of the flat buffer): from the second
         # step on all forward / data-gradient packs of the iteration are ONE launch (train_hrnet.PackedFilters)
         from .train_hrnet import PackedFilters
@@ -241,13 +248,21 @@ class LifterTrainStep(object):
                                           _lib.ptr(varu), _lib.ptr(u.bn.running_mean),
                                           _lib.ptr(u.bn.running_var), mom, _lib.ptr(ws), st), 'bn_stats')
             mask = None
-            if self.p > 0:
-                mask = buf('mask%d' % ui, B, u.outf)
-                mask.bernoulli_(1.0 - self.p)          # keep mask (0/1), one launch, capture-aware RNG
             y = buf('y%d' % ui, B, u.outf)
-            _lib.check(L.egn_bn_act_fwd_f32(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(u.bn.weight),
-                                            _lib.ptr(u.bn.bias), _lib.ptr(mask), keep, self.act, None, _lib.ptr(y), B,
-                                            u.outf, u.outf, st), 'bn_act_fwd')
+            if self.p > 0 and self.rng_dropout:
+                # keep mask drawn inside the kernel (Philox on (seed; element, unit, step)): the backward kernels
+                # regenerate it -- no mask tensor, no RNG kernel in the step
+                _lib.check(L.egn_bn_act_fwd_drop_f32(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(u.bn.weight),
+                                                     _lib.ptr(u.bn.bias), self.p, self.drop_seed, _lib.ptr(self.drop_step),
+                                                     ui, self.act, None, _lib.ptr(y), B, u.outf, u.outf, st),
+                           'bn_act_fwd_drop')
+            else:
+                if self.p > 0:
+                    mask = buf('mask%d' % ui, B, u.outf)
+                    mask.bernoulli_(1.0 - self.p)          # keep mask (0/1), one launch, capture-aware RNG
+                _lib.check(L.egn_bn_act_fwd_f32(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(u.bn.weight),
+                                                _lib.ptr(u.bn.bias), _lib.ptr(mask), keep, self.act, None, _lib.ptr(y), B,
+                                                u.outf, u.outf, st), 'bn_act_fwd')
             saved.append((a, ld_a, z, mean, istd, mask))
             if ui == 0:
                 block_in = y
@@ -296,15 +311,27 @@ class LifterTrainStep(object):
             if ui == 0 or ui % 2 == 0:
                 d_y = d_block_out     # unit 0 and the second unit of a block see the block-output gradient
             dbeta, dgamma = g(u.bn.bias), g(u.bn.weight)
-            _lib.check(L.egn_bn_bwd_sums_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
-                                             _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), self.act, None,
-                                             B, u.outf, u.outf, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(ws),
-                                             st), 'bn_bwd_sums')
             dz = buf('dz%d' % ui, B, u.outf)     # per unit: the side stream reads it until the join
-            _lib.check(L.egn_bn_bwd_dz_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
-                                           _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), self.act, None,
-                                           _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(dz), None, B, u.outf,
-                                           u.outf, st), 'bn_bwd_dz')
+            if keep != 1.0 and mask is None:     # the forward drew its mask in the kernel: same (seed, unit, step) here
+                _lib.check(L.egn_bn_bwd_sums_drop_f32(_lib.ptr(d_y), _lib.ptr(z), self.p, self.drop_seed,
+                                                      _lib.ptr(self.drop_step), ui, _lib.ptr(mean), _lib.ptr(istd),
+                                                      _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), self.act, None, B,
+                                                      u.outf, u.outf, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(ws), st),
+                           'bn_bwd_sums_drop')
+                _lib.check(L.egn_bn_bwd_dz_drop_f32(_lib.ptr(d_y), _lib.ptr(z), self.p, self.drop_seed,
+                                                    _lib.ptr(self.drop_step), ui, _lib.ptr(mean), _lib.ptr(istd),
+                                                    _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), self.act, None,
+                                                    _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(dz), None, B, u.outf,
+                                                    u.outf, st), 'bn_bwd_dz_drop')
+            else:
+                _lib.check(L.egn_bn_bwd_sums_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
+                                                 _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), self.act,
+                                                 None, B, u.outf, u.outf, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(ws),
+                                                 st), 'bn_bwd_sums')
+                _lib.check(L.egn_bn_bwd_dz_f32(_lib.ptr(d_y), _lib.ptr(z), _lib.ptr(mask), keep, _lib.ptr(mean),
+                                               _lib.ptr(istd), _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), self.act, None,
+                                               _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(dz), None, B, u.outf,
+                                               u.outf, st), 'bn_bwd_dz')
             self._wgrad(a_in, ld_in, u.inf, dz, u.outf, u.outf, B, g(u.fc.weight), keep=(a_in, dz) if fresh else None)
             _lib.check(L.egn_colsum_f32(_lib.ptr(dz), B, u.outf, u.outf, _lib.ptr(g(u.fc.bias)), _lib.ptr(ws), st))
             if sess is not None:

@@ -312,6 +312,25 @@ int egn_bn_bwd_dz_f32(const float* dy, const float* z, const float* mask,
                       const float* res, const float* dbeta, const float* dgamma,
                       float* dz, float* dres, int rows, int cols, int ld,
                       void* stream);
+/* The same three with the inverted-dropout keep mask DRAWN IN THE KERNEL (nn.Dropout(p) after every ReLU of the
+ * lifter, libs/model/FCmodel.py:24, 38-41): Philox4x32-10 keyed by `seed`, counter = (float4 group index of the
+ * element, `layer`, *step_dev); element kept <=> its 32-bit draw >= p * 2^32; kept values are scaled by 1/(1-p).
+ * Forward and backward regenerate the same mask from the same (seed, layer, *step_dev): no mask tensor, no RNG
+ * kernel inside a training step; *step_dev is read on the device (the optimizer's step counter: hipGraph-safe).
+ * egn_dropout_mask_f32 writes the mask those kernels use (tests). */
+int egn_bn_act_fwd_drop_f32(const float* z, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, float p, unsigned long long seed, const int* step_dev, int layer,
+                            int relu, const float* res, float* y, int rows, int cols, int ld, void* stream);
+int egn_bn_bwd_sums_drop_f32(const float* dy, const float* z, float p, unsigned long long seed, const int* step_dev,
+                             int layer, const float* mean, const float* invstd, const float* gamma,
+                             const float* beta, int relu, const float* res, int rows, int cols, int ld,
+                             float* dbeta, float* dgamma, void* ws, void* stream);
+int egn_bn_bwd_dz_drop_f32(const float* dy, const float* z, float p, unsigned long long seed, const int* step_dev,
+                           int layer, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           int relu, const float* res, const float* dbeta, const float* dgamma, float* dz,
+                           float* dres, int rows, int cols, int ld, void* stream);
+int egn_dropout_mask_f32(float* mask, long n, float p, unsigned long long seed, const int* step_dev, int layer,
+                         void* stream);
 int egn_add_f32(const float* a, const float* b, float* y, long n, void* stream);
 /* *loss += weight*mean((pred-tgt)^2) (zero it first);
  * dpred (= or, with accumulate, +=) weight*2(pred-tgt)/(rows*cols).

@@ -23,6 +23,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', required=True)
     ap.add_argument('--match', default='')
+    ap.add_argument('--retime', default='', help='comma list of cfg ids to measure again in this run (same box, same '
+                    'session as the new ones: boxes of the pool differ by a few per cent)')
     a = ap.parse_args()
     with open(tuner.TABLE_PATH) as f:
         table = json.load(f)
@@ -33,7 +35,8 @@ def main():
         if not m or a.match not in key:
             continue
         args = tuple(int(v) for v in m.groups())
-        have = {int(k) for k in table[key].get('ms', {})}
+        again = {int(v) for v in a.retime.split(',') if v}
+        have = {int(k) for k in table[key].get('ms', {})} - again
         _, times = tuner.tune(dev, args, skip=have)
         if not times:
             continue

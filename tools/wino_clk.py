@@ -16,7 +16,7 @@ from egonet_amd import _lib, engine  # noqa: E402
 NTK = 48
 
 
-def run(shape):
+def run(shape, cfg):
     L = _lib.lib()
     n, h, w, cin, cout = shape
     st = _lib.current_stream()
@@ -30,15 +30,15 @@ def run(shape):
     stamps = torch.zeros(256 * (8 * NTK + 1) * 2, dtype=torch.float32, device='cuda')     # u64 view
     for _ in range(3):
         rc = L.egn_conv2d_f32(_lib.ptr(x), _lib.ptr(wu), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(stamps), _lib.ptr(y),
-                              n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 1, 0, 58, st)
+                              n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 1, 0, cfg, st)
         assert rc == 0, rc
     torch.cuda.synchronize()
     t = stamps.cpu().numpy().view(np.uint64).reshape(256, 8 * NTK + 1)
     nt = int(t[0, 0])
     nchunk = cin // 16
     per_item = 3 * nchunk + 3
-    print('shape %s: %d stamps per wave, %d K steps per item, %d items in the stamp window' % (
-        shape, nt, nchunk, (min(nt, NTK) - 1) // per_item))
+    print('cfg %d shape %s: %d stamps per wave, %d K steps per item, %d items in the stamp window' % (
+        cfg, shape, nt, nchunk, (min(nt, NTK) - 1) // per_item))
     tk = t[:, 1:].reshape(256, 8, NTK).astype(np.int64)
     used = min(nt, NTK)
     nitems = (used - 1) // per_item
@@ -81,4 +81,5 @@ if __name__ == '__main__':
         [(64, 64, 64, 48, 48), (64, 32, 32, 96, 96), (64, 16, 16, 192, 192)]
     torch.cuda.set_device(0)
     for s in shapes:
-        run(s)
+        for cfg in (58, 63):          # conv_wino8_kernel / conv_wino9_kernel stamp builds
+            run(s, cfg)
