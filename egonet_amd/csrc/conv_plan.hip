@@ -20,6 +20,9 @@ int egn_conv_launch_staged(const ConvArgs& a, int cfg_id, size_t lds, hipStream_
 int egn_conv_launch_dma(const ConvArgs& a, int cfg_id, size_t lds, hipStream_t stream);
 int egn_conv_launch_c48(const ConvArgs& a, size_t lds, int waves, hipStream_t stream);
 int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t stream);
+int egn_conv_launch_stem(const ConvArgs& a, size_t lds, hipStream_t stream);   // conv_stem.hip
+bool egn_conv_stem_applies(const ConvArgs& a);
+size_t egn_conv_stem_lds_bytes();
 size_t egn_conv_wino_lds_bytes(int variant, int cout);
 int egn_conv_wino_stats_rows(const ConvArgs& a, int variant);
 
@@ -90,6 +93,9 @@ static const ConvConfig kConfigs[] = {
     {61, 4, 1, 1, 3, 4, 8, 5},     // ... two 8 x 8 images, 4 waves
     {62, 4, 1, 1, 3, 4, 9, 5},     // ... 8 x 16 pixel tile, 4 waves
     {63, 8, 1, 1, 3, 4, 0x46, 5},  // 59 with s_memtime stamps (tools/wino_clk.py)
+    {64, 4, 1, 1, 4, 0, 0, 6},     // the stem: 3x3 s2, 3 -> 64 channels, K = (tap, channel) (conv_stem.hip)
+    {65, 6, 1, 1, 3, 4, 10, 5},    // fused Winograd F(4x4,3x3), conv_wino43_kernel: filter from egn ... kind 2
+    {66, 6, 1, 1, 3, 4, 0x1a, 5},  // 65 with s_memtime stamps
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -111,7 +117,8 @@ extern "C" int egn_conv_config_kind(int cfg) {
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 3) return -1;  // retired ids
   if (c.dma != 5) return 0;
-  return (c.bi >> 4) ? -1 : 1;
+  if (c.bi >> 4) return -1;
+  return (c.bi & 15) == 10 ? 2 : 1;     // 2: F(4x4,3x3) filter (engine.pack_wino43_weight)
 }
 
 // kernel symbol of a config as rocprofv3 prints it (lets bench.py line its
@@ -119,14 +126,17 @@ extern "C" int egn_conv_config_kind(int cfg) {
 extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (cfg < 1 || cfg > kNumConfigs || !buf || len < 8) return EGN_E_BADARG;
   const ConvConfig& c = kConfigs[cfg - 1];
+  if (c.dma == 6) { snprintf(buf, len, "conv_stem_kernel(ConvArgs)"); return 0; }
+  if (c.dma == 5 && (c.bi & 15) == 10) { snprintf(buf, len, "void conv_wino43_kernel<0>(ConvArgs)"); return 0; }
+  if (c.dma == 5 && (c.bi & 15) >= 6) {
+    static const char* geo9[4] = {"16, 16, 1, 8", "8, 8, 4, 8", "8, 8, 2, 4", "8, 16, 1, 4"};
+    snprintf(buf, len, "void conv_wino9_kernel<%s, 3>(ConvArgs)", geo9[(c.bi & 15) - 6]);
+    return 0;
+  }
   if (c.dma == 5)
     // conv_wino8_kernel<TH, TW, TNB, ABL, NW, NT>: the symbol of the 48-channel co-tile build (NT = 3: the W48
     // widths); layers with Cout % 48 != 0 run the NT = 2 build of the same kernel
-    if ((c.bi & 15) >= 6) {
-      static const char* geo9[4] = {"16, 16, 1, 8", "8, 8, 4, 8", "8, 8, 2, 4", "8, 16, 1, 4"};
-      snprintf(buf, len, "void conv_wino9_kernel<%s, 3>(ConvArgs)", geo9[(c.bi & 15) - 6]);
-    }
-    else if ((c.bi & 15) == 4) snprintf(buf, len, "void conv_wino8_kernel<8, 8, 2, 0, 4, 3>(ConvArgs)");
+    if ((c.bi & 15) == 4) snprintf(buf, len, "void conv_wino8_kernel<8, 8, 2, 0, 4, 3>(ConvArgs)");
     else if ((c.bi & 15) == 5) snprintf(buf, len, "void conv_wino8_kernel<8, 16, 1, 0, 4, 3>(ConvArgs)");
     else if (c.bi & 2) snprintf(buf, len, "void conv_wino8_kernel<%s, %d, 8, 3>(ConvArgs)", (c.bi & 1) ? "8, 8, 4" : "16, 16, 1", c.bi >> 4);
     else snprintf(buf, len, "void conv_wino_kernel<%s, %d>(ConvArgs)", (c.bi & 1) ? "8, 8, 4" : "16, 16, 1", c.bi >> 4);
@@ -157,6 +167,7 @@ static size_t lds_stage_bytes(const ConvArgs& a, const ConvConfig& cf) {
   return ((main_loop > epi ? main_loop : epi) + 15) & ~(size_t)15;
 }
 static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
+  if (cf.dma == 6) return egn_conv_stem_lds_bytes();
   if (cf.dma == 5) return egn_conv_wino_lds_bytes(cf.bi, a.Cout);
   if (cf.dma == 4 && cf.bi == 2) return (size_t)(3 * 336 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // chunk ring + filter
   if (cf.dma == 4) return (size_t)(2 * 3 * 192 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // 2 halo buffers + filter
@@ -168,11 +179,30 @@ static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
 // to the per-lane staging depth (ai / bi dwordx4 loads per stage).
 static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, double* cost_out) {
   if (cf.dma == 3) return false;  // retired ids
+  if (cf.dma == 6) {
+    if (!egn_conv_stem_applies(a)) return false;
+    a.TH = 16; a.TW = 16; a.TNB = 1; a.HH = 33; a.HW = 33;
+    a.npix = 33 * 33; a.npixp = (a.npix + 15) & ~15; a.tps = 9;
+    a.tiles_x = (a.Wo + 15) / 16;
+    a.tiles_y = (a.Ho + 15) / 16;
+    if (cost_out) *cost_out = 0.0;
+    return true;
+  }
   if (cf.dma == 5) {
     // conv_wino.hip: 3x3 stride-1 pad-1 NHWC layers with unpadded channel strides, even maps
     if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.pad != 1 || a.Cin % EGN_CK || a.cs_in != a.Cin ||
         a.cs_out != a.Cout || a.out_nchw || (a.Ho & 1) || (a.Wo & 1))
       return false;
+    if ((cf.bi & 15) == 10) {
+      // conv_wino43_kernel: 16 x 16 pixel tiles of whole-tile maps, 4-channel K steps, 48-channel co-tiles
+      if (a.Cout % 48 || a.Cin % 4 || (a.Ho % 16) || (a.Wo % 16)) return false;
+      a.TH = 16; a.TW = 16; a.TNB = 1; a.HH = 18; a.HW = 18;
+      a.npix = 18 * 18; a.npixp = (a.npix + 15) & ~15; a.tps = 36;
+      a.tiles_x = a.Wo / 16;
+      a.tiles_y = a.Ho / 16;
+      if (cost_out) *cost_out = 0.0;
+      return true;
+    }
     // co-tile 48 (4- and 8-wave kernels) or 32 (8-wave kernels only): egn_wino_cot in conv_wino.hip
     if (a.Cout % 48 != 0 && !(a.Cout % 32 == 0 && (cf.bi & 15) >= 2)) return false;
     const int geo = (cf.bi & 15) >= 6 ? (cf.bi & 15) - 4 : (cf.bi & 15);   // 6..9: conv_wino9_kernel on 2..5's tiles
@@ -308,6 +338,7 @@ int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {
   if (cfg_id < 1 || cfg_id > kNumConfigs) return EGN_E_BADARG;
   const ConvConfig& cf = kConfigs[cfg_id - 1];
   const size_t lds = lds_bytes_for(a, cf);
+  if (cf.dma == 6) return egn_conv_launch_stem(a, lds, stream);
   if (cf.dma == 5) return egn_conv_launch_wino(a, lds, cf.bi, stream);
   if (cf.dma == 4) return egn_conv_launch_c48(a, lds, cf.bi == 2 ? -1 : cf.bi == 1 ? 0 : cf.wm, stream);
   if (cf.dma == 3) return EGN_E_BADARG;

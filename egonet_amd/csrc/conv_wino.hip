@@ -1382,6 +1382,375 @@ static int wino8_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
   return EGN_E_BADARG;
 }
 
+// ---------------------------------------------------------------------------------------------
+// conv_wino43_kernel -- fused Winograd F(4x4,3x3) for the wide layers (Cout % 48 == 0, maps that are multiples
+// of 16: HRNet's 96-channel 32 x 32 and 192-channel 16 x 16 branches; configs 65 / ..).  [round 3]
+//
+// 36 multiplies per 4x4 output patch and (ci, co) instead of the 64 of F(2x2,3x3) (144 direct): the matrix
+// pipe, which bounds these layers (and on which fp32 MFMAs and every VALU instruction compete for the same FMA
+// lanes, profiles/r3_mfma_tax.txt), gets 1.78x less to do.  Price: transforms with the constants of the points
+// (0, +-1, +-2) -- whole-network fp32 emulation (tools/wino43_network_study.py): heat-maps within 2.5e-5 of the
+// fp32 oracle (bar 5e-4), arg-max unchanged, soft-arg-max within 7e-5 px (bar 1e-3).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A,   d = 6x6 input patch, 36 frequencies f = (i, j)
+//
+//   * block = ONE m-tile: the 16 Winograd tiles (4 x 4 output pixels each) of a 16 x 16 pixel tile, 48 output
+//     channels; SIX waves, wave i owns frequency ROW i: 6 frequencies x 3 co sub-tiles = 72 accumulators, so
+//     two blocks (12 waves, three per SIMD) share a CU with 2 x 70 KB of LDS;
+//   * K step = 4 input channels = the four k lanes of v_mfma_f32_16x16x4_f32 (lane (tile = l & 15, kq = l >> 4)
+//     holds channel kq): everything a lane touches is one dword, the halo is pixel major [slot][4] with rows
+//     skewed (slot = 24 y + x + (y >> 2)) so that the 16 tiles spread over all banks (2-way conflicts, the
+//     minimum for 16 tiles x 2 channels on 32 banks);
+//   * input transform per wave: T[i][c] = sum_a B^T[i][a] d[a][c] -- row i of B^T has at most four non-zeros,
+//     one of them 1: three v_fma with wave-uniform coefficients, which rows a are read is a per-wave LDS
+//     offset -- then the 6-point transform along the row (12 operations): 30 VALU per 18 MFMAs;
+//   * U = G g G^T transformed in float64 on the host and rounded once, packed [co-tile][K step][f][kq][48];
+//   * output transform: wave i forms t_i[b] = sum_j M[i][j] A[j][b] (10 operations per accumulator vector), the
+//     six waves exchange them through LDS one co sub-tile at a time, waves 0..3 finish the output rows
+//     a = 0..3 of every tile: Y[a][b] = sum_i A^T[a][i] t_i[b], scale / shift / residual / ReLU, dword stores.
+// Persistent blocks over (tile, co-tile) items, XCD-aware like conv_wino8_kernel; the next item's first stage is
+// prefetched during the last K step.  Stage ring of two, ONE barrier per K step.
+namespace {
+constexpr int W43_RP = 24;                       // halo row pitch in pixel slots
+constexpr int W43_HS = 448;                      // halo slots per m-tile and stage (17 * 24 + 17 + 4 < 448 = 7 x 64)
+constexpr int W43_HP = W43_HS / 64;              // 7 DMA pieces per m-tile
+constexpr int W43_MT = 2;                        // m-tiles (16 x 16 pixel tiles) per block
+constexpr int W43_UF = 36 * 4 * 48;              // floats per (co-tile, K step) slab of U: 27 648 B
+constexpr int W43_UP = W43_UF / 256;             // 27 DMA pieces
+constexpr int W43_NP = W43_MT * W43_HP + W43_UP; // 41 pieces per stage
+constexpr int W43_HF = W43_HS * 4;               // floats of one halo image
+constexpr int W43_STAGE = W43_MT * W43_HF + W43_UF;   // floats per stage: 10 496 (41 984 B)
+constexpr int W43_RING = 3;                      // stages: the DMA of a K step has two K steps to land
+constexpr int W43_NW = 6 * W43_MT;               // 12 waves: (m-tile, frequency row)
+constexpr int W43_NTH = 64 * W43_NW;
+constexpr int W43_KP = (W43_NP + W43_NW - 1) / W43_NW;   // 4 piece slots per wave; the last one only for waves < 5
+}  // namespace
+
+// K step = 4 input channels; a wave's DMA pieces of a stage: p = k * 12 + wave (k = 0..3), p < 14: halo of m-tile
+// p / 7, else U slab.  Ring of three stages: the pieces of K step g + 2 go out during step g (into the stage step
+// g - 1 consumed), so every piece has two whole steps to land -- with 18 MFMAs per wave and step a two-stage ring
+// made every step wait a full DMA round trip (first version: 69 us where this one takes 3x.. see DESIGN).
+template <int CLK = 0>
+__global__ __launch_bounds__(W43_NTH, 3) void conv_wino43_kernel(ConvArgs a) {
+  extern __shared__ float4 smem[];
+  float* sm = reinterpret_cast<float*>(smem);
+  const unsigned lds0 = wino_lds_addr(smem);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mt = wave / 6;                         // m-tile of the block
+  const int fr = wave - 6 * mt;                    // frequency row i
+  const int li = lane & 15, kq = lane >> 4;
+
+  const int C = a.Cin, Co = a.Cout;
+  const int nct = Co / 48;
+  const int nsteps = C / 4;
+  const unsigned long long xaddr = reinterpret_cast<unsigned long long>(a.x);
+  const unsigned long long uaddr = reinterpret_cast<unsigned long long>(a.w);
+  const u32x4 rxv = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, (unsigned)((size_t)a.N * a.H * a.W * C * 4), 0x00020000u};
+  const u32x4 ruv = {(unsigned)uaddr, (unsigned)(uaddr >> 32) & 0xffffu, (unsigned)((size_t)nct * nsteps * W43_UF * 4), 0x00020000u};
+  const unsigned out_bytes = (unsigned)((size_t)a.N * a.Ho * a.Wo * Co * 4);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, out_bytes, 0x00020000);
+
+  // ---- halo pieces of this wave: k = 0 -> p = wave (all 12 are halo pieces), k = 1 -> p = 12 + wave (waves 0, 1) ----
+  int hyx[2], hrel[2], hmt[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int p = k * W43_NW + wave;
+    const int m_ = p / W43_HP, q = p - m_ * W43_HP;
+    const int e = q * 64 + lane;
+    const int y = e / W43_RP, x = e - y * W43_RP - (y >> 2);
+    const bool ok = p < W43_MT * W43_HP && y < 18 && x >= 0 && x < 18;
+    hyx[k] = ok ? ((y << 8) | x) : -1;
+    hrel[k] = ok ? (y * a.W + x) * C * 4 : 0;
+    hmt[k] = m_ < W43_MT ? m_ : 0;
+  }
+  // ---- B^T row of this wave: T = c0 d[r0] + c1 d[r1] + c2 d[r2] + d[r3] ----
+  //   row 0: 4 d0 - 5 d2 + d4      1: -4 d1 - 4 d2 + d3 + d4     2: 4 d1 - 4 d2 - d3 + d4
+  //       3: -2 d1 - d2 + 2 d3 + d4    4: 2 d1 - d2 - 2 d3 + d4      5: 4 d1 - 5 d3 + d5
+  int r0, r1, r2, r3;
+  float c0, c1, c2;
+  switch (fr) {
+    case 0: r0 = 0; r1 = 2; r2 = 2; r3 = 4; c0 = 4.f; c1 = -5.f; c2 = 0.f; break;
+    case 1: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = -4.f; c1 = -4.f; c2 = 1.f; break;
+    case 2: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = 4.f; c1 = -4.f; c2 = -1.f; break;
+    case 3: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = -2.f; c1 = -1.f; c2 = 2.f; break;
+    case 4: r0 = 1; r1 = 2; r2 = 3; r3 = 4; c0 = 2.f; c1 = -1.f; c2 = -2.f; break;
+    default: r0 = 1; r1 = 3; r2 = 3; r3 = 5; c0 = 4.f; c1 = -5.f; c2 = 0.f; break;
+  }
+  // float index (inside a stage) of patch element (row a, column 0) of this lane's tile (ty = li >> 2, tx = li & 3)
+  const int tyl = li >> 2, txl = li & 3;
+#define W43_PROW(A) (mt * W43_HF + (((4 * tyl + (A)) * W43_RP + 4 * txl + tyl + ((A) >> 2)) * 4) + kq)
+  const int pr0 = W43_PROW(r0), pr1 = W43_PROW(r1), pr2 = W43_PROW(r2), pr3 = W43_PROW(r3);
+#undef W43_PROW
+  // float index of this lane's B fragment of frequency (fr, 0), co sub-tile 0
+  const int ub = W43_MT * W43_HF + ((fr * 6) * 4 + kq) * 48 + li;
+
+  const int tiles_xy = a.tiles_x * a.tiles_y;
+  const int ntile = tiles_xy * a.N;
+  const int npair = (ntile + 1) >> 1;              // items = pairs of consecutive tiles (a row of a 32-wide map, or two images)
+  const int nwork = ((npair + 7) >> 3) * nct * 8;
+  const int gsz = __builtin_amdgcn_readfirstlane((int)gridDim.x);
+
+  unsigned long long* sT = nullptr;
+  int ntk = 0;
+  if constexpr (CLK != 0) sT = reinterpret_cast<unsigned long long*>(sm + W43_RING * W43_STAGE);
+#define W43_CLK()                                                                        \
+  {                                                                                      \
+    if constexpr (CLK != 0) {                                                            \
+      if (lane == 0 && ntk < 48) sT[wave * 48 + ntk] = __builtin_readcyclecounter();     \
+      ++ntk;                                                                             \
+    }                                                                                    \
+  }
+
+// work index -> (tile pair, co-tile); TILE (0 / 1) = 2 * pair + m-tile -> (n, ty, tx), all on the scalar unit
+#define W43_ITEM(Wi, PAIR_, CT_)                                                 \
+  {                                                                              \
+    const unsigned wi_ = (unsigned)__builtin_amdgcn_readfirstlane((int)(Wi));    \
+    const unsigned x_ = wi_ & 7u, q_ = wi_ >> 3;                                 \
+    const unsigned qq_ = wn_udiv(q_, a.mg_nct);                                  \
+    PAIR_ = (int)(qq_ * 8u + x_);                                                \
+    CT_ = (int)(q_ - qq_ * (unsigned)nct);                                       \
+  }
+#define W43_TILE(TILE_, N_, TY_, TX_)                                            \
+  {                                                                              \
+    const unsigned tbq_ = wn_udiv((unsigned)(TILE_), a.mg_txy);                  \
+    const unsigned rq_ = (unsigned)(TILE_)-tbq_ * (unsigned)tiles_xy;            \
+    const unsigned tyq_ = wn_udiv(rq_, a.mg_tx);                                 \
+    N_ = (int)tbq_; TY_ = (int)tyq_; TX_ = (int)(rq_ - tyq_ * (unsigned)a.tiles_x); \
+  }
+// halo DMA byte offsets (K step 0) of this wave's halo pieces for tile pair PAIR_
+#define W43_DOFF(PAIR_, OUT)                                                                                 \
+  {                                                                                                          \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                          \
+      const int t_ = 2 * (PAIR_) + hmt[k];                                                                   \
+      int n_, ty_2, tx_2;                                                                                    \
+      W43_TILE(t_, n_, ty_2, tx_2)                                                                           \
+      const int iy0_ = ty_2 * 16 - 1, ix0_ = tx_2 * 16 - 1;                                                  \
+      const int base_ = ((n_ * a.H + iy0_) * a.W + ix0_) * C * 4;                                            \
+      const unsigned iy_ = (unsigned)(iy0_ + (hyx[k] >> 8)), ix_ = (unsigned)(ix0_ + (hyx[k] & 255));        \
+      const bool in_ = t_ < ntile && hyx[k] >= 0 && iy_ < (unsigned)a.H && ix_ < (unsigned)a.W;              \
+      OUT[k] = in_ ? (unsigned)(base_ + hrel[k]) : EGN_OOB;                                                  \
+    }                                                                                                        \
+  }
+// DMA piece slot K (0..3) of this wave for ring stage P: channel group STEP, U slab (CT, STEP)
+#define W43_PIECE(K, P, OFF, CT, STEP)                                                                        \
+  {                                                                                                          \
+    const int p_ = (K)*W43_NW + wave;                                                                        \
+    if (p_ < W43_MT * W43_HP) {                                                                              \
+      wino_dma16(rxv, lds0 + (unsigned)((P)*W43_STAGE * 4 + p_ * 1024), OFF[(K) < 2 ? (K) : 0], (unsigned)(STEP)*16u); \
+    } else if (p_ < W43_NP) {                                                                                \
+      wino_dma16(ruv, lds0 + (unsigned)((P)*W43_STAGE * 4 + W43_MT * W43_HF * 4 + (p_ - W43_MT * W43_HP) * 1024), \
+                 (unsigned)lane * 16u, (unsigned)((((CT)*nsteps + (STEP)) * W43_UP + (p_ - W43_MT * W43_HP)) * 1024)); \
+    }                                                                                                        \
+  }
+#define W43_ISSUE(P, OFF, CT, STEP) { _Pragma("unroll") for (int k_ = 0; k_ < W43_KP; ++k_) W43_PIECE(k_, P, OFF, CT, STEP) }
+
+  int w = blockIdx.x;
+  int pair = 0, ct = 0;
+  W43_ITEM(w, pair, ct)
+  unsigned doff[2];
+  W43_DOFF(pair, doff)
+  int rs = 0;                                    // ring stage of the K step about to be computed
+  if (w < nwork) {
+    W43_ISSUE(0, doff, ct, 0)
+    if (nsteps > 1) W43_ISSUE(1, doff, ct, 1)
+  }
+  bool first = true;
+  const float act_lo = (a.act & EGN_ACT_MASK) == EGN_ACT_RELU ? 0.f : -__builtin_inff();
+  const bool has_res = CLK ? false : a.res != nullptr;
+  const unsigned colpitch = (unsigned)Co * 4u;
+  const bool fin = fr < 4;                       // waves with fr = 0..3 finish output row a = fr of every tile of their m-tile
+  const bool pw4 = wave < W43_NP - (W43_KP - 1) * W43_NW;   // this wave has a piece in the last slot (4 pieces per stage, else 3)
+  W43_CLK()
+
+  for (; w < nwork; w += gsz) {
+    int pair_n = 0, ct_n = 0;
+    W43_ITEM(w + gsz, pair_n, ct_n)
+    const bool more = (w + gsz) < nwork;
+    unsigned doff_n[2];
+    W43_DOFF(pair_n, doff_n)
+    // this wave's m-tile: output pixel (4 kq + a, 4 r + b) of tile row kq: byte offset of (row a = fr, column 0)
+    unsigned vbase;
+    {
+      const int t_ = 2 * pair + mt;
+      int n_, ty_, tx_;
+      W43_TILE(t_, n_, ty_, tx_)
+      vbase = (t_ < ntile) ? (unsigned)((((n_ * a.Ho + ty_ * 16 + 4 * kq + (fin ? fr : 0)) * a.Wo + tx_ * 16) * Co + ct * 48 + li) * 4)
+                           : EGN_OOB;
+    }
+    float sc[3], sh[3];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      sc[nt] = a.scale[ct * 48 + nt * 16 + li];
+      sh[nt] = a.shift[ct * 48 + nt * 16 + li];
+    }
+    f32x4 acc[6][3];
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) acc[j][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c = 0; c < nsteps; ++c) {
+      asm volatile("" ::: "memory");
+      W43_CLK()
+      // The stage of this K step has landed in this wave's share.  In flight behind it (issue order): the next
+      // K step's pieces (3 or 4 of this wave) -- except at the last step of an item, whose successor was not
+      // issued yet -- and, at the first step after an epilogue, the 48 stores of a finishing wave.
+      {
+        const bool tail_free = (c + 1 == nsteps);            // nothing newer than this stage (but the stores)
+        if (c == 0 && !first && fin) {
+          // [stage of this step] [48 stores]: the stage was issued before the epilogue
+          __builtin_amdgcn_s_waitcnt(0xC070);                                // vmcnt(48)
+        } else if (tail_free || (c == 0 && !first)) {
+          __builtin_amdgcn_s_waitcnt(0x0070);                                // vmcnt(0)
+        } else if (pw4) {
+          __builtin_amdgcn_s_waitcnt(0x0074);                                // vmcnt(4)
+        } else {
+          __builtin_amdgcn_s_waitcnt(0x0073);                                // vmcnt(3)
+        }
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      W43_CLK()
+      // ---- issue: K step c + 2 of this item into the stage step c - 1 consumed; the item's first step also issues
+      // its step 1 (deferred: at the end of the previous item only stage 0 of this one was prefetched, the other
+      // two stages served the exchange); the item's LAST-BUT-ONE step prefetches the next item's step 0 ----
+      int st2 = rs + 2; if (st2 >= W43_RING) st2 -= W43_RING;
+      int st1 = rs + 1; if (st1 >= W43_RING) st1 -= W43_RING;
+#define W43_NEXT(K)                                                               \
+  {                                                                               \
+    __builtin_amdgcn_sched_barrier(0x0106);                                       \
+    if (c + 2 < nsteps) W43_PIECE(K, st2, doff, ct, c + 2)                        \
+    else if (c + 2 == nsteps && more) W43_PIECE(K, st2, doff_n, ct_n, 0)          \
+    __builtin_amdgcn_sched_barrier(0x0106);                                       \
+  }
+      if (c == 0 && !first && nsteps > 1) W43_ISSUE(st1, doff, ct, 1)
+      first = false;
+      const float* hb = sm + rs * W43_STAGE;
+      // ---- input transform: row `fr` of B^T d, then the 6-point transform along it ----
+      float t[6];
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc)
+        t[cc] = __builtin_fmaf(c0, hb[pr0 + cc * 4], __builtin_fmaf(c1, hb[pr1 + cc * 4], __builtin_fmaf(c2, hb[pr2 + cc * 4], hb[pr3 + cc * 4])));
+      float V[6];
+      {
+        const float u = __builtin_fmaf(-4.f, t[2], t[4]), v = __builtin_fmaf(-4.f, t[1], t[3]);
+        const float p = t[4] - t[2], q = t[3] - t[1];
+        V[0] = __builtin_fmaf(4.f, t[0], __builtin_fmaf(-5.f, t[2], t[4]));
+        V[1] = u + v;
+        V[2] = u - v;
+        V[3] = __builtin_fmaf(2.f, q, p);
+        V[4] = __builtin_fmaf(-2.f, q, p);
+        V[5] = __builtin_fmaf(4.f, t[1], __builtin_fmaf(-5.f, t[3], t[5]));
+      }
+      // ---- 6 frequencies x 3 co sub-tiles, one MFMA (k = the 4 channels) each ----
+      const float* ubp = hb + ub;
+      float bf[2][3];
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) bf[0][nt] = ubp[nt * 16];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        if (j + 1 < 6) {
+#pragma unroll
+          for (int nt = 0; nt < 3; ++nt) bf[(j + 1) & 1][nt] = ubp[(j + 1) * 192 + nt * 16];
+        }
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt)
+          acc[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[j], bf[j & 1][nt], acc[j][nt], 0, 0, 0);
+        if (j < W43_KP) W43_NEXT(j)
+      }
+#undef W43_NEXT
+      if (++rs == W43_RING) rs = 0;
+    }
+    W43_CLK()
+
+    // ---- output transform, first half: t_i[b] = sum_j M[i][j] A[j][b]  (vectors over the 4 tile columns r) ----
+    f32x4 tb[3][4];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      const f32x4 p = acc[1][nt] + acc[2][nt], q = acc[1][nt] - acc[2][nt];
+      const f32x4 r_ = acc[3][nt] + acc[4][nt], s_ = acc[3][nt] - acc[4][nt];
+      tb[nt][0] = acc[0][nt] + p + r_;
+      tb[nt][1] = q + 2.f * s_;
+      tb[nt][2] = p + 4.f * r_;
+      tb[nt][3] = q + 8.f * s_ + acc[5][nt];
+    }
+    // ---- exchange, one co sub-tile per round, through the stages that hold nothing: `rs` is the stage of the next
+    // item's step 0 (prefetched at this item's last-but-one step); the stage before it (consumed by the last
+    // step) and the one after it (its filling was deferred) are free: 2 x 42 KB for 12 waves x 4 KB ----
+    int xs = rs + 1; if (xs >= W43_RING) xs -= W43_RING;
+    // (with a ring of 3 the stage after `rs` and the stage before `rs` are (rs + 1) and (rs + 2) mod 3: m-tile 0
+    //  exchanges in one, m-tile 1 in the other)
+    int xs2 = rs + 2; if (xs2 >= W43_RING) xs2 -= W43_RING;
+    f32x4* xch = reinterpret_cast<f32x4*>(sm + (mt == 0 ? xs : xs2) * W43_STAGE);
+    float rv[2][4][4];     // residual of round nt (slot nt & 1): [b][r]
+    if (fin) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[0][b][r] = wino_load4(rr, has_res ? vbase : EGN_OOB, (unsigned)(4 * r + b) * colpitch);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): own LDS reads of the K loop / of the previous round are done
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int b = 0; b < 4; ++b) xch[(fr * 4 + b) * 64 + lane] = tb[nt][b];
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (fin) {
+        if (nt + 1 < 3) {      // next round's residual, one round ahead
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              rv[(nt + 1) & 1][b][r] = wino_load4(rr, has_res ? vbase : EGN_OOB, (unsigned)(4 * r + b) * colpitch + (nt + 1) * 64u);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          f32x4 ti[6];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) ti[i] = xch[(i * 4 + b) * 64 + lane];
+          // A^T rows: (1,1,1,1,1,0) (0,1,-1,2,-2,0) (0,1,1,4,4,0) (0,1,-1,8,-8,1)
+          f32x4 y;
+          if (fr == 0) y = ti[0] + ti[1] + ti[2] + ti[3] + ti[4];
+          else if (fr == 1) y = (ti[1] - ti[2]) + 2.f * (ti[3] - ti[4]);
+          else if (fr == 2) y = (ti[1] + ti[2]) + 4.f * (ti[3] + ti[4]);
+          else y = (ti[1] - ti[2]) + 8.f * (ti[3] - ti[4]) + ti[5];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = fmaxf(y[r] * sc[nt] + sh[nt] + rv[nt & 1][b][r], act_lo);
+            wino_store4(ry, vbase, (unsigned)(4 * r + b) * colpitch + nt * 64u, v);
+          }
+        }
+      }
+    }
+    W43_CLK()
+    pair = pair_n; ct = ct_n;
+    doff[0] = doff_n[0]; doff[1] = doff_n[1];
+  }
+  if constexpr (CLK != 0) {
+    __syncthreads();
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res)) + (size_t)blockIdx.x * (W43_NW * 48 + 1);
+    for (int e = tid; e < W43_NW * 48; e += W43_NTH) out[1 + e] = sT[e];
+    if (tid == 0) out[0] = (unsigned long long)ntk;
+  }
+#undef W43_ITEM
+#undef W43_TILE
+#undef W43_DOFF
+#undef W43_PIECE
+#undef W43_ISSUE
+#undef W43_CLK
+}
+
+size_t egn_conv_wino43_lds_bytes(int clk) { return (size_t)W43_RING * W43_STAGE * 4 + (clk ? W43_NW * 48 * 8 : 0); }
+
 static unsigned wino_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
 template <int TH, int TW, int TNB, int NW, int NT, int CLK = 0>
@@ -1405,10 +1774,38 @@ static int wino9_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
   return EGN_E_BADARG;
 }
 
+template <int CLK>
+static int wino43_launch(ConvArgs a, size_t lds, hipStream_t stream) {
+  static bool raised[EGN_MAX_DEVICES];
+  static int cus = 0;
+  if (egn_first_use_on_device(raised)) {
+    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino43_kernel<CLK>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+  }
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  const int nct = a.Cout / 48;
+  a.mg_nct = wino_magic(nct);
+  a.mg_txy = wino_magic(a.tiles_x * a.tiles_y);
+  a.mg_tx = wino_magic(a.tiles_x);
+  const int ntile = a.tiles_x * a.tiles_y * a.N;
+  const int npair = (ntile + 1) / 2;
+  const int nwork = ((npair + 7) / 8) * 8 * nct;
+  int cap = cus / (8 * nct) * (8 * nct);              // one 126 KB block per CU, whole XCD rounds
+  if (cap <= 0) cap = 8 * nct;
+  const int grid = nwork < cap ? nwork : cap;
+  hipLaunchKernelGGL((conv_wino43_kernel<CLK>), dim3(grid), dim3(W43_NTH), lds, stream, a);
+  return (int)hipGetLastError();
+}
+
 // rows of the BatchNorm partial table a launch writes (0 = this variant has no fused statistics)
 int egn_conv_wino_stats_rows(const ConvArgs& a, int variant) {
   int v = variant & 15;
-  if ((variant >> 4) || v < 2) return 0;
+  if ((variant >> 4) || v < 2 || v >= 10) return 0;      // (10: the F(4x4,3x3) kernel has no fused statistics)
   if (v >= 6) v -= 4;              // variants 6..9 = conv_wino9_kernel on the geometries of 2..5
   const int tnb = v == 3 ? 4 : (v == 4 ? 2 : 1);
   return wino8_grid(a, tnb);       // one partial row per block
@@ -1417,6 +1814,7 @@ int egn_conv_wino_stats_rows(const ConvArgs& a, int variant) {
 // variant 0: 16 x 16 pixel tile of one image; variant 1: four 8 x 8 images (the 8 x 8 maps);
 // variants 2 / 3: the same two geometries on the 8-wave kernel; variant 4: two 8 x 8 images, 4 waves
 size_t egn_conv_wino_lds_bytes(int variant, int cout) {
+  if ((variant & 15) == 10) return egn_conv_wino43_lds_bytes(variant >> 4);
   int v = variant & 15;
   if (v >= 6) v -= 4;              // conv_wino9_kernel: the LDS image of conv_wino8_kernel
   size_t halo = (v & 1) ? WinoDims<8, 8, 4>::BUF : WinoDims<16, 16, 1>::BUF;
@@ -1437,6 +1835,8 @@ int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t
     case 3: return wino8_launch<8, 8, 4>(a, lds, stream);
     case 4: return wino8_launch<8, 8, 2, 0, 4>(a, lds, stream);
     case 5: return wino8_launch<8, 16, 1, 0, 4>(a, lds, stream);
+    case 10: return a.stats ? EGN_E_BADARG : wino43_launch<0>(a, lds, stream);
+    case 0x1a: return wino43_launch<1>(a, lds, stream);           // s_memtime stamps (tools/wino_clk.py)
     case 6: return wino9_launch<16, 16, 1>(a, lds, stream);
     case 7: return wino9_launch<8, 8, 4>(a, lds, stream);
     case 8: return wino9_launch<8, 8, 2, 4>(a, lds, stream);

@@ -74,6 +74,27 @@ def pack_wino_weight(w):
     return u.permute(0, 2, 5, 3, 1, 4).contiguous().reshape(-1)
 
 
+def pack_wino43_weight(w):
+    """[Cout,Cin,3,3] -> the Winograd F(4x4,3x3) filter U = G g G^T (points 0, +-1, +-2; float64, rounded once to
+    fp32) in the layout conv_wino43_kernel stages through LDS:
+    flat fp32 [co-tile = Cout/48][K step = Cin/4][f = 6i+j][kq = ci % 4][48], one contiguous 27 KB slab per
+    (co-tile, K step)."""
+    w = w.detach().to(torch.float64).cpu()
+    cout, cin, kh, kw = w.shape
+    assert (kh, kw) == (3, 3) and cout % 48 == 0 and cin % 4 == 0, w.shape
+    G = torch.tensor([[1 / 4., 0., 0.], [-1 / 6., -1 / 6., -1 / 6.], [-1 / 6., 1 / 6., -1 / 6.],
+                      [1 / 24., 1 / 12., 1 / 6.], [1 / 24., -1 / 12., 1 / 6.], [0., 0., 1.]], dtype=torch.float64)
+    u = torch.einsum('ia,ocab,jb->ocij', G, w, G).to(torch.float32)        # [Cout,Cin,6,6]
+    u = u.reshape(cout // 48, 48, cin // 4, 4, 36)                          # ct, col, step, kq, f
+    return u.permute(0, 2, 4, 3, 1).contiguous().reshape(-1)
+
+
+def pack_for_kind(w, kind):
+    """The filter in the layout the kernels of a tile-configuration KIND read (egn_conv_config_kind):
+    0 direct, 1 Winograd F(2x2,3x3), 2 Winograd F(4x4,3x3)."""
+    return pack_wino43_weight(w) if kind == 2 else (pack_wino_weight(w) if kind == 1 else pack_conv_weight(w))
+
+
 def fold_scale_shift(cout, bias=None, bn=None):
     """Per-channel (scale, shift) so that  bn(conv(x) + bias) == conv(x)*scale + shift,
     eval-mode BatchNorm (running stats).  Computed in float64, stored fp32,
@@ -343,9 +364,9 @@ class Program(object):
                 continue
             if 'cfg' not in op:
                 plain_act = (op['act'] & 0xf) in (ACT_NONE, ACT_RELU) and not (op['act'] & ACT_RES_AFTER)
-                op['cfg'] = tuner.choose(device, self._conv_key(op), allow_wino=plain_act)
-            wino = op['cfg'] > 0 and L.egn_conv_config_kind(op['cfg']) == 1
-            op['w'] = rec.weight(pack_wino_weight(op['w_src']) if wino else pack_conv_weight(op['w_src']))
+                op['cfg'] = tuner.choose(device, self._conv_key(op), allow_wino=plain_act, allow_f43=plain_act)
+            kind = L.egn_conv_config_kind(op['cfg']) if op['cfg'] > 0 else 0
+            op['w'] = rec.weight(pack_for_kind(op['w_src'], kind))
 
     def _emit(self, kind, op):
         L, h = self.lib, self.handle

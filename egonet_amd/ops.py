@@ -54,11 +54,15 @@ def fill_coord_ramps(y, c0):
 class PackedConv(object):
     """Device-resident packed weights + folded scale/shift of one conv layer."""
 
-    def __init__(self, weight, bias=None, bn=None, device='cuda', wino=False):
+    def __init__(self, weight, bias=None, bn=None, device='cuda', wino=False, kind=None):
         """``wino``: pack for the fused Winograd kernels (config kind 1) ON THE DEVICE
-        (egn_wino_pack_weight_f32) instead of the direct layout."""
+        (egn_wino_pack_weight_f32) instead of the direct layout; ``kind`` 2: the F(4x4,3x3) filter
+        (engine.pack_wino43_weight, host float64)."""
         self.cout, self.cin, self.kh, self.kw = weight.shape
-        if wino:
+        if kind == 2:
+            from .engine import pack_wino43_weight
+            self.w = pack_wino43_weight(weight).to(device)
+        elif wino or kind == 1:
             L = _lib.lib()
             nfl = L.egn_wino_weight_floats(self.cout, self.cin, 0)
             if nfl == 0 or (self.kh, self.kw) != (3, 3):

@@ -83,7 +83,7 @@ def tune(device, args, skip=()):
         x = torch.randn(n * h * wd * cs_in, device=device)
         # one buffer serves both packings (random data: only the timing matters); the Winograd
         # kernels read 16 floats per (co, ci)
-        w = torch.randn(max(nchunk * kh * kw * 4 * coutp * 4, cout * cin * 16), device=device) * 0.05
+        w = torch.randn(max(nchunk * kh * kw * 4 * coutp * 4, cout * cin * 36), device=device) * 0.05
         sc = torch.ones(coutp, device=device)
         sh = torch.zeros(coutp, device=device)
         ny = n * ho * wo * (cout if out_nchw else cs_out)
@@ -108,53 +108,61 @@ def tune(device, args, skip=()):
     return min(times, key=times.get), times
 
 
-def _pick(entry, allow_wino):
-    """Fastest measured configuration of a table entry; without ``allow_wino`` the fastest
-    DIRECT one (callers that hand the kernel a direct-packed filter: the training tape,
-    activations the Winograd epilogue does not implement)."""
-    cfg = int(entry['cfg'])
-    if allow_wino or cfg <= 0 or _lib.lib().egn_conv_config_kind(cfg) == 0:
-        return cfg
+def _pick(entry, allow_wino, allow_f43=False):
+    """Fastest measured configuration of a table entry among the kernel KINDS the caller can feed
+    (egn_conv_config_kind: 0 direct-packed filter -- always; 1 Winograd F(2x2,3x3) with ``allow_wino``;
+    2 Winograd F(4x4,3x3) with ``allow_f43``: the inference engine, which transforms filters on the host)."""
     L = _lib.lib()
-    direct = {int(k): v for k, v in entry.get('ms', {}).items() if L.egn_conv_config_kind(int(k)) == 0}
-    return min(direct, key=direct.get) if direct else 0
+    ok = {0} | ({1} if allow_wino else set()) | ({2} if allow_f43 else set())
+    cfg = int(entry['cfg'])
+    if cfg <= 0 or L.egn_conv_config_kind(cfg) in ok:
+        return cfg
+    fit = {int(k): v for k, v in entry.get('ms', {}).items() if L.egn_conv_config_kind(int(k)) in ok}
+    return min(fit, key=fit.get) if fit else 0
 
 
-def _forced_wino(args):
-    """EGONET_AMD_WINO=1: the Winograd configuration for every shape one plans for (parity tests pin
-    both kernel families on the same fixtures); returns 0 if none does."""
+def _forced_wino(args, kind=1):
+    """EGONET_AMD_WINO=1 / =43: the Winograd F(2x2,3x3) / F(4x4,3x3) configuration for every shape one plans
+    for (parity tests pin the kernel families on the same fixtures); returns 0 if none does."""
     n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, has_res, out_nchw = args
     L = _lib.lib()
     out = (C.c_int * 12)()
     for cfg in range(L.egn_conv_num_configs(), 0, -1):
-        if L.egn_conv_config_kind(cfg) == 1 and L.egn_conv_plan_query(
+        if L.egn_conv_config_kind(cfg) == kind and L.egn_conv_plan_query(
                 n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, int(out_nchw), cfg, out) == 0:
             return cfg
     return 0
 
 
-def choose(device, args, allow_wino=False):
-    """``allow_wino``: the caller packs the filter for whatever configuration comes back
-    (egn_conv_config_kind).  EGONET_AMD_WINO=0 never returns a Winograd configuration, =1 always
-    does where one plans; default: whichever measured fastest."""
+def choose(device, args, allow_wino=False, allow_f43=False):
+    """``allow_wino`` / ``allow_f43``: the caller packs the filter for whatever configuration kind comes back
+    (egn_conv_config_kind 1 / 2).  EGONET_AMD_WINO=0 never returns a Winograd configuration, =1 always the
+    F(2x2,3x3) one where it plans, =43 the F(4x4,3x3) one where it plans (else F(2x2,3x3)); EGONET_AMD_F43=0
+    keeps F(4x4,3x3) out; default: whichever measured fastest."""
     mode = os.environ.get('EGONET_AMD_WINO', '')
+    if os.environ.get('EGONET_AMD_F43', '1') == '0' or mode in ('0', '1'):
+        allow_f43 = False
     if mode == '0':
         allow_wino = False
-    elif mode == '1' and allow_wino:
+    elif mode == '43' and allow_f43:
+        cfg = _forced_wino(args, 2) or (_forced_wino(args, 1) if allow_wino else 0)
+        if cfg:
+            return cfg
+    elif mode in ('1', '43') and allow_wino:
         cfg = _forced_wino(args)
         if cfg:
             return cfg
     key = shape_key(*args)
     tab = _load()
     if key in tab:
-        return _pick(tab[key], allow_wino)
+        return _pick(tab[key], allow_wino, allow_f43)
     if not autotune_enabled():
         return 0               # deterministic: the shipped table or the cost model, whatever was tuned earlier
     if key in _tuned_here:
-        return _pick(_tuned_here[key], allow_wino)
+        return _pick(_tuned_here[key], allow_wino, allow_f43)
     cfg, times = tune(device, args)
     _tuned_here[key] = {'cfg': cfg, 'ms': {str(k): round(v, 5) for k, v in times.items()}}
-    return _pick(_tuned_here[key], allow_wino)
+    return _pick(_tuned_here[key], allow_wino, allow_f43)
 
 
 def tuned_in_process():

@@ -109,6 +109,24 @@ def test_conv_every_tile_config(cfg):
     assert _lib.lib().egn_conv_plan_query(3, 19, 13, 20, 20, 40, 40, 3, 3, 1, 1, 0, 31 + (cfg - 1) % 10, out) != 0   # retired ids never plan
 
 
+@pytest.mark.parametrize('n,h,w,act', [(2, 256, 256, 1), (3, 64, 48, 1), (1, 34, 22, 0), (5, 32, 32, 3)])
+def test_conv_stem_kernel(n, h, w, act):
+    """cfg 64 (csrc/conv_stem.hip): the 3 -> 64 channel 3x3 stride-2 stem (hrnet.py:311-314) with K = (tap, channel)
+    -- full size, ragged tiles (maps that are not multiples of 16), more tiles than blocks, LeakyReLU."""
+    import ctypes as C
+    from egonet_amd import _lib
+    L = _lib.lib()
+    out = (C.c_int * 12)()
+    assert L.egn_conv_config_kind(64) == 0
+    assert L.egn_conv_plan_query(n, h, w, 3, 4, 64, 64, 3, 3, 2, 1, 0, 64, out) == 0
+    err = _conv_case(n, h, w, 3, 64, 3, 2, 1, act=act, cfg=64, seed=h)
+    assert err < 2e-4, err
+    # what it must refuse: stride 1, other widths, a residual-after activation
+    assert L.egn_conv_plan_query(n, h, w, 3, 4, 64, 64, 3, 3, 1, 1, 0, 64, out) != 0
+    assert L.egn_conv_plan_query(n, h, w, 3, 4, 48, 48, 3, 3, 2, 1, 0, 64, out) != 0
+    assert L.egn_conv_plan_query(n, h, w, 16, 16, 64, 64, 3, 3, 2, 1, 0, 64, out) != 0
+
+
 @pytest.mark.parametrize('n,h,w,cin,cout,res,act', [
     (2, 64, 64, 48, 48, True, 1),      # the HRNet shape classes (SURVEY.md 2.1) at small batch
     (2, 32, 32, 96, 96, True, 1),
@@ -131,12 +149,15 @@ def test_conv_winograd_kernels(n, h, w, cin, cout, res, act):
     import ctypes as C
     from egonet_amd import _lib
     L = _lib.lib()
-    assert [L.egn_conv_config_kind(c) for c in (44, 45, 46, 51, 52, 56, 57)] == [0, 1, 1, 1, 1, 1, 1]
+    assert [L.egn_conv_config_kind(c) for c in (44, 45, 46, 51, 52, 56, 57, 59, 60, 61, 62)] == [0] + [1] * 10
     assert L.egn_conv_config_kind(47) == -1 and L.egn_conv_config_kind(53) == -1     # timing ablations: never selectable
+    assert L.egn_conv_config_kind(58) == -1 and L.egn_conv_config_kind(63) == -1     # stamp builds neither
     out = (C.c_int * 12)()
-    for cfg in (45, 46, 51, 52, 56, 57):    # 56 / 57: 4 waves on 32 tiles (two 8 x 8 images / an 8 x 16 tile)
+    # 56 / 57: 4 waves on 32 tiles (two 8 x 8 images / an 8 x 16 tile); 59..62 = conv_wino9_kernel (round 3: scalar
+    # item index math, one instruction stream for both frequency halves) on the geometries of 51 / 52 / 56 / 57
+    for cfg in (45, 46, 51, 52, 56, 57, 59, 60, 61, 62):
         rc = L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, cfg, out)
-        if (cfg in (46, 52, 56) and (h > 8 or w > 8)) or (cfg in (45, 46) and cout % 48):
+        if (cfg in (46, 52, 56, 60, 61) and (h > 8 or w > 8)) or (cfg in (45, 46) and cout % 48):
             assert rc != 0
             continue
         assert rc == 0

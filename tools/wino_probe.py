@@ -35,12 +35,14 @@ def main():
         wt = torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (3 * cin ** 0.5))
         wd = engine.pack_conv_weight(wt).cuda()
         wu = engine.pack_wino_weight(wt).cuda()
+        wu43 = engine.pack_wino43_weight(wt).cuda() if cout % 48 == 0 and cin % 4 == 0 else None
         sc = (torch.rand(cout, generator=g) + 0.5).cuda()
         sh = torch.randn(cout, generator=g).cuda()
         res = torch.randn(n, h, w, cout, generator=g).cuda() if a.res else None
         flops = 2.0 * n * h * w * cout * cin * 9
         dcfg = dcfgs[si] if len(dcfgs) > 1 else dcfgs[0]
-        cases = [('direct%d' % dcfg, dcfg, wd)] + [('wino%s' % c, int(c), wu) for c in a.wino.split(',')]
+        cases = [('direct%d' % dcfg, dcfg, wd)] + [('wino%s' % c, int(c), wu43 if L.egn_conv_config_kind(int(c)) == 2 else wu)
+                                                    for c in a.wino.split(',')]
         outs, ok = {}, []
         for name, cfg, wp in cases:
             y = torch.full((n, h, w, cout), float('nan'), device='cuda')
