@@ -130,7 +130,7 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (c.dma == 5 && (c.bi & 15) == 10) { snprintf(buf, len, "void conv_wino43_kernel<0>(ConvArgs)"); return 0; }
   if (c.dma == 5 && (c.bi & 15) >= 6) {
     static const char* geo9[4] = {"16, 16, 1, 8", "8, 8, 4, 8", "8, 8, 2, 4", "8, 16, 1, 4"};
-    snprintf(buf, len, "void conv_wino9_kernel<%s, 3>(ConvArgs)", geo9[(c.bi & 15) - 6]);
+    snprintf(buf, len, "void conv_wino9_kernel<%s, 3, 0>(ConvArgs)", geo9[(c.bi & 15) - 6]);
     return 0;
   }
   if (c.dma == 5)

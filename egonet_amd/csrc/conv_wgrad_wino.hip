@@ -87,68 +87,77 @@ struct WgwSel {
   float sr, tr, sc;
 };
 
-template <int TW, int TNB, int ABL, int S0, int S1>
-__device__ __forceinline__ void wgw_ksteps(const float* __restrict__ sp, int hb, int db, const WgwSel& w, int lane,
-                                           int tile, f32x4 (&acc)[2][3][3]) {
+// One LDS dword at a VGPR byte address + compile-time byte offset, as raw ISA.  Through plain loads the
+// compiler pairs the reads into ds_read2_b32 (8-bit offsets) and pays one v_add_u32 per pair for the stage /
+// K-step part of the address: 156 address adds per stage of 144 MFMAs -- and beside fp32 MFMAs every VALU
+// instruction costs matrix-pipe time (profiles/r3_mfma_tax.txt) while an LDS read costs nothing.  The 16-bit
+// immediate of ds_read_b32 holds every offset of a stage.  The reads are asynchronous for the compiler: the
+// values are tied to the `s_waitcnt lgkmcnt(0)` below (wgw_landed) before anything uses them.
+template <int OFF>
+__device__ __forceinline__ float wgw_lds(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b32 immediate");
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ void wgw_landed(float (&a)[15]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                 "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]));
+}
+
+template <int TW, int TNB, int ABL, int S>
+__device__ __forceinline__ void wgw_kstep(const unsigned (&ax)[2][3], const unsigned (&ae)[2][2], const WgwSel& w,
+                                          int lane, int tile, f32x4 (&acc)[2][3][3]) {
   using G = WgwGeom<TW, TNB>;
-  // the ten read bases of the stage (patch rows x columns, dy rows x columns): everything else is an
-  // immediate offset of the ds_read
-  const float* px[2][3];
-  const float* pe[2][2];
+  // K step S: tile row S >> 1; the left / right half of the 16-wide tile, or image S & 1 of the pair
+  constexpr int ho = ((TNB == 2 ? (S & 1) * G::HPI : 8 * (S & 1)) * G::PXD + 2 * (S >> 1) * G::HW * G::PXD) * 4;
+  constexpr int eo = ((TNB == 2 ? (S & 1) * G::DPI : 8 * (S & 1)) * G::PXD + 2 * (S >> 1) * TW * G::PXD) * 4;
+  float v[2][15];     // [0]: d[r][c][j] for (r, c, j) = 0..14, [1]: d 15..17 then e[r][c][j] 0..11
+  if constexpr ((ABL & 2) != 0) {
 #pragma unroll
-  for (int r = 0; r < 2; ++r) {
+    for (int k = 0; k < 30; ++k) v[k / 15][k % 15] = (float)(lane + k + tile + S);
+  } else {
+#define WGW_RD(K) v[(K) / 15][(K) % 15] = (K) < 18 ? wgw_lds<ho + 64 * ((K) % 3)>(ax[((K) / 9) % 2][(((K) / 3) % 3)]) \
+                                                      : wgw_lds<eo + 64 * ((K) % 3)>(ae[(((K)-18) / 6) % 2][((((K)-18) / 3) % 2)]);
+    WGW_RD(0) WGW_RD(1) WGW_RD(2) WGW_RD(3) WGW_RD(4) WGW_RD(5) WGW_RD(6) WGW_RD(7) WGW_RD(8) WGW_RD(9)
+    WGW_RD(10) WGW_RD(11) WGW_RD(12) WGW_RD(13) WGW_RD(14) WGW_RD(15) WGW_RD(16) WGW_RD(17) WGW_RD(18) WGW_RD(19)
+    WGW_RD(20) WGW_RD(21) WGW_RD(22) WGW_RD(23) WGW_RD(24) WGW_RD(25) WGW_RD(26) WGW_RD(27) WGW_RD(28) WGW_RD(29)
+#undef WGW_RD
+    wgw_landed(v[0]);
+    wgw_landed(v[1]);
+  }
+  float d[2][3][3], e[2][2][3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) px[r][c] = sp + (hb + w.hro[r] + w.hco[c]);
+  for (int k = 0; k < 18; ++k) d[k / 9][(k / 3) % 3][k % 3] = v[k / 15][k % 15];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) pe[r][c] = sp + (db + w.ero[r] + w.eco[c]);
+  for (int k = 0; k < 12; ++k) e[k / 6][(k / 3) % 2][k % 3] = v[(k + 18) / 15][(k + 18) % 15];
+  float T[3][3], V[2][3], R[2][3], M[2][3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) T[c][j] = __builtin_fmaf(w.sr, d[1][c][j], d[0][c][j]);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    V[0][j] = T[0][j] - T[1][j];
+    V[1][j] = __builtin_fmaf(w.sc, T[1][j], T[2][j]);
   }
 #pragma unroll
-  for (int s = S0; s < S1; ++s) {
-    // K step s: tile row s >> 1; the left / right half of the 16-wide tile, or image s & 1 of the pair
-    const int ho = (TNB == 2 ? (s & 1) * G::HPI : 8 * (s & 1)) * G::PXD + 2 * (s >> 1) * G::HW * G::PXD;
-    const int eo = (TNB == 2 ? (s & 1) * G::DPI : 8 * (s & 1)) * G::PXD + 2 * (s >> 1) * TW * G::PXD;
-    float d[2][3][3], e[2][2][3];
+  for (int c = 0; c < 2; ++c)
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int j = 0; j < 3; ++j) R[c][j] = __builtin_fmaf(w.tr, e[1][c][j], e[0][c][j]);
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          d[r][c][j] = (ABL & 2) ? (float)(lane + r + c + j + tile) : px[r][c][ho + 16 * j];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-          e[r][c][j] = (ABL & 2) ? (float)(lane - r + c + j + s) : pe[r][c][eo + 16 * j];
-    float T[3][3], V[2][3], R[2][3], M[2][3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) T[c][j] = __builtin_fmaf(w.sr, d[1][c][j], d[0][c][j]);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      V[0][j] = T[0][j] - T[1][j];
-      V[1][j] = __builtin_fmaf(w.sc, T[1][j], T[2][j]);
-    }
-#pragma unroll
-    for (int c = 0; c < 2; ++c)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) R[c][j] = __builtin_fmaf(w.tr, e[1][c][j], e[0][c][j]);
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      M[0][j] = R[0][j];
-      M[1][j] = __builtin_fmaf(w.sc, R[0][j], R[1][j]);
-    }
-#pragma unroll
-    for (int fj = 0; fj < 2; ++fj)
-#pragma unroll
-      for (int ja = 0; ja < 3; ++ja)
-#pragma unroll
-        for (int jc = 0; jc < 3; ++jc)
-          acc[fj][ja][jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(M[fj][ja], V[fj][jc], acc[fj][ja][jc], 0, 0, 0);
+  for (int j = 0; j < 3; ++j) {
+    M[0][j] = R[0][j];
+    M[1][j] = __builtin_fmaf(w.sc, R[0][j], R[1][j]);
   }
+#pragma unroll
+  for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+    for (int ja = 0; ja < 3; ++ja)
+#pragma unroll
+      for (int jc = 0; jc < 3; ++jc)
+        acc[fj][ja][jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(M[fj][ja], V[fj][jc], acc[fj][ja][jc], 0, 0, 0);
 }
 
 // ABL != 0: timing ablations (wrong results by construction; EGN_WGW_ABL, tools/wgrad_probe.py only):
@@ -176,8 +185,15 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino_kernel(WgradArgs a) {
                     (unsigned)((size_t)a.N * a.H * a.W * a.Cout * 4), 0x00020000u};
   const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(lds_ptr_wgw_t)wgw_smem;
 
-  // DMA slot of this lane in instruction i = wave + 8k: (quad << 16 | image << 12 | row << 6 | column), -1 = pad
-  int meta[IT];
+  // DMA slot of this lane in instruction i = wave + 8k: image dn, row dy, column dx of the stage's halo (x) or
+  // dy tile and the channel quad.  Per lane and instruction, ONCE: the byte offset relative to the tile's first
+  // (image, row - 1, column - 1) and the packed coordinates for the bounds test -- per stage the offset is then
+  // `tile base (SGPR) + rel` and the zero-padding test is two subtractions and two ands on guard-bit fields
+  // (7 VALU per instruction instead of ~20: beside fp32 MFMAs every VALU instruction costs matrix-pipe time).
+  //   mg = 0x808080 | dn << 16 | dy << 8 | dx (a pad slot: all fields 127, never in range)
+  //   t1 = mg - lo            field f keeps its guard bit iff v_f >= lo_f
+  //   t2 = X - mg             X_f = hi_f + 255: field f = 128 + hi_f - 1 - v_f keeps its guard bit iff v_f < hi_f
+  unsigned rel[IT], mg[IT];
 #pragma unroll
   for (int k = 0; k < IT; ++k) {
     const int i = wave + 8 * k;
@@ -201,7 +217,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino_kernel(WgradArgs a) {
       col = r - row * TW;
       ok = q < 12;
     }
-    meta[k] = ok ? ((q << 16) | (img << 12) | (row << 6) | col) : -1;
+    const int C_ = i < G::NHI ? a.Cin : a.Cout;
+    rel[k] = ok ? (unsigned)(((img * a.H + row) * a.W + col) * C_ + 4 * q) * 4u : 0u;
+    mg[k] = ok ? (0x808080u | (unsigned)(img << 16) | (unsigned)(row << 8) | (unsigned)col) : 0x00ffffffu;
   }
 
   const int tiles_xy = a.tiles_x * a.tiles_y;
@@ -211,15 +229,20 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino_kernel(WgradArgs a) {
     const int r_ = (TILE)-tb_ * tiles_xy;                                                                \
     const int ty_ = r_ / a.tiles_x, tx_ = r_ - ty_ * a.tiles_x;                                          \
     const int n0_ = tb_ * TNB, y0_ = ty_ * 8, x0_ = tx_ * TW;                                            \
+    const unsigned hn_ = (unsigned)min(a.N - n0_, 127) + 255u;                                           \
+    /* scalars of the tile: [0] the halo of x (first pixel (y0 - 1, x0 - 1)), [1] the dy tile */         \
+    unsigned base_[2], lo_[2], X_[2];                                                                    \
+    _Pragma("unroll") for (int e_ = 0; e_ < 2; ++e_) {                                                   \
+      const int ys_ = y0_ - (e_ == 0 ? 1 : 0), xs_ = x0_ - (e_ == 0 ? 1 : 0);                            \
+      const int C_ = e_ == 0 ? a.Cin : a.Cout, c0_ = e_ == 0 ? ci0 : co0;                                \
+      base_[e_] = (unsigned)(((n0_ * a.H + ys_) * a.W + xs_) * C_ + c0_) * 4u;                           \
+      lo_[e_] = (unsigned)max(0, -xs_) | ((unsigned)max(0, -ys_) << 8);                                  \
+      X_[e_] = ((unsigned)min(a.W - xs_, 127) + 255u) + (((unsigned)min(a.H - ys_, 127) + 255u) << 8) + (hn_ << 16); \
+    }                                                                                                    \
     _Pragma("unroll") for (int k = 0; k < IT; ++k) {                                                     \
-      const bool isx_ = wave + 8 * k < G::NHI;        /* wave uniform: halo of x, else dy tile */        \
-      int m_ = meta[k];                                                                                  \
-      asm volatile("" : "+v"(m_));                    /* keep the decode inside the loop: 9 registers, not 36 */ \
-      const int n_ = n0_ + ((m_ >> 12) & 15);                                                            \
-      const int iy_ = y0_ + ((m_ >> 6) & 63) - (isx_ ? 1 : 0), ix_ = x0_ + (m_ & 63) - (isx_ ? 1 : 0);   \
-      const int C_ = isx_ ? a.Cin : a.Cout, c0_ = isx_ ? ci0 : co0;                                      \
-      const bool in_ = m_ >= 0 && n_ < a.N && iy_ >= 0 && iy_ < a.H && ix_ >= 0 && ix_ < a.W;            \
-      OUT[k] = in_ ? (unsigned)(((n_ * a.H + iy_) * a.W + ix_) * C_ + c0_ + 4 * ((m_ >> 16) & 15)) * 4u : EGN_OOB; \
+      const int e_ = wave + 8 * k < G::NHI ? 0 : 1;   /* wave uniform */                                 \
+      const unsigned t_ = (mg[k] - lo_[e_]) & (X_[e_] - mg[k]) & 0x808080u;                              \
+      OUT[k] = t_ == 0x808080u ? base_[e_] + rel[k] : EGN_OOB;                                           \
     }                                                                                                    \
   }
 #define WGW_ISSUE(K, P, OFF)                                                                             \
@@ -276,17 +299,35 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_wino_kernel(WgradArgs a) {
     __builtin_amdgcn_s_barrier();        // everyone's have; everyone is done reading the other stage
     asm volatile("" ::: "memory");
     WGW_CLK()
-    const float* sp = sm + par * (G::STAGE * 4);
+    // the ten LDS read bases of the stage (byte addresses: patch rows x columns, dy rows x columns); everything
+    // else is an immediate of the ds_read
+    unsigned ax[2][3], ae[2][2];
+    {
+      const unsigned sb = lds0 + (unsigned)(par * (G::STAGE * 16));
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ax[r][c] = sb + (unsigned)(hb + sel.hro[r] + sel.hco[c]) * 4u;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) ae[r][c] = sb + (unsigned)(db + sel.ero[r] + sel.eco[c]) * 4u;
+      }
+    }
     // the first K step goes out before the next stage's DMA is computed and issued: the matrix pipe
     // has work while the offsets are formed (all waves pass the barrier together)
-    wgw_ksteps<TW, TNB, ABL, 0, 1>(sp, hb, db, sel, lane, tile, acc);
+    wgw_kstep<TW, TNB, ABL, 0>(ax, ae, sel, lane, tile, acc);
     if (!(ABL & 1) && tile + 1 < t_end) {
       WGW_OFFS(tile + 1, off)
 #pragma unroll
       for (int k = 0; k < IT; ++k) WGW_ISSUE(k, par ^ 1, off)
     }
     asm volatile("" ::: "memory");       // the remaining LDS reads stay below the DMA issue
-    wgw_ksteps<TW, TNB, ABL, 1, 8>(sp, hb, db, sel, lane, tile, acc);
+    wgw_kstep<TW, TNB, ABL, 1>(ax, ae, sel, lane, tile, acc);
+    wgw_kstep<TW, TNB, ABL, 2>(ax, ae, sel, lane, tile, acc);
+    wgw_kstep<TW, TNB, ABL, 3>(ax, ae, sel, lane, tile, acc);
+    wgw_kstep<TW, TNB, ABL, 4>(ax, ae, sel, lane, tile, acc);
+    wgw_kstep<TW, TNB, ABL, 5>(ax, ae, sel, lane, tile, acc);
+    wgw_kstep<TW, TNB, ABL, 6>(ax, ae, sel, lane, tile, acc);
+    wgw_kstep<TW, TNB, ABL, 7>(ax, ae, sel, lane, tile, acc);
     par ^= 1;
     WGW_CLK()
   }

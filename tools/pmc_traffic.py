@@ -30,13 +30,21 @@ def per_kernel(root, counter):
 
 
 def main():
-    fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
-    write = per_kernel(sys.argv[2], 'WRITE_SIZE')
+    # one or more (FETCH_SIZE run, WRITE_SIZE run) directory pairs: bench.py, tools/train_hc_bench.py,
+    # tools/train_bench.py -- merged into one table keyed by kernel symbol
+    fetch, write = defaultdict(list), defaultdict(list)
+    dirs = sys.argv[1:]
+    for i in range(0, len(dirs) - 1, 2):
+        for k, v in per_kernel(dirs[i], 'FETCH_SIZE').items():
+            fetch[k] += v
+        for k, v in per_kernel(dirs[i + 1], 'WRITE_SIZE').items():
+            write[k] += v
     out = {'_note': 'HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, mean over all dispatches of '
-                    'one `bench.py --steps 1 --warmup 1` run per counter (gfx950: FETCH_SIZE counts 64 B per '
+                    'one short run per counter and program (bench.py, tools/train_hc_bench.py, tools/train_bench.py) (gfx950: FETCH_SIZE counts 64 B per '
                     '128-B request of a wide stream)', 'kernels': {}}
     for name in sorted(set(fetch) | set(write)):
-        if not any(k in name for k in ('conv_', 'fuse', 'decode', 'nchw', 'nhwc', 'kpts', 'pose', 'unnorm', 'ramps')):
+        if not any(k in name for k in ('conv_', 'fuse', 'decode', 'nchw', 'nhwc', 'kpts', 'pose', 'unnorm', 'ramps', 'gemm',
+                                       'bn_', 'colreduce', 'wgrad', 'adam', 'elem_loss', 'mse_')):
             continue
         f = fetch.get(name, [])
         w = write.get(name, [])
