@@ -97,7 +97,7 @@ def _symbol(cfg, cout=None):
         if cout is not None and cout % 48 and 'conv_wino8_kernel' in sym:
             sym = sym.replace(', 3>(', ', 2>(')
         if cout is not None and cout % 48 and 'conv_wino9_kernel' in sym:
-            sym = sym.replace(', 3, 0>(', ', 2, 0>(')
+            sym = sym.replace(', 3, 0, ', ', 2, 0, ')
         return sym
     return None
 

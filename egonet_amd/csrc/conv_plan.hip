@@ -96,6 +96,9 @@ static const ConvConfig kConfigs[] = {
     {64, 4, 1, 1, 4, 0, 0, 6},     // the stem: 3x3 s2, 3 -> 64 channels, K = (tap, channel) (conv_stem.hip)
     {65, 6, 1, 1, 3, 4, 10, 5},    // fused Winograd F(4x4,3x3), conv_wino43_kernel: filter from egn ... kind 2
     {66, 6, 1, 1, 3, 4, 0x1a, 5},  // 65 with s_memtime stamps
+    {67, 4, 1, 1, 3, 4, 11, 5},    // conv_wino9_kernel with 8-channel stages: 8 x 16 tile, 4 waves, TWO blocks per CU
+    {68, 4, 1, 1, 3, 4, 12, 5},    // ... two 8 x 8 images
+    {69, 4, 1, 1, 3, 4, 0x4b, 5},  // 67 with s_memtime stamps (tools/wino_clk.py)
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -128,9 +131,13 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 6) { snprintf(buf, len, "conv_stem_kernel(ConvArgs)"); return 0; }
   if (c.dma == 5 && (c.bi & 15) == 10) { snprintf(buf, len, "void conv_wino43_kernel<0>(ConvArgs)"); return 0; }
+  if (c.dma == 5 && ((c.bi & 15) == 11 || (c.bi & 15) == 12)) {
+    snprintf(buf, len, "void conv_wino9_kernel<%s, 4, 3, 0, 2>(ConvArgs)", (c.bi & 15) == 11 ? "8, 16, 1" : "8, 8, 2");
+    return 0;
+  }
   if (c.dma == 5 && (c.bi & 15) >= 6) {
     static const char* geo9[4] = {"16, 16, 1, 8", "8, 8, 4, 8", "8, 8, 2, 4", "8, 16, 1, 4"};
-    snprintf(buf, len, "void conv_wino9_kernel<%s, 3, 0>(ConvArgs)", geo9[(c.bi & 15) - 6]);
+    snprintf(buf, len, "void conv_wino9_kernel<%s, 3, 0, 4>(ConvArgs)", geo9[(c.bi & 15) - 6]);
     return 0;
   }
   if (c.dma == 5)
@@ -205,7 +212,8 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
     }
     // co-tile 48 (4- and 8-wave kernels) or 32 (8-wave kernels only): egn_wino_cot in conv_wino.hip
     if (a.Cout % 48 != 0 && !(a.Cout % 32 == 0 && (cf.bi & 15) >= 2)) return false;
-    const int geo = (cf.bi & 15) >= 6 ? (cf.bi & 15) - 4 : (cf.bi & 15);   // 6..9: conv_wino9_kernel on 2..5's tiles
+    const int vv = cf.bi & 15;      // 6..9: conv_wino9_kernel on 2..5's tiles; 11 / 12: its 8-channel-stage form on 5 / 4's
+    const int geo = vv == 11 ? 5 : (vv == 12 ? 4 : (vv >= 6 ? vv - 4 : vv));
     if (geo == 4) { a.TH = 8; a.TW = 8; a.TNB = 2; }
     else if (geo == 5) { a.TH = 8; a.TW = 16; a.TNB = 1; }
     else if (geo == 1 || geo == 3) { a.TH = 8; a.TW = 8; a.TNB = 4; }

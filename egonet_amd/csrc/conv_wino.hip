@@ -920,15 +920,29 @@ __device__ __forceinline__ f32x4 wn_add4(f32x4 a, f32x4 b) { return f32x4{wn_add
 __device__ __forceinline__ f32x4 wn_fma4_s(float s, f32x4 b, f32x4 c) { return f32x4{wn_fma_s(s, b[0], c[0]), wn_fma_s(s, b[1], c[1]), wn_fma_s(s, b[2], c[2]), wn_fma_s(s, b[3], c[3])}; }
 __device__ __forceinline__ unsigned wn_udiv(unsigned x, unsigned magic) { return magic ? __umulhi(x, magic) : x; }
 
-template <int TH, int TW, int TNB, int NW = 8, int NT = 3, int CLK = 0>
+// KQ = channel quads per K stage: 4 (a whole 16-channel chunk of the packed filter, one 140 KB block per CU) or
+// 2 (half a chunk: 8-channel stages, 68 KB of LDS -- TWO 4-wave blocks per CU, one wave of each on every SIMD.
+// The blocks run out of phase: while one sits in its barrier, its exchange or its epilogue the other one's
+// MFMAs keep the matrix pipe busy -- profiles/r3_wino8_vs_wino9_timeline.txt has the lock-stepped 8-wave block
+// at 8 400 cycles per 16 channels against 6 144 of MFMA issue, plus 4 400 cycles of MFMA-free phases per item).
+// With KQ = 2 lane group kq reads quad kq & 1 and the float pair kq >> 1 of it: the MFMA's four k lanes cover
+// channels {0, 1} of both quads, then {2, 3}: KQ MFMAs per frequency and co sub-tile, the same VALU work per MFMA.
+template <int KQ> struct WinoVec;
+template <> struct WinoVec<4> { typedef f32x4 type; };
+template <> struct WinoVec<2> { typedef float __attribute__((ext_vector_type(2))) type; };
+
+template <int TH, int TW, int TNB, int NW = 8, int NT = 3, int CLK = 0, int KQ = EGN_CKQ>
 __global__ __launch_bounds__(64 * NW, 2) void conv_wino9_kernel(ConvArgs a) {
   constexpr int CO_T = 16 * NT;
-  constexpr int USL = 16 * EGN_CKQ * CO_T;
+  constexpr int USL = 16 * KQ * CO_T;           // float4 slots of one filter stage
+  constexpr int HS = EGN_CKQ / KQ;              // stages per 16-channel chunk
+  constexpr int UCH = 16 * EGN_CKQ * CO_T;      // float4 slots of one packed chunk
+  typedef typename WinoVec<KQ>::type vk_t;
   using G = WinoGeom<TH, TW, TNB>;
   constexpr int NTH = 64 * NW;
   constexpr int MTILES = NW / 2;
   static_assert(TNB * (TH / 2) * (TW / 2) == 16 * MTILES, "one m-tile per wave pair");
-  constexpr int SLOTS = EGN_CKQ * G::PLANE;
+  constexpr int SLOTS = KQ * G::PLANE;
   constexpr int IT = (SLOTS + NTH - 1) / NTH;
   constexpr int BUF = SLOTS;
   constexpr int UIT = USL / NTH;
@@ -958,6 +972,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino9_kernel(ConvArgs a) {
   const int fh = wave / MTILES;
   const int li = lane & 15;
   const int kq = lane >> 4;
+  const int kqq = kq % KQ, kqc = (kq / KQ) * KQ;   // this lane's quad of the stage, first float of its share
   const float sigma = fh == 0 ? 1.f : -1.f;     // wave-uniform sign of the one term that differs between the halves
 
   const int C = a.Cin, Co = a.Cout;
@@ -969,7 +984,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino9_kernel(ConvArgs a) {
   const u32x4 rxv = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu,
                      (unsigned)((size_t)a.N * a.H * a.W * C * 4), 0x00020000u};
   const u32x4 ruv = {(unsigned)uaddr, (unsigned)(uaddr >> 32) & 0xffffu,
-                     (unsigned)((size_t)nct * nchunk * USL * 16), 0x00020000u};
+                     (unsigned)((size_t)nct * nchunk * UCH * 16), 0x00020000u};
   const unsigned out_bytes = (unsigned)((size_t)a.N * a.Ho * a.Wo * Co * 4);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr =
@@ -984,7 +999,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino9_kernel(ConvArgs a) {
   for (int it = 0; it < IT; ++it) {
     const int e = it * NTH + tid;
     const int q = e / G::PLANE;
-    const int m = (e < SLOTS && q < EGN_CKQ) ? G::decode(e - q * G::PLANE) : -1;
+    const int m = (e < SLOTS && q < KQ) ? G::decode(e - q * G::PLANE) : -1;
     const int b_ = m >> 16, y_ = (m >> 8) & 255, x_ = m & 255;
     hyx[it] = m < 0 ? -1 : ((y_ << 16) | x_);
     hb[it] = m < 0 ? 0 : b_;
@@ -997,7 +1012,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino9_kernel(ConvArgs a) {
   {
     int pr[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) pr[r] = kq * G::PLANE + G::patch_base(mt, li, r >> 1) + r * G::ROFF;
+    for (int r = 0; r < 4; ++r) pr[r] = kqq * G::PLANE + G::patch_base(mt, li, r >> 1) + r * G::ROFF;
     prow[0] = fh == 0 ? pr[0] : pr[1];
     prow[1] = fh == 0 ? pr[2] : pr[3];
     prow[2] = fh == 0 ? pr[1] : pr[2];
@@ -1048,16 +1063,31 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino9_kernel(ConvArgs a) {
       OUT[it] = in_ ? (unsigned)(base_ + hrel[it]) : EGN_OOB;                                                \
     }                                                                                                        \
   }
+  // CH = stage index: chunk CH / HS, quads (CH % HS) * KQ ... of it
 #define W9_PIECE(K, P, OFF, CT, CH)                                                                  \
   {                                                                                                  \
     if ((K) < IT) {                                                                                  \
       if ((K)*NTH + wave * 64 < SLOTS)                                                               \
         wino_dma16(rxv, wino_lds_addr(sH + (P)*BUF + wave * 64) + (K)*NTH * 16, OFF[(K) < IT ? (K) : 0], \
-                   (unsigned)(CH)*64u);                                                              \
-    } else {                                                                                         \
+                   (unsigned)(CH) * (KQ * 16u));                                                     \
+    } else if constexpr (KQ == EGN_CKQ) {                                                            \
       wino_dma16(ruv, wino_lds_addr(sU + (P)*USL + wave * 64) + ((K)-IT) * NTH * 16, (unsigned)tid * 16u, \
                  (unsigned)(((CT)*nchunk + (CH)) * USL) * 16u + ((K)-IT) * NTH * 16);                \
+    } else {                                                                                         \
+      const unsigned ch_ = (unsigned)(CH) / HS, hs_ = (unsigned)(CH) - ch_ * HS;                     \
+      wino_dma16(ruv, wino_lds_addr(sU + (P)*USL + wave * 64) + ((K)-IT) * NTH * 16, urel[(K) >= IT ? (K)-IT : 0], \
+                 (((unsigned)(CT)*nchunk + ch_) * UCH + hs_ * (KQ * CO_T)) * 16u);                   \
     }                                                                                                \
+  }
+  // filter stage slot e = piece * NTH + tid -> frequency e / (KQ * CO_T): its KQ * CO_T slots sit EGN_CKQ * CO_T apart
+  // in the packed chunk
+  unsigned urel[KQ == EGN_CKQ ? 1 : UIT];
+  if constexpr (KQ != EGN_CKQ) {
+#pragma unroll
+    for (int k_ = 0; k_ < UIT; ++k_) {
+      const int e = k_ * NTH + tid, f_ = e / (KQ * CO_T);
+      urel[k_] = (unsigned)(f_ * (EGN_CKQ * CO_T) + (e - f_ * (KQ * CO_T))) * 16u;
+    }
   }
 
   int w = blockIdx.x;
@@ -1115,8 +1145,9 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino9_kernel(ConvArgs a) {
       for (int nt = 0; nt < NT; ++nt) acc[f][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     float rv[4][2][NT];
 
-    for (int c = 0; c < nchunk; ++c) {
-      const bool last = c + 1 == nchunk;
+    const int nstage = nchunk * HS;
+    for (int c = 0; c < nstage; ++c) {
+      const bool last = c + 1 == nstage;
       asm volatile("" ::: "memory");
       W9_CLK()
       if (c == 0 && !first) __builtin_amdgcn_s_waitcnt(0x4078);  // vmcnt(24): all but the last item's stores
@@ -1143,16 +1174,16 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino9_kernel(ConvArgs a) {
       // beside MFMAs): the scheduler sinks each V row to its first use, so the MFMAs of row 0 start while row
       // 1 is still being formed -- asm wrappers pinned all 64 instructions in front of the first MFMA.
       const float4* hb_ = sH + par * BUF;
-      f32x4 V[8];
+      vk_t V[8];
       constexpr int TOPP = 2;                                   // DMA pieces issued at the top of a K step ...
       constexpr int PERF = (NPIECE - TOPP + 7) / 8;             // ... and after each of the 8 frequencies
       static_assert(NPIECE <= TOPP + 8 * PERF, "every DMA piece has a slot");
       {
-        f32x4 dx[4], dy[4], ta[4];
+        vk_t dx[4], dy[4], ta[4];
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-          dx[cc] = *reinterpret_cast<const f32x4*>(&hb_[prow[0] + cc]);
-          dy[cc] = *reinterpret_cast<const f32x4*>(&hb_[prow[1] + cc]);
+          dx[cc] = *reinterpret_cast<const vk_t*>(reinterpret_cast<const float*>(&hb_[prow[0] + cc]) + kqc);
+          dy[cc] = *reinterpret_cast<const vk_t*>(reinterpret_cast<const float*>(&hb_[prow[1] + cc]) + kqc);
         }
         W9_NEXT(0) W9_NEXT(1)
 #pragma unroll
@@ -1162,11 +1193,11 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino9_kernel(ConvArgs a) {
       // (the second row's patch reads stay behind the first row's arithmetic: 32 fewer live registers)
       asm volatile("" ::: "memory");
       {
-        f32x4 dz[4], dw[4], tb_[4];
+        vk_t dz[4], dw[4], tb_[4];
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-          dz[cc] = *reinterpret_cast<const f32x4*>(&hb_[prow[2] + cc]);
-          dw[cc] = *reinterpret_cast<const f32x4*>(&hb_[prow[3] + cc]);
+          dz[cc] = *reinterpret_cast<const vk_t*>(reinterpret_cast<const float*>(&hb_[prow[2] + cc]) + kqc);
+          dw[cc] = *reinterpret_cast<const vk_t*>(reinterpret_cast<const float*>(&hb_[prow[3] + cc]) + kqc);
         }
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) tb_[cc] = sigma * dw[cc] + dz[cc];
@@ -1174,20 +1205,21 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino9_kernel(ConvArgs a) {
       }
 
       // ---- 8 frequencies x NT co sub-tiles x 4 k-steps ----
-      const float4* ub0 = sU + par * USL + (urow0 * EGN_CKQ + kq) * CO_T + li;
-      const float4* ub1 = sU + par * USL + (urow1 * EGN_CKQ + kq) * CO_T + li;
-      f32x4 bf[2][NT];
+      const float4* ub0 = sU + par * USL + (urow0 * KQ + kqq) * CO_T + li;
+      const float4* ub1 = sU + par * USL + (urow1 * KQ + kqq) * CO_T + li;
+      vk_t bf[2][NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *reinterpret_cast<const f32x4*>(&ub0[nt * 16]);
+      for (int nt = 0; nt < NT; ++nt) bf[0][nt] = *reinterpret_cast<const vk_t*>(reinterpret_cast<const float*>(&ub0[nt * 16]) + kqc);
 #pragma unroll
       for (int f = 0; f < 8; ++f) {
         if (f + 1 < 8) {
-          const float4* un = (f + 1 < 4 ? ub0 : ub1) + ((f + 1) & 3) * EGN_CKQ * CO_T;
+          const float4* un = (f + 1 < 4 ? ub0 : ub1) + ((f + 1) & 3) * KQ * CO_T;
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) bf[(f + 1) & 1][nt] = *reinterpret_cast<const f32x4*>(&un[nt * 16]);
+          for (int nt = 0; nt < NT; ++nt)
+            bf[(f + 1) & 1][nt] = *reinterpret_cast<const vk_t*>(reinterpret_cast<const float*>(&un[nt * 16]) + kqc);
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < KQ; ++s)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
             acc[f][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(V[f][s], bf[f & 1][nt][s], acc[f][nt], 0, 0, 0);
@@ -1344,7 +1376,7 @@ static int wino_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
 // persistent grid of the frequency-halves kernel: at most one block per CU, a multiple of 8 * nct so that
 // (a) blocks w, w+8, ... stay on one XCD and (b) a block's items all have the same co-tile
 // (ct = (w >> 3) % nct and w advances by the grid size) -- its BatchNorm partial row covers one co-tile
-static int wino8_grid(const ConvArgs& a, int tnb) {
+static int wino8_grid(const ConvArgs& a, int tnb, int blocks_per_cu = 1) {
   const int cot = egn_wino_cot(a.Cout);
   static int cus = 0;
   if (!cus) {
@@ -1357,7 +1389,7 @@ static int wino8_grid(const ConvArgs& a, int tnb) {
   const int nct = a.Cout / (cot ? cot : 48);
   const int ntile = a.tiles_x * a.tiles_y * ((a.N + tnb - 1) / tnb);
   const int nwork = ((ntile + 7) / 8) * 8 * nct;
-  int cap = cus / (8 * nct) * (8 * nct);
+  int cap = blocks_per_cu * cus / (8 * nct) * (8 * nct);
   if (cap <= 0) cap = 8 * nct;
   return nwork < cap ? nwork : cap;
 }
@@ -1753,24 +1785,24 @@ size_t egn_conv_wino43_lds_bytes(int clk) { return (size_t)W43_RING * W43_STAGE 
 
 static unsigned wino_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
-template <int TH, int TW, int TNB, int NW, int NT, int CLK = 0>
+template <int TH, int TW, int TNB, int NW, int NT, int CLK = 0, int KQ = EGN_CKQ>
 static int wino9_launch_nt(ConvArgs a, size_t lds, hipStream_t stream) {
   static bool raised[EGN_MAX_DEVICES];
   if (egn_first_use_on_device(raised)) {
-    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino9_kernel<TH, TW, TNB, NW, NT, CLK>),
+    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino9_kernel<TH, TW, TNB, NW, NT, CLK, KQ>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
   }
   a.mg_nct = wino_magic(a.Cout / (16 * NT));
   a.mg_txy = wino_magic(a.tiles_x * a.tiles_y);
   a.mg_tx = wino_magic(a.tiles_x);
-  const int grid = wino8_grid(a, TNB);
-  hipLaunchKernelGGL((conv_wino9_kernel<TH, TW, TNB, NW, NT, CLK>), dim3(grid), dim3(64 * NW), lds, stream, a);
+  const int grid = wino8_grid(a, TNB, KQ == EGN_CKQ ? 1 : 2);     // half-chunk stages: two blocks per CU
+  hipLaunchKernelGGL((conv_wino9_kernel<TH, TW, TNB, NW, NT, CLK, KQ>), dim3(grid), dim3(64 * NW), lds, stream, a);
   return (int)hipGetLastError();
 }
-template <int TH, int TW, int TNB, int NW = 8>
+template <int TH, int TW, int TNB, int NW = 8, int KQ = EGN_CKQ>
 static int wino9_launch(const ConvArgs& a, size_t lds, hipStream_t stream) {
-  if (egn_wino_cot(a.Cout) == 48) return wino9_launch_nt<TH, TW, TNB, NW, 3>(a, lds, stream);
-  if (egn_wino_cot(a.Cout) == 32) return wino9_launch_nt<TH, TW, TNB, NW, 2>(a, lds, stream);
+  if (egn_wino_cot(a.Cout) == 48) return wino9_launch_nt<TH, TW, TNB, NW, 3, 0, KQ>(a, lds, stream);
+  if (egn_wino_cot(a.Cout) == 32) return wino9_launch_nt<TH, TW, TNB, NW, 2, 0, KQ>(a, lds, stream);
   return EGN_E_BADARG;
 }
 
@@ -1805,10 +1837,12 @@ static int wino43_launch(ConvArgs a, size_t lds, hipStream_t stream) {
 // rows of the BatchNorm partial table a launch writes (0 = this variant has no fused statistics)
 int egn_conv_wino_stats_rows(const ConvArgs& a, int variant) {
   int v = variant & 15;
-  if ((variant >> 4) || v < 2 || v >= 10) return 0;      // (10: the F(4x4,3x3) kernel has no fused statistics)
+  if ((variant >> 4) || v < 2 || v == 10 || v > 12) return 0;      // (10: the F(4x4,3x3) kernel has no fused statistics)
+  const int per_cu = v >= 11 ? 2 : 1;
+  if (v >= 11) v = v == 11 ? 5 : 4;   // 11 / 12: conv_wino9_kernel with 8-channel stages on the tiles of 5 / 4
   if (v >= 6) v -= 4;              // variants 6..9 = conv_wino9_kernel on the geometries of 2..5
   const int tnb = v == 3 ? 4 : (v == 4 ? 2 : 1);
-  return wino8_grid(a, tnb);       // one partial row per block
+  return wino8_grid(a, tnb, per_cu);       // one partial row per block
 }
 
 // variant 0: 16 x 16 pixel tile of one image; variant 1: four 8 x 8 images (the 8 x 8 maps);
@@ -1816,6 +1850,12 @@ int egn_conv_wino_stats_rows(const ConvArgs& a, int variant) {
 size_t egn_conv_wino_lds_bytes(int variant, int cout) {
   if ((variant & 15) == 10) return egn_conv_wino43_lds_bytes(variant >> 4);
   int v = variant & 15;
+  if (v == 11 || v == 12) {        // 8-channel stages, 4 waves: half the filter stage and half the halo planes
+    const int cot = egn_wino_cot(cout) ? egn_wino_cot(cout) : WN_CO;
+    const size_t halo2 = 2 * (size_t)(v == 11 ? WinoGeom<8, 16, 1>::PLANE : WinoGeom<8, 8, 2>::PLANE);
+    return (2 * (size_t)(16 * 2 * cot) + 2 * halo2) * 16 + (size_t)4 * 2 * cot * sizeof(double) +
+           ((variant >> 4) == 4 ? 4 * 48 * sizeof(unsigned long long) : 0);     // stamp build
+  }
   if (v >= 6) v -= 4;              // conv_wino9_kernel: the LDS image of conv_wino8_kernel
   size_t halo = (v & 1) ? WinoDims<8, 8, 4>::BUF : WinoDims<16, 16, 1>::BUF;
   if (v >= 2) halo = (v & 1) ? EGN_CKQ * WinoGeom<8, 8, 4>::PLANE : EGN_CKQ * WinoGeom<16, 16, 1>::PLANE;
@@ -1841,11 +1881,14 @@ int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t
     case 7: return wino9_launch<8, 8, 4>(a, lds, stream);
     case 8: return wino9_launch<8, 8, 2, 4>(a, lds, stream);
     case 9: return wino9_launch<8, 16, 1, 4>(a, lds, stream);
+    case 11: return wino9_launch<8, 16, 1, 4, 2>(a, lds, stream);   // 8-channel stages, two blocks per CU
+    case 12: return wino9_launch<8, 8, 2, 4, 2>(a, lds, stream);
     case 0x12: return wino8_launch<16, 16, 1, 16>(a, lds, stream);
     case 0x22: return wino8_launch<16, 16, 1, 7>(a, lds, stream);
     case 0x32: return wino8_launch<16, 16, 1, 3>(a, lds, stream);
     case 0x42: return wino8_launch<16, 16, 1, 32>(a, lds, stream);   // timeline stamps (tools/wino_clk.py)
     case 0x46: return egn_wino_cot(a.Cout) == 48 ? wino9_launch_nt<16, 16, 1, 8, 3, 1>(a, lds, stream) : EGN_E_BADARG;
+    case 0x4b: return egn_wino_cot(a.Cout) == 48 ? wino9_launch_nt<8, 16, 1, 4, 3, 1, 2>(a, lds, stream) : EGN_E_BADARG;
     case 0x10: return wino_launch<16, 16, 1, 15>(a, lds, stream);
     case 0x20: return wino_launch<16, 16, 1, 7>(a, lds, stream);
     case 0x30: return wino_launch<16, 16, 1, 3>(a, lds, stream);

@@ -149,15 +149,16 @@ def test_conv_winograd_kernels(n, h, w, cin, cout, res, act):
     import ctypes as C
     from egonet_amd import _lib
     L = _lib.lib()
-    assert [L.egn_conv_config_kind(c) for c in (44, 45, 46, 51, 52, 56, 57, 59, 60, 61, 62)] == [0] + [1] * 10
+    assert [L.egn_conv_config_kind(c) for c in (44, 45, 46, 51, 52, 56, 57, 59, 60, 61, 62, 67, 68)] == [0] + [1] * 12
     assert L.egn_conv_config_kind(47) == -1 and L.egn_conv_config_kind(53) == -1     # timing ablations: never selectable
     assert L.egn_conv_config_kind(58) == -1 and L.egn_conv_config_kind(63) == -1     # stamp builds neither
     out = (C.c_int * 12)()
     # 56 / 57: 4 waves on 32 tiles (two 8 x 8 images / an 8 x 16 tile); 59..62 = conv_wino9_kernel (round 3: scalar
-    # item index math, one instruction stream for both frequency halves) on the geometries of 51 / 52 / 56 / 57
-    for cfg in (45, 46, 51, 52, 56, 57, 59, 60, 61, 62):
+    # item index math, one instruction stream for both frequency halves) on the geometries of 51 / 52 / 56 / 57;
+    # 67 / 68 = conv_wino9_kernel with 8-channel stages (two 4-wave blocks per CU) on the tiles of 62 / 61
+    for cfg in (45, 46, 51, 52, 56, 57, 59, 60, 61, 62, 67, 68):
         rc = L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, cfg, out)
-        if (cfg in (46, 52, 56, 60, 61) and (h > 8 or w > 8)) or (cfg in (45, 46) and cout % 48):
+        if (cfg in (46, 52, 56, 60, 61, 68) and (h > 8 or w > 8)) or (cfg in (45, 46) and cout % 48):
             assert rc != 0
             continue
         assert rc == 0

@@ -33,6 +33,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--B', type=int, default=4096)
     ap.add_argument('--H', type=int, default=1024)
+    ap.add_argument('--data', default='randn', choices=['randn', 'zeros'],
+                    help='operand values: zeros toggle no datapath bits -- the time difference is the clock (power) share')
     a = ap.parse_args()
     L = _lib.lib()
     torch.cuda.set_device(0)
@@ -43,6 +45,8 @@ def main():
     act2 = torch.randn(B, H, generator=g).cuda()
     W = (torch.randn(H, H, generator=g) / H ** 0.5).cuda()   # [out][in]
     bias = torch.randn(H, generator=g).cuda()
+    if a.data == 'zeros':
+        act.zero_(); act2.zero_(); W.zero_(); bias.zero_()
     cases = [
         ('NT fwd  z = a W^T + b', 0, act, W, bias, B, H, H, (act.double() @ W.double().t() + bias.double()), (0, 1, 2, 3)),
         ('NN dgrad da = dz W', 1, act, W, None, B, H, H, (act.double() @ W.double()), (0, 1, 2)),

@@ -23,6 +23,9 @@ def main():
     ap.add_argument('--iters', type=int, default=20)
     ap.add_argument('--rounds', type=int, default=3)
     ap.add_argument('--res', type=int, default=1)
+    ap.add_argument('--data', default='randn', choices=['randn', 'zeros', 'ones'],
+                    help='operand VALUES (timing only): zeros / ones toggle far fewer datapath bits than random data -- '
+                         'the difference is the power-management (clock) share of a kernel time')
     a = ap.parse_args()
     L = _lib.lib()
     torch.cuda.set_device(0)
@@ -36,9 +39,16 @@ def main():
         wd = engine.pack_conv_weight(wt).cuda()
         wu = engine.pack_wino_weight(wt).cuda()
         wu43 = engine.pack_wino43_weight(wt).cuda() if cout % 48 == 0 and cin % 4 == 0 else None
+        if a.data != 'randn':
+            fill = 0.0 if a.data == 'zeros' else 1.0
+            x.fill_(fill); wd.fill_(fill); wu.fill_(fill)
+            if wu43 is not None:
+                wu43.fill_(fill)
         sc = (torch.rand(cout, generator=g) + 0.5).cuda()
         sh = torch.randn(cout, generator=g).cuda()
         res = torch.randn(n, h, w, cout, generator=g).cuda() if a.res else None
+        if res is not None and a.data != 'randn':
+            res.zero_()
         flops = 2.0 * n * h * w * cout * cin * 9
         dcfg = dcfgs[si] if len(dcfgs) > 1 else dcfgs[0]
         cases = [('direct%d' % dcfg, dcfg, wd)] + [('wino%s' % c, int(c), wu43 if L.egn_conv_config_kind(int(c)) == 2 else wu)
