@@ -23,6 +23,9 @@ int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t
 int egn_conv_launch_stem(const ConvArgs& a, size_t lds, hipStream_t stream);   // conv_stem.hip
 bool egn_conv_stem_applies(const ConvArgs& a);
 size_t egn_conv_stem_lds_bytes();
+int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, hipStream_t stream);          // conv_wino4.hip
+bool egn_conv_wino4_applies(const ConvArgs& a);
+size_t egn_conv_wino4_lds_bytes();
 size_t egn_conv_wino_lds_bytes(int variant, int cout);
 int egn_conv_wino_stats_rows(const ConvArgs& a, int variant);
 
@@ -99,6 +102,14 @@ static const ConvConfig kConfigs[] = {
     {67, 4, 1, 1, 3, 4, 11, 5},    // conv_wino9_kernel with 8-channel stages: 8 x 16 tile, 4 waves, TWO blocks per CU
     {68, 4, 1, 1, 3, 4, 12, 5},    // ... two 8 x 8 images
     {69, 4, 1, 1, 3, 4, 0x4b, 5},  // 67 with s_memtime stamps (tools/wino_clk.py)
+    {70, 12, 1, 1, 3, 0, 0, 7},    // fused Winograd F(4x4,3x3), conv_wino4_kernel (conv_wino4.hip): filter kind 3
+    {71, 12, 1, 1, 3, 0, 1, 7},    // timing ablations of 70 (WRONG RESULTS, tools/wino_probe.py only): no input transform
+    {72, 12, 1, 1, 3, 0, 2, 7},    // ... no MFMAs
+    {73, 12, 1, 1, 3, 0, 4, 7},    // ... no exchange / output transform / stores
+    {74, 12, 1, 1, 3, 0, 8, 7},    // ... no filter loads
+    {75, 12, 1, 1, 3, 0, 16, 7},   // ... no halo DMA
+    {76, 12, 1, 1, 3, 0, 7, 7},    // ... only DMA + filter loads + barriers
+    {77, 12, 1, 1, 3, 0, 32, 7},   // ... halo reads without bank conflicts
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -119,6 +130,7 @@ extern "C" int egn_conv_config_kind(int cfg) {
   if (cfg < 1 || cfg > kNumConfigs) return -1;
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 3) return -1;  // retired ids
+  if (c.dma == 7) return c.bi ? -1 : 3;   // F(4x4,3x3) filter in the register-feed layout (engine.pack_wino4_weight)
   if (c.dma != 5) return 0;
   if (c.bi >> 4) return -1;
   return (c.bi & 15) == 10 ? 2 : 1;     // 2: F(4x4,3x3) filter (engine.pack_wino43_weight)
@@ -130,6 +142,7 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (cfg < 1 || cfg > kNumConfigs || !buf || len < 8) return EGN_E_BADARG;
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 6) { snprintf(buf, len, "conv_stem_kernel(ConvArgs)"); return 0; }
+  if (c.dma == 7) { snprintf(buf, len, "void conv_wino4_kernel<%d>(ConvArgs)", c.bi); return 0; }
   if (c.dma == 5 && (c.bi & 15) == 10) { snprintf(buf, len, "void conv_wino43_kernel<0>(ConvArgs)"); return 0; }
   if (c.dma == 5 && ((c.bi & 15) == 11 || (c.bi & 15) == 12)) {
     snprintf(buf, len, "void conv_wino9_kernel<%s, 4, 3, 0, 2>(ConvArgs)", (c.bi & 15) == 11 ? "8, 16, 1" : "8, 8, 2");
@@ -175,6 +188,7 @@ static size_t lds_stage_bytes(const ConvArgs& a, const ConvConfig& cf) {
 }
 static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
   if (cf.dma == 6) return egn_conv_stem_lds_bytes();
+  if (cf.dma == 7) return egn_conv_wino4_lds_bytes();
   if (cf.dma == 5) return egn_conv_wino_lds_bytes(cf.bi, a.Cout);
   if (cf.dma == 4 && cf.bi == 2) return (size_t)(3 * 336 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // chunk ring + filter
   if (cf.dma == 4) return (size_t)(2 * 3 * 192 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // 2 halo buffers + filter
@@ -192,6 +206,16 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
     a.npix = 33 * 33; a.npixp = (a.npix + 15) & ~15; a.tps = 9;
     a.tiles_x = (a.Wo + 15) / 16;
     a.tiles_y = (a.Ho + 15) / 16;
+    if (cost_out) *cost_out = 0.0;
+    return true;
+  }
+  if (cf.dma == 7) {
+    // conv_wino4.hip: 16 x 32 pixel regions of whole-region maps, 8-channel stages, 48-channel co-tiles
+    if (!egn_conv_wino4_applies(a)) return false;
+    a.TH = 16; a.TW = 32; a.TNB = 1; a.HH = 18; a.HW = 34;
+    a.npix = 18 * 34; a.npixp = (a.npix + 15) & ~15; a.tps = 36;
+    a.tiles_x = a.Wo / 32;
+    a.tiles_y = a.Ho / 16;
     if (cost_out) *cost_out = 0.0;
     return true;
   }
@@ -347,6 +371,7 @@ int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {
   const ConvConfig& cf = kConfigs[cfg_id - 1];
   const size_t lds = lds_bytes_for(a, cf);
   if (cf.dma == 6) return egn_conv_launch_stem(a, lds, stream);
+  if (cf.dma == 7) return egn_conv_launch_wino4(a, lds, cf.bi, stream);
   if (cf.dma == 5) return egn_conv_launch_wino(a, lds, cf.bi, stream);
   if (cf.dma == 4) return egn_conv_launch_c48(a, lds, cf.bi == 2 ? -1 : cf.bi == 1 ? 0 : cf.wm, stream);
   if (cf.dma == 3) return EGN_E_BADARG;

@@ -1,0 +1,503 @@
+// conv_wino4.hip -- fused Winograd F(4x4,3x3), second design: "transform once, multiply from LDS" [round 3].
+//
+// Why a second F(4x4,3x3) kernel.  F(4x4,3x3) executes 36 multiplies per 16 outputs and (ci, co) pair -- 1.78x
+// fewer MFMAs than the F(2x2,3x3) kernels of conv_wino.hip, which sit at 61-64 % of MFMA issue in their own
+// cycles (profiles/r3_wino9_kq2_timeline.txt) with nothing left to remove.  conv_wino43_kernel (the first
+// attempt) had every wave transform its own frequency row in front of 18 MFMAs: 2.9 VALU + 13 SALU per MFMA, a
+// barrier per 4 channels, filter stages filling the LDS -- as fast as F(2x2,3x3), no faster.  What round 3
+// measured (profiles/r3_mfma_tax.txt): beside fp32 MFMAs an LDS read, an LDS-DMA piece or a global load costs
+// nothing, every VALU instruction costs 3-6 cycles of matrix-pipe time.  So:
+//   * the input transform V = B^T d B runs ONCE per (tile, channel) -- 144 VALU per 64 (tile, channel) pairs,
+//     written to LDS as MFMA A operands -- by ONE wave per SIMD and stage, in rotation (1.33 VALU per MFMA
+//     at a 48-channel co-tile), while the other waves multiply;
+//   * the multiplying waves read A from LDS (free) and B -- the transformed filter -- straight from global
+//     memory into registers, each element by exactly one wave of the block (free, and the LDS holds no
+//     filter: 8-channel stages, one barrier per 36 MFMAs of a wave);
+//   * 12 waves = 3 per SIMD; wave w owns frequency points 3w .. 3w+2 for all 3 co sub-tiles and both m-tiles:
+//     18 MFMAs per 4-channel k-group, 72 accumulator registers.
+//
+// Block = 16 x 32 output pixels of one image = 4 x 8 tiles of 4 x 4 pixels = 2 m-tiles (tile rows {0,1} / {2,3})
+// x 48 output channels; K stages of 8 channels (two k-groups of 4).  LDS (120 KB): two halo buffers
+// [18 x 34 pixels][8 ch] filled by LDS-DMA two stages ahead, two V buffers [36 points][m-tile][k-group][64] floats.
+// Stage s: every wave issues its 2 DMA pieces of stage s + 2 and its 9 filter loads of the next k-group; the 4
+// transforming waves turn halo s + 1 into V s + 1; all waves multiply V s; one barrier.
+// Item end: the accumulators go through LDS once per m-tile ([point][co sub-tile][lane] float4, 108 KB) so
+// that every lane gets all 36 points of ONE (tile, co): Y = A^T M A (100 VALU), scale / shift / residual / ReLU,
+// 16 stores of 64 B segments.
+//
+// Matrices (Lavin & Gray, points 0, +-1, +-2, inf), filter transform on the host (engine.pack_wino4_weight):
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// Reference: the 3x3 stride-1 convolutions of libs/model/heatmapModel/hrnet.py (BasicBlock :49-76 and the
+// branches built from it); tolerance as for the F(2x2,3x3) kernels, see tools/wino43_network_study.py.
+#include "conv_common.h"
+
+typedef __attribute__((address_space(3))) void* lds_ptr_w4_t;
+
+namespace {
+constexpr int W4_NW = 12, W4_NTH = 64 * W4_NW;
+constexpr int W4_CO = 48;
+// Halo of the 16 x 32 region: 18 x 34 pixels x 8 channels, in 16-byte slots (one pixel, one channel quad) ordered
+// [quad][x mod 4][y][x div 4 (pitch 10)]: the transform's lane (tile (ty, tx), channel kq) reads pixel (4 ty + i,
+// 4 tx + j) at slot 40 ty + tx + const(i, j) -- the 16 tiles of an m-tile land on 16 different slots mod 16, the
+// wave read on 64 different banks.  (Pixel-major order put them on 8 banks: the transform alone took 5 000 cycles
+// per stage, profiles/r3_wino4_ablations.txt.)  The DMA lanes gather their pixels accordingly.
+constexpr int W4_RH = 18, W4_RW = 34;
+constexpr int W4_XD = 10;                             // slots per row and plane (9 used)
+constexpr int W4_PLANE = W4_RH * W4_XD;               // 180
+constexpr int W4_QUAD = 4 * W4_PLANE;                 // 720 slots per channel quad
+constexpr int W4_HSLOT = 2 * W4_QUAD;                 // 1440 16-byte DMA slots
+constexpr int W4_HBYTES = 2 * W4_NW * 1024;           // every wave issues 2 whole pieces: 24 KB
+constexpr int W4_VBYTES = 36 * 1024;                  // [pt][mt][g][lane] floats
+constexpr int W4_V0 = 0, W4_V1 = W4_VBYTES, W4_H0 = 2 * W4_VBYTES, W4_H1 = W4_H0 + W4_HBYTES;
+constexpr int W4_LDS = W4_H1 + W4_HBYTES;             // 122 880 B
+constexpr int W4_XBYTES = 36 * 3 * 1024;              // exchange [pt][nt][lane] float4: 110 592 B
+static_assert(W4_XBYTES <= W4_LDS, "the exchange reuses the stage buffers");
+static_assert(W4_HSLOT <= 2 * W4_NW * 64, "two DMA pieces per wave cover the halo");
+constexpr int W4_UKG = W4_NW * 9 * 64;                // filter floats of one (co-tile, stage, k-group): 6912
+constexpr unsigned W4_PAST = 0x80000000u;             // scalar byte offset past every buffer (tensors stay below 2 GB)
+}  // namespace
+
+__device__ __forceinline__ void w4_dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "m0");
+}
+// one LDS dword at a VGPR byte address + immediate (see conv_wgrad_wino.hip: the compiler's ds_read2 pairing
+// costs a v_add per pair); the values are tied to w4_landed's s_waitcnt before use
+template <int OFF>
+__device__ __forceinline__ float w4_lds(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read_b32 immediate");
+  float v;
+  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+__device__ __forceinline__ void w4_landed6(float (&a)[6], float (&b)[6]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(b[0]), "+v"(b[1]),
+                 "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]));
+}
+__device__ __forceinline__ void w4_tie6(float (&a)[6]) {
+  asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
+}
+template <int OFF>
+__device__ __forceinline__ float w4_gld(u32x4 rsrc, unsigned voff, unsigned soff) {
+  float v;
+  asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void w4_vm_landed9(float (&b)[9]) {
+  asm volatile("s_waitcnt vmcnt(%9)"
+               : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8])
+               : "n"(N));
+}
+template <int OFF>
+__device__ __forceinline__ void w4_xwr(unsigned addr, f32x4 v) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int PT>
+__device__ __forceinline__ float w4_xrd(unsigned xr0, unsigned xr1) {
+  if constexpr (PT < 18) return w4_lds<PT * 3072>(xr0);
+  else return w4_lds<(PT - 18) * 3072>(xr1);
+}
+__device__ __forceinline__ unsigned w4_udiv(unsigned x, unsigned magic) { return magic ? __umulhi(x, magic) : x; }
+
+// 1-D input transform of six values (12 instructions)
+__device__ __forceinline__ void w4_bt(const float (&t)[6], float (&o)[6]) {
+  o[0] = __builtin_fmaf(4.f, t[0], __builtin_fmaf(-5.f, t[2], t[4]));
+  const float u = __builtin_fmaf(-4.f, t[2], t[4]), v = __builtin_fmaf(-4.f, t[1], t[3]);
+  o[1] = u + v;
+  o[2] = u - v;
+  const float p = t[4] - t[2], q = t[3] - t[1];
+  o[3] = __builtin_fmaf(2.f, q, p);
+  o[4] = __builtin_fmaf(-2.f, q, p);
+  o[5] = __builtin_fmaf(4.f, t[1], __builtin_fmaf(-5.f, t[3], t[5]));
+}
+// 1-D output transform of six values (10 instructions)
+__device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4]) {
+  const float p = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], s = m[3] - m[4];
+  y[0] = m[0] + p + r;
+  y[1] = __builtin_fmaf(2.f, s, q);
+  y[2] = __builtin_fmaf(4.f, r, p);
+  y[3] = __builtin_fmaf(8.f, s, q) + m[5];
+}
+
+// halo of stage parity P -> V of parity P, for this wave's (m-tile, k-group) share; hb / vw: per-lane byte bases
+template <int P>
+__device__ __forceinline__ void w4_transform(unsigned hb0, unsigned vw0) {
+  constexpr int HB = P ? W4_H1 : W4_H0;
+  constexpr int VB = P ? W4_V1 : W4_V0;
+  static_assert(W4_H1 - W4_H0 + (3 * W4_PLANE + 5 * W4_XD + 1) * 16 < 65536, "halo immediates");
+  // hb0 holds W4_H0 (the immediates of both halo buffers stay below 64 K); vw0 holds THIS parity's V buffer
+  constexpr int HO = HB - W4_H0, VO = 0;
+  (void)VB;
+#define W4_D(I, J) w4_lds<HO + (((J) & 3) * W4_PLANE + (I)*W4_XD + ((J) >> 2)) * 16>(hb0)
+#define W4_WR(PT, VAL) asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(vw0), "v"(VAL), "n"(VO + (PT)*1024) : "memory")
+#define W4_ROW(FI, O)                                                                                   \
+  W4_WR((FI)*6 + 0, (O)[0]); W4_WR((FI)*6 + 1, (O)[1]); W4_WR((FI)*6 + 2, (O)[2]);                      \
+  W4_WR((FI)*6 + 3, (O)[3]); W4_WR((FI)*6 + 4, (O)[4]); W4_WR((FI)*6 + 5, (O)[5]);
+  static_assert(VO + 35 * 1024 < 65536, "V immediates");
+  {  // frequency row 0: T0 = 4 d0 - 5 d2 + d4; row 5: T5 = 4 d1 - 5 d3 + d5 (18 + 18 reads, two batches)
+    float a[6], b[6], c[6], t[6], o[6];
+    a[0] = W4_D(0, 0); a[1] = W4_D(0, 1); a[2] = W4_D(0, 2); a[3] = W4_D(0, 3); a[4] = W4_D(0, 4); a[5] = W4_D(0, 5);
+    b[0] = W4_D(2, 0); b[1] = W4_D(2, 1); b[2] = W4_D(2, 2); b[3] = W4_D(2, 3); b[4] = W4_D(2, 4); b[5] = W4_D(2, 5);
+    c[0] = W4_D(4, 0); c[1] = W4_D(4, 1); c[2] = W4_D(4, 2); c[3] = W4_D(4, 3); c[4] = W4_D(4, 4); c[5] = W4_D(4, 5);
+    w4_landed6(a, b);
+    w4_tie6(c);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) t[j] = __builtin_fmaf(4.f, a[j], __builtin_fmaf(-5.f, b[j], c[j]));
+    w4_bt(t, o);
+    W4_ROW(0, o)
+  }
+  {  // rows 1..4 from input rows 1..4: u = d4 - 4 d2, v = d3 - 4 d1, p = d4 - d2, q = d3 - d1
+    float d1[6], d2[6], d3[6], d4[6];
+    d1[0] = W4_D(1, 0); d1[1] = W4_D(1, 1); d1[2] = W4_D(1, 2); d1[3] = W4_D(1, 3); d1[4] = W4_D(1, 4); d1[5] = W4_D(1, 5);
+    d2[0] = W4_D(2, 0); d2[1] = W4_D(2, 1); d2[2] = W4_D(2, 2); d2[3] = W4_D(2, 3); d2[4] = W4_D(2, 4); d2[5] = W4_D(2, 5);
+    w4_landed6(d1, d2);
+    d3[0] = W4_D(3, 0); d3[1] = W4_D(3, 1); d3[2] = W4_D(3, 2); d3[3] = W4_D(3, 3); d3[4] = W4_D(3, 4); d3[5] = W4_D(3, 5);
+    d4[0] = W4_D(4, 0); d4[1] = W4_D(4, 1); d4[2] = W4_D(4, 2); d4[3] = W4_D(4, 3); d4[4] = W4_D(4, 4); d4[5] = W4_D(4, 5);
+    w4_landed6(d3, d4);
+    float t1[6], t2[6], t3[6], t4[6], o[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const float u = __builtin_fmaf(-4.f, d2[j], d4[j]), v = __builtin_fmaf(-4.f, d1[j], d3[j]);
+      t1[j] = u + v;
+      t2[j] = u - v;
+      const float p = d4[j] - d2[j], q = d3[j] - d1[j];
+      t3[j] = __builtin_fmaf(2.f, q, p);
+      t4[j] = __builtin_fmaf(-2.f, q, p);
+    }
+    w4_bt(t1, o);
+    W4_ROW(1, o)
+    w4_bt(t2, o);
+    W4_ROW(2, o)
+    w4_bt(t3, o);
+    W4_ROW(3, o)
+    w4_bt(t4, o);
+    W4_ROW(4, o)
+  }
+  {
+    float a[6], b[6], c[6], t[6], o[6];
+    a[0] = W4_D(1, 0); a[1] = W4_D(1, 1); a[2] = W4_D(1, 2); a[3] = W4_D(1, 3); a[4] = W4_D(1, 4); a[5] = W4_D(1, 5);
+    b[0] = W4_D(3, 0); b[1] = W4_D(3, 1); b[2] = W4_D(3, 2); b[3] = W4_D(3, 3); b[4] = W4_D(3, 4); b[5] = W4_D(3, 5);
+    c[0] = W4_D(5, 0); c[1] = W4_D(5, 1); c[2] = W4_D(5, 2); c[3] = W4_D(5, 3); c[4] = W4_D(5, 4); c[5] = W4_D(5, 5);
+    w4_landed6(a, b);
+    w4_tie6(c);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) t[j] = __builtin_fmaf(4.f, a[j], __builtin_fmaf(-5.f, b[j], c[j]));
+    w4_bt(t, o);
+    W4_ROW(5, o)
+  }
+#undef W4_D
+#undef W4_WR
+#undef W4_ROW
+}
+
+// ABL != 0: timing ablations (WRONG RESULTS; configs 71.., tools/wino_probe.py only): bit 0 no input transform,
+// bit 1 no MFMAs, bit 2 no exchange / output transform / stores, bit 3 no filter loads, bit 4 no halo DMA,
+// bit 5 bank-conflict-free halo reads
+template <int ABL>
+__global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
+  extern __shared__ float4 w4_smem[];
+  const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(lds_ptr_w4_t)w4_smem;
+  const float* smf = reinterpret_cast<const float*>(w4_smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int tgrp = wave >> 2;              // transform rotation: group (s mod 3) transforms stage s
+  const int tw = wave & 3;                 // its share: m-tile tw >> 1, k-group tw & 1
+
+  const int C = a.Cin, Co = a.Cout;
+  const int nct = Co / W4_CO;
+  const int S = C >> 3;                    // stages of 8 channels
+
+  const unsigned long long xaddr = reinterpret_cast<unsigned long long>(a.x);
+  const unsigned long long uaddr = reinterpret_cast<unsigned long long>(a.w);
+  const u32x4 rxv = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, (unsigned)((size_t)a.N * a.H * a.W * C * 4),
+                     0x00020000u};
+  const u32x4 ruv = {(unsigned)uaddr, (unsigned)(uaddr >> 32) & 0xffffu, (unsigned)((size_t)nct * S * 2 * W4_UKG * 4),
+                     0x00020000u};
+  const unsigned out_bytes = (unsigned)((size_t)a.N * a.Ho * a.Wo * Co * 4);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, out_bytes, 0x00020000);
+
+  // ---- halo DMA: this wave's pieces wave and wave + 12; slot e -> (pixel = e >> 1, channel quad e & 1)
+  int hyx[2];
+  unsigned hrel[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = (wave + W4_NW * k) * 64 + lane;
+    const int hq = e / W4_QUAD, r = e - hq * W4_QUAD;
+    const int pl = r / W4_PLANE, rr = r - pl * W4_PLANE;
+    const int hy = rr / W4_XD, hx = 4 * (rr - hy * W4_XD) + pl;
+    const bool ok = e < W4_HSLOT && hx < W4_RW;
+    hyx[k] = ok ? ((hy << 16) | hx) : -1;
+    hrel[k] = ok ? (unsigned)(((hy * a.W + hx) * C + 4 * hq) * 4) : 0u;
+  }
+  // ---- transform share of this wave: lane (tile li of m-tile tw >> 1, channel 4 (tw & 1) + kq)
+  unsigned hb0, vw0;
+  {
+    const int mt = tw >> 1, g = tw & 1;
+    const int ty = 2 * mt + (li >> 3), tx = li & 7;
+    hb0 = lds0 + (unsigned)(W4_H0 + (g * W4_QUAD + 4 * W4_XD * ty + tx) * 16 + kq * 4);
+    vw0 = lds0 + (unsigned)(W4_V0 + (mt * 2 + g) * 256 + lane * 4);
+    if constexpr ((ABL & 32) != 0) hb0 = lds0 + (unsigned)(W4_H0 + lane * 4);     // conflict-free reads (wrong data)
+  }
+  // ---- multiply: A operands V[3 wave + pl][mt][g][lane], filter block of this wave
+  const float* va0 = smf + (W4_V0 / 4) + (3 * wave) * 256 + lane;
+  const unsigned uvo = (unsigned)lane * 4u;
+  // ---- exchange + output: this lane finishes tile 4 (wave & 3) + (lane >> 4) of the m-tile, co 16 (wave >> 2) + li
+  const int ont = wave >> 2, okq = wave & 3;
+  const unsigned xw0 = lds0 + (unsigned)((3 * wave) * 3 * 1024 + lane * 16);
+  const unsigned xr0 = lds0 + (unsigned)((ont * 64 + okq * 16 + li) * 16 + kq * 4);
+
+  const int regs_x = a.tiles_x, regs_xy = a.tiles_x * a.tiles_y;
+  const int nreg = regs_xy * a.N;
+  const int nwork = ((nreg + 7) >> 3) * nct * 8;
+  const int gsz = __builtin_amdgcn_readfirstlane((int)gridDim.x);
+  const float act_lo = (a.act & EGN_ACT_MASK) == EGN_ACT_RELU ? 0.f : -__builtin_inff();
+  const bool has_res = a.res != nullptr;
+  const unsigned rowpitch = (unsigned)(a.Wo * Co) * 4u, colpitch = (unsigned)Co * 4u;
+
+  for (int w = blockIdx.x; w < nwork; w += gsz) {
+    // item -> (region, co-tile): blocks w, w + 8, ... stay on one XCD (conv_wino.hip: wino8_grid)
+    const unsigned wi = (unsigned)__builtin_amdgcn_readfirstlane(w);
+    const unsigned xq = wi & 7u, q_ = wi >> 3;
+    const unsigned qq = w4_udiv(q_, a.mg_nct);
+    const int reg = (int)(qq * 8u + xq);
+    const int ct = (int)(q_ - qq * (unsigned)nct);
+    if (reg >= nreg) continue;                         // (uniform) padding of the last group of 8
+    const unsigned n_ = w4_udiv((unsigned)reg, a.mg_txy);
+    const unsigned r_ = (unsigned)reg - n_ * (unsigned)regs_xy;
+    const unsigned ry_ = w4_udiv(r_, a.mg_tx);
+    const int n = (int)n_, y0 = (int)ry_ * 16, x0 = (int)(r_ - ry_ * (unsigned)regs_x) * 32;
+
+    // halo offsets of the item (stage 0): uniform base + per-lane relative offset, zero padding by OOB offsets
+    unsigned doff[2];
+    {
+      const int base = ((n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * C * 4;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const unsigned iy = (unsigned)(y0 - 1 + (hyx[k] >> 16)), ix = (unsigned)(x0 - 1 + (hyx[k] & 0xffff));
+        const bool in = hyx[k] >= 0 && iy < (unsigned)a.H && ix < (unsigned)a.W;
+        doff[k] = in ? (unsigned)base + hrel[k] : EGN_OOB;
+      }
+    }
+#define W4_DMA(P, STAGE) /* STAGE: byte offset of the stage's channels, W4_PAST = none */                      \
+  if constexpr ((ABL & 16) == 0) {                                                                             \
+    w4_dma16(rxv, lds0 + (unsigned)((P) ? W4_H1 : W4_H0) + (unsigned)wave * 1024u, doff[0], (unsigned)(STAGE)); \
+    w4_dma16(rxv, lds0 + (unsigned)((P) ? W4_H1 : W4_H0) + (unsigned)(wave + W4_NW) * 1024u, doff[1],          \
+             (unsigned)(STAGE));                                                                               \
+  }
+    // filter k-group h = 2 stage + g of this wave: 9 dwords per lane, raw ISA -- the compiler's own vmcnt
+    // bookkeeping does not see the LDS-DMA pieces and would wait for them with every filter wait
+    const unsigned ubase = (unsigned)(ct * S) * (2u * W4_UKG * 4u) + (unsigned)wave * (9u * 64u * 4u);
+#define W4_LOADB(DST, HS)                                                                                      \
+  if constexpr ((ABL & 8) != 0) {                                                                              \
+    _Pragma("unroll") for (int p_ = 0; p_ < 9; ++p_) DST[p_] = (float)(lane + p_);                             \
+  } else {                                                                                                     \
+    const unsigned so_ = (HS);        /* byte offset of the k-group, W4_PAST = none */                        \
+    DST[0] = w4_gld<0>(ruv, uvo, so_); DST[1] = w4_gld<256>(ruv, uvo, so_); DST[2] = w4_gld<512>(ruv, uvo, so_);       \
+    DST[3] = w4_gld<768>(ruv, uvo, so_); DST[4] = w4_gld<1024>(ruv, uvo, so_); DST[5] = w4_gld<1280>(ruv, uvo, so_);   \
+    DST[6] = w4_gld<1536>(ruv, uvo, so_); DST[7] = w4_gld<1792>(ruv, uvo, so_); DST[8] = w4_gld<2048>(ruv, uvo, so_);  \
+  }
+    float b0[9], b1[9];
+    W4_DMA(0, 0u)
+    W4_DMA(1, 32u)
+    W4_LOADB(b0, ubase)
+    asm volatile("s_waitcnt vmcnt(11)" ::: "memory");   // stage 0's pieces landed (2 pieces + 9 filter loads are newer)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if ((ABL & 1) == 0 && tgrp == 0) w4_transform<0>(hb0, vw0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the V writes
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    f32x4 acc[3][3][2];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[pl][nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int tsel = 1;                        // group that transforms stage s + 1 during stage s
+#define W4_MUL(P, G, B)                                                                                        \
+  if constexpr ((ABL & 2) == 0) {                                                                              \
+    float av_[3][2];                                                                                           \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)          \
+        av_[pl][mt] = va0[((P) ? W4_VBYTES / 4 : 0) + ((pl * 2 + mt) * 2 + (G)) * 64];                         \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) _Pragma("unroll") for (int nt = 0; nt < 3; ++nt)          \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) acc[pl][nt][mt] =                                     \
+            __builtin_amdgcn_mfma_f32_16x16x4f32(av_[pl][mt], B[pl * 3 + nt], acc[pl][nt][mt], 0, 0, 0);       \
+  }
+  // vmcnt is in-order: a wait for filter loads also waits for every OLDER DMA piece.  Order of a stage: filter
+  // k-group 2s landed (nothing newer in flight) | issue k-group 2s+1, THEN the DMA pieces of stage s + 2 | multiply
+  // g = 0 | k-group 2s+1 landed (the 2 pieces stay in flight) | issue k-group 2s+2 | multiply g = 1 | the pieces
+  // landed (k-group 2s+2 stays in flight) | barrier: the pieces get a whole stage to arrive.
+  // Straight-line code with CONSTANT counts: past the last stage the loads / pieces are still issued, beyond the
+  // buffers' ends (zeros).  The filter registers are written asynchronously behind the compiler's back: the
+  // destination of a load must reach its s_waitcnt without being copied -- tools/check_wino4_isa.py asserts that
+  // on the compiled ISA (tests/test_wino4_design_cpu.py).
+#define W4_STAGE(P, SI)                                                                                        \
+  {                                                                                                            \
+    const int s_ = (SI);                                                                                       \
+    w4_vm_landed9<0>(b0);                                                                                      \
+    W4_LOADB(b1, s_ < S ? ubase + (unsigned)(2 * s_ + 1) * (W4_UKG * 4u) : W4_PAST)                                                                \
+    W4_DMA(P, s_ + 2 < S ? (unsigned)(s_ + 2) * 32u : W4_PAST)                                                                   \
+    if ((ABL & 1) == 0 && s_ + 1 < S && tgrp == tsel) {                                                        \
+      /* the stage's critical path: beside two waves that saturate the matrix pipe a plain-priority wave gets   \
+         one VALU issue per MFMA slot (the transform alone took 5 000 cycles) */                                \
+      __builtin_amdgcn_s_setprio(3);                                                                           \
+      w4_transform<1 - (P)>(hb0, vw0 + (unsigned)((1 - (P)) * W4_VBYTES));                                     \
+      __builtin_amdgcn_s_setprio(0);                                                                           \
+    }                                                                                                          \
+    W4_MUL(P, 0, b0)                                                                                           \
+    w4_vm_landed9<2>(b1);                                                                                      \
+    W4_LOADB(b0, s_ + 1 < S ? ubase + (unsigned)(2 * s_ + 2) * (W4_UKG * 4u) : W4_PAST)                                                            \
+    W4_MUL(P, 1, b1)                                                                                           \
+    tsel = tsel == 2 ? 0 : tsel + 1;                                                                           \
+    asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");                                                \
+    __builtin_amdgcn_s_barrier();                                                                              \
+    asm volatile("" ::: "memory");                                                                             \
+  }
+    for (int s = 0; s < S; s += 2) {     // (S is even: Cin % 16 == 0)
+      W4_STAGE(0, s)
+      W4_STAGE(1, s + 1)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the loads past the end
+#undef W4_STAGE
+#undef W4_MUL
+#undef W4_LOADB
+#undef W4_DMA
+
+    // ---- item end: per m-tile, accumulators -> LDS -> one (tile, co) per lane -> Y = A^T M A -> epilogue
+    const float sc = a.scale[ct * W4_CO + ont * 16 + li];
+    const float sh = a.shift[ct * W4_CO + ont * 16 + li];
+    if constexpr ((ABL & 4) != 0) {
+      f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) t += acc[pl][nt][0] + acc[pl][nt][1];
+      if (t[0] + t[1] + t[2] + t[3] == 12345.f) a.y[tid] = t[0];
+      continue;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      // this lane's output tile of the round: tile 4 okq + kq of m-tile mt, channel 16 ont + li
+      const int tile = 4 * okq + kq, ty = 2 * mt + (tile >> 3), tx = tile & 7;
+      const unsigned vo = (unsigned)((((n * a.Ho + y0 + 4 * ty) * a.Wo + x0 + 4 * tx) * Co + ct * W4_CO + ont * 16 + li) * 4);
+      float rv[4][4];
+#pragma unroll
+      for (int oa = 0; oa < 4; ++oa)
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob)
+          rv[oa][ob] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                     rr, has_res ? vo : EGN_OOB, oa * rowpitch + ob * colpitch, 0));
+      w4_xwr<0 * 1024>(xw0, acc[0][0][mt]); w4_xwr<1 * 1024>(xw0, acc[0][1][mt]); w4_xwr<2 * 1024>(xw0, acc[0][2][mt]);
+      w4_xwr<3 * 1024>(xw0, acc[1][0][mt]); w4_xwr<4 * 1024>(xw0, acc[1][1][mt]); w4_xwr<5 * 1024>(xw0, acc[1][2][mt]);
+      w4_xwr<6 * 1024>(xw0, acc[2][0][mt]); w4_xwr<7 * 1024>(xw0, acc[2][1][mt]); w4_xwr<8 * 1024>(xw0, acc[2][2][mt]);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // M[i][j] = X[6 i + j]: two columns per batch (12 reads), column pass A^T right away: 24 values stay
+      float yc[4][6];
+#define W4_M(I, J) w4_xrd<(I)*6 + (J)>(xr0, xr1)
+#define W4_COLS(J0)                                                                                     \
+  {                                                                                                     \
+    float ca_[6], cb_[6], ya_[4], yb_[4];                                                               \
+    ca_[0] = W4_M(0, J0); ca_[1] = W4_M(1, J0); ca_[2] = W4_M(2, J0); ca_[3] = W4_M(3, J0); ca_[4] = W4_M(4, J0);  \
+    ca_[5] = W4_M(5, J0);                                                                               \
+    cb_[0] = W4_M(0, J0 + 1); cb_[1] = W4_M(1, J0 + 1); cb_[2] = W4_M(2, J0 + 1); cb_[3] = W4_M(3, J0 + 1);        \
+    cb_[4] = W4_M(4, J0 + 1); cb_[5] = W4_M(5, J0 + 1);                                                 \
+    w4_landed6(ca_, cb_);                                                                               \
+    w4_at(ca_, ya_);                                                                                    \
+    w4_at(cb_, yb_);                                                                                    \
+    _Pragma("unroll") for (int oa = 0; oa < 4; ++oa) { yc[oa][J0] = ya_[oa]; yc[oa][J0 + 1] = yb_[oa]; } \
+  }
+      const unsigned xr1 = xr0 + 18u * 3072u;
+      W4_COLS(0)
+      W4_COLS(2)
+      W4_COLS(4)
+#undef W4_COLS
+#undef W4_M
+#pragma unroll
+      for (int oa = 0; oa < 4; ++oa) {
+        float yo[4];
+        w4_at(yc[oa], yo);
+#pragma unroll
+        for (int ob = 0; ob < 4; ++ob) {
+          const float v = fmaxf(__builtin_fmaf(yo[ob], sc, sh) + rv[oa][ob], act_lo);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, vo, oa * rowpitch + ob * colpitch, 0);
+        }
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_s_barrier();      // the exchange buffer is free again (next round / next item's DMA)
+      asm volatile("" ::: "memory");
+    }
+  }
+}
+
+bool egn_conv_wino4_applies(const ConvArgs& a) {
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 16 == 0 && a.cs_in == a.Cin &&
+         a.Cout % W4_CO == 0 && a.cs_out == a.Cout && !a.out_nchw && a.Ho % 16 == 0 && a.Wo % 32 == 0 &&
+         !(a.act & EGN_ACT_RES_AFTER) &&
+         ((a.act & EGN_ACT_MASK) == EGN_ACT_NONE || (a.act & EGN_ACT_MASK) == EGN_ACT_RELU);
+}
+size_t egn_conv_wino4_lds_bytes() { return W4_LDS; }
+// floats of the packed filter (engine.pack_wino4_weight): [co-tile][stage = Cin / 8][k-group][wave][9][64]
+extern "C" long long egn_wino4_weight_floats(int cout, int cin) {
+  if (cout % W4_CO || cin % 8 || cin < 16) return 0;
+  return (long long)(cout / W4_CO) * (cin / 8) * 2 * W4_UKG;
+}
+
+static unsigned w4_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
+
+template <int ABL>
+static int wino4_launch(ConvArgs a, size_t lds, hipStream_t stream) {
+  static bool raised[EGN_MAX_DEVICES];
+  static int cus = 0;
+  if (egn_first_use_on_device(raised)) {
+    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_kernel<ABL>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+  }
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0) cus = 256;
+  }
+  const int nct = a.Cout / W4_CO;
+  a.mg_nct = w4_magic(nct);
+  a.mg_txy = w4_magic(a.tiles_x * a.tiles_y);
+  a.mg_tx = w4_magic(a.tiles_x);
+  const int nreg = a.tiles_x * a.tiles_y * a.N;
+  const int nwork = ((nreg + 7) / 8) * 8 * nct;
+  int cap = cus / (8 * nct) * (8 * nct);              // one 120 KB block per CU, whole XCD rounds
+  if (cap <= 0) cap = 8 * nct;
+  const int grid = nwork < cap ? nwork : cap;
+  hipLaunchKernelGGL(conv_wino4_kernel<ABL>, dim3(grid), dim3(W4_NTH), lds, stream, a);
+  return (int)hipGetLastError();
+}
+int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, hipStream_t stream) {
+  if (!egn_conv_wino4_applies(a) || a.stats) return EGN_E_BADARG;
+  switch (abl) {
+    case 0: return wino4_launch<0>(a, lds, stream);
+    case 1: return wino4_launch<1>(a, lds, stream);
+    case 2: return wino4_launch<2>(a, lds, stream);
+    case 4: return wino4_launch<4>(a, lds, stream);
+    case 8: return wino4_launch<8>(a, lds, stream);
+    case 16: return wino4_launch<16>(a, lds, stream);
+    case 7: return wino4_launch<7>(a, lds, stream);
+    case 32: return wino4_launch<32>(a, lds, stream);
+    default: return EGN_E_BADARG;
+  }
+}

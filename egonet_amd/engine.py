@@ -89,9 +89,27 @@ def pack_wino43_weight(w):
     return u.permute(0, 2, 4, 3, 1).contiguous().reshape(-1)
 
 
+def pack_wino4_weight(w):
+    """[Cout,Cin,3,3] -> the Winograd F(4x4,3x3) filter U = G g G^T (float64, rounded once to fp32) in the layout
+    conv_wino4_kernel's waves load straight into MFMA B registers (csrc/conv_wino4.hip):
+    flat fp32 [co-tile = Cout/48][stage = Cin/8][k-group g][wave 0..11][p = 3 pl + nt][lane = 16 kq + li] with
+    point 3 wave + pl, co = 48 ct + 16 nt + li, ci = 8 stage + 4 g + kq."""
+    w = w.detach().to(torch.float64).cpu()
+    cout, cin, kh, kw = w.shape
+    assert (kh, kw) == (3, 3) and cout % 48 == 0 and cin % 8 == 0, w.shape
+    G = torch.tensor([[1 / 4., 0., 0.], [-1 / 6., -1 / 6., -1 / 6.], [-1 / 6., 1 / 6., -1 / 6.],
+                      [1 / 24., 1 / 12., 1 / 6.], [1 / 24., -1 / 12., 1 / 6.], [0., 0., 1.]], dtype=torch.float64)
+    u = torch.einsum('ia,ocab,jb->ocij', G, w, G).to(torch.float32).reshape(cout, cin, 36)
+    #   co = (ct, nt, li)          ci = (stage, g, kq)        pt = (wave, pl)
+    u = u.reshape(cout // 48, 3, 16, cin // 8, 2, 4, 12, 3)   # ct nt li stage g kq wave pl
+    return u.permute(0, 3, 4, 6, 7, 1, 5, 2).contiguous().reshape(-1)      # ct stage g wave pl nt kq li
+
+
 def pack_for_kind(w, kind):
     """The filter in the layout the kernels of a tile-configuration KIND read (egn_conv_config_kind):
-    0 direct, 1 Winograd F(2x2,3x3), 2 Winograd F(4x4,3x3)."""
+    0 direct, 1 Winograd F(2x2,3x3), 2 / 3 Winograd F(4x4,3x3) (conv_wino43_kernel / conv_wino4_kernel)."""
+    if kind == 3:
+        return pack_wino4_weight(w)
     return pack_wino43_weight(w) if kind == 2 else (pack_wino_weight(w) if kind == 1 else pack_conv_weight(w))
 
 

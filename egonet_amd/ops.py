@@ -59,9 +59,9 @@ class PackedConv(object):
         (egn_wino_pack_weight_f32) instead of the direct layout; ``kind`` 2: the F(4x4,3x3) filter
         (engine.pack_wino43_weight, host float64)."""
         self.cout, self.cin, self.kh, self.kw = weight.shape
-        if kind == 2:
-            from .engine import pack_wino43_weight
-            self.w = pack_wino43_weight(weight).to(device)
+        if kind in (2, 3):
+            from .engine import pack_for_kind
+            self.w = pack_for_kind(weight, kind).to(device)
         elif wino or kind == 1:
             L = _lib.lib()
             nfl = L.egn_wino_weight_floats(self.cout, self.cin, 0)

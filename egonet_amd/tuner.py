@@ -113,7 +113,7 @@ def _pick(entry, allow_wino, allow_f43=False):
     (egn_conv_config_kind: 0 direct-packed filter -- always; 1 Winograd F(2x2,3x3) with ``allow_wino``;
     2 Winograd F(4x4,3x3) with ``allow_f43``: the inference engine, which transforms filters on the host)."""
     L = _lib.lib()
-    ok = {0} | ({1} if allow_wino else set()) | ({2} if allow_f43 else set())
+    ok = {0} | ({1} if allow_wino else set()) | ({2, 3} if allow_f43 else set())
     cfg = int(entry['cfg'])
     if cfg <= 0 or L.egn_conv_config_kind(cfg) in ok:
         return cfg
@@ -145,7 +145,7 @@ def choose(device, args, allow_wino=False, allow_f43=False):
     if mode == '0':
         allow_wino = False
     elif mode == '43' and allow_f43:
-        cfg = _forced_wino(args, 2) or (_forced_wino(args, 1) if allow_wino else 0)
+        cfg = _forced_wino(args, 3) or _forced_wino(args, 2) or (_forced_wino(args, 1) if allow_wino else 0)
         if cfg:
             return cfg
     elif mode in ('1', '43') and allow_wino:

@@ -83,8 +83,16 @@ int egn_conv_config_name(int cfg, char* buf, int len);
  *   1  fused Winograd F(2x2,3x3) kernels (3x3, stride 1, pad 1, Cin % 16 == 0,
  *      Cout % 48 == 0 or -- the 8-wave kernels -- Cout % 32 == 0, unpadded channel
  *      strides, act none/ReLU): the TRANSFORMED filter from egn_wino_pack_weight_f32
+ *   2  fused Winograd F(4x4,3x3), conv_wino43_kernel: U = G g G^T for points 0, +-1, +-2,
+ *      inf packed [Cout/48][Cin/4][f = 6i+j][ci % 4][48] (host: engine.pack_wino43_weight)
+ *   3  fused Winograd F(4x4,3x3), conv_wino4_kernel (3x3, stride 1, pad 1, Cin % 8 == 0,
+ *      Cout % 48 == 0, maps of whole 16 x 32 pixel regions): the same U packed for
+ *      register feeding, [Cout/48][Cin/8][k-group 2][wave 12][9][64] floats
+ *      (egn_wino4_weight_floats; host: engine.pack_wino4_weight)
  *  -1  not selectable (timing-ablation builds, invalid id) */
 int egn_conv_config_kind(int cfg);
+/* floats of the kind-3 filter of a [Cout][Cin][3][3] weight (0 = shape not supported) */
+long long egn_wino4_weight_floats(int Cout, int Cin);
 /* Winograd filter transform on the device: torch weight [Cout][Cin][3][3] ->
  * U = G g G^T (float64 arithmetic, rounded once to fp32) packed as
  * [Cout/T][Cin/16][f = 4i+j][quad][T][4] floats (ci = chunk*16 + quad*4 + r),

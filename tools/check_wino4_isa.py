@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Static check of conv_wino4_kernel's compiled ISA (csrc/conv_wino4.hip).
+
+The kernel loads its MFMA B operands (the transformed filter) with raw `buffer_load_dword` instructions and
+waits for them with hand-counted `s_waitcnt vmcnt(N)`: the compiler does not know that the destination
+registers are written asynchronously.  The source is arranged so that a loaded register reaches its wait
+untouched; this script ASSERTS it on the ISA hipcc produced: between a `buffer_load_dword vN` and the
+`s_waitcnt vmcnt` that retires it, no instruction may read or write vN (a register copy there would move a
+value that has not arrived).  It also checks that no scratch is used (a spill would do the same).
+
+    python tools/check_wino4_isa.py [conv_wino4.s]        # without an argument: compiles the file with hipcc -S
+Exit code 0 = clean.  Linear scan in program order (the stage loop is straight-line code by construction).
+"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def compile_isa():
+    src = os.path.join(ROOT, 'egonet_amd', 'csrc', 'conv_wino4.hip')
+    out = os.path.join(tempfile.mkdtemp(prefix='w4isa'), 'conv_wino4.s')
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-c', '-S', '--cuda-device-only', '-o', out, src],
+                   check=True, stderr=subprocess.DEVNULL)
+    return out
+
+
+def regs_of(operand_text):
+    """Set of VGPR numbers named in an operand string (v12, v[4:7])."""
+    out = set()
+    for m in re.finditer(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b', operand_text):
+        if m.group(3) is not None:
+            out.add(int(m.group(3)))
+        else:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def check(path):
+    text = open(path).read()
+    m = re.search(r'^(_Z\d+conv_wino4_kernelILi0E\w*):', text, re.M)
+    assert m, 'kernel symbol not found'
+    body = text[m.end():text.index('s_endpgm', m.end())]
+    queue = []          # outstanding vector-memory operations, oldest first: destination VGPR or None
+    problems, nload, nwait = [], 0, 0
+    for ln in body.split('\n'):
+        t = ln.split(';')[0].strip()
+        if not t or t.endswith(':') or t.startswith('.'):
+            continue
+        op, _, rest = t.partition(' ')
+        if op.startswith('buffer_load') or op.startswith('buffer_store'):
+            dst = None
+            if op == 'buffer_load_dword' and ' lds' not in t:
+                dst = int(re.match(r'\s*v(\d+)', rest).group(1))
+                nload += 1
+            used = regs_of(rest.split(',', 1)[1] if dst is not None else rest)     # address / data operands
+            hit = used & {q for q in queue if q is not None}
+            if hit:
+                problems.append('%s  <- uses in-flight v%s' % (t, sorted(hit)))
+            queue.append(dst)
+            continue
+        if op == 's_waitcnt':
+            mm = re.search(r'vmcnt\((\d+)\)', rest)
+            if mm:
+                nwait += 1
+                keep = int(mm.group(1))
+                while len(queue) > keep:
+                    queue.pop(0)
+            continue
+        hit = regs_of(rest) & {q for q in queue if q is not None}
+        if hit:
+            problems.append('%s  <- touches in-flight v%s' % (t, sorted(hit)))
+    scratch = re.search(r'\.private_segment_fixed_size:\s*(\d+)', text)
+    if scratch and int(scratch.group(1)) != 0:
+        problems.append('scratch in use: %s bytes per lane' % scratch.group(1))
+    return problems, nload, nwait
+
+
+if __name__ == '__main__':
+    path = sys.argv[1] if len(sys.argv) > 1 else compile_isa()
+    problems, nload, nwait = check(path)
+    print('%d filter / residual loads, %d vmcnt waits, %d problems' % (nload, nwait, len(problems)))
+    for p in problems[:40]:
+        print('  ' + p)
+    sys.exit(1 if problems else 0)

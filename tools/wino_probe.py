@@ -39,11 +39,14 @@ def main():
         wd = engine.pack_conv_weight(wt).cuda()
         wu = engine.pack_wino_weight(wt).cuda()
         wu43 = engine.pack_wino43_weight(wt).cuda() if cout % 48 == 0 and cin % 4 == 0 else None
+        wu4 = engine.pack_wino4_weight(wt).cuda() if cout % 48 == 0 and cin % 8 == 0 else None
         if a.data != 'randn':
             fill = 0.0 if a.data == 'zeros' else 1.0
             x.fill_(fill); wd.fill_(fill); wu.fill_(fill)
             if wu43 is not None:
                 wu43.fill_(fill)
+            if wu4 is not None:
+                wu4.fill_(fill)
         sc = (torch.rand(cout, generator=g) + 0.5).cuda()
         sh = torch.randn(cout, generator=g).cuda()
         res = torch.randn(n, h, w, cout, generator=g).cuda() if a.res else None
@@ -51,7 +54,7 @@ def main():
             res.zero_()
         flops = 2.0 * n * h * w * cout * cin * 9
         dcfg = dcfgs[si] if len(dcfgs) > 1 else dcfgs[0]
-        cases = [('direct%d' % dcfg, dcfg, wd)] + [('wino%s' % c, int(c), wu43 if L.egn_conv_config_kind(int(c)) == 2 else wu)
+        cases = [('direct%d' % dcfg, dcfg, wd)] + [('wino%s' % c, int(c), wu4 if int(c) >= 70 else {2: wu43, 3: wu4}.get(L.egn_conv_config_kind(int(c)), wu))
                                                     for c in a.wino.split(',')]
         outs, ok = {}, []
         for name, cfg, wp in cases:
