@@ -51,6 +51,7 @@ PEAK_HBM_GBPS = 8000.0
 # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_r3.sh + tools/pmc_traffic.py), newest first
 TRAFFIC_JSONS = [os.path.join(ROOT, 'profiles', n) for n in ('r3_pmc_traffic.json', 'r2_pmc_traffic.json')]
 WINO_EXECUTED = 16.0 / 36.0       # fused Winograd F(2x2,3x3): multiplies executed per direct-algorithm multiply
+WINO4_EXECUTED = 36.0 / 144.0     # F(4x4,3x3): 36 multiplies per 16 outputs instead of 144
 
 
 def parse():
@@ -109,7 +110,14 @@ def _klass_cout(klass):
 
 def _is_wino(cfg):
     from egonet_amd import _lib
-    return bool(cfg) and cfg > 0 and _lib.lib().egn_conv_config_kind(cfg) == 1
+    return bool(cfg) and cfg > 0 and _lib.lib().egn_conv_config_kind(cfg) in (1, 2, 3)
+
+
+def _executed(cfg):
+    """Executed multiplies per direct-algorithm multiply of a tile configuration (1 for the direct kernels)."""
+    from egonet_amd import _lib
+    kind = _lib.lib().egn_conv_config_kind(cfg) if cfg and cfg > 0 else 0
+    return WINO_EXECUTED if kind == 1 else (WINO4_EXECUTED if kind in (2, 3) else 1.0)
 
 
 def kernel_tables(prog, ms):
@@ -123,7 +131,7 @@ def kernel_tables(prog, ms):
         cfg = meta.get('cfg', 0)
         sym = _symbol(cfg, _klass_cout(meta.get('klass'))) if meta['kind'] == 'conv' \
             else meta['kind'] + '_kernel'
-        ex = meta['flops'] * (WINO_EXECUTED if meta['kind'] == 'conv' and _is_wino(cfg) else 1.0)
+        ex = meta['flops'] * (_executed(cfg) if meta['kind'] == 'conv' else 1.0)
         for table, key in ((by_class, meta['klass']), (by_symbol, sym)):
             a = table.setdefault(key, dict(name=key, kind=meta['kind'], launches=0, ms=0.0, flops=0.0, xflops=0.0,
                                            bytes=0.0))
@@ -170,8 +178,11 @@ def mfma_roofline(symbol, direct_tflops, executed_tflops):
             'direct_equivalent_tflops': direct_tflops,
             'direct_equivalent_x_peak': direct_tflops / PEAK_FP32_MFMA_TFLOPS}
     if abs(direct_tflops - executed_tflops) > 1e-9 * max(direct_tflops, 1.0):
-        roof['algorithm'] = ('fused Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs and (ci,co) instead of 36; '
-                             'achieved = executed flops, direct_equivalent = SURVEY 8(d) algorithmic flops')
+        f43 = 'wino4' in symbol
+        roof['algorithm'] = (('fused Winograd F(4x4,3x3): 36 multiplies per 4x4 outputs and (ci,co) instead of 144; '
+                              if f43 else
+                              'fused Winograd F(2x2,3x3): 16 multiplies per 2x2 outputs and (ci,co) instead of 36; ')
+                             + 'achieved = executed flops, direct_equivalent = SURVEY 8(d) algorithmic flops')
     traffic, src = measured_traffic(symbol)
     roof['traffic'] = traffic
     roof['traffic_source'] = None if traffic is None else \
@@ -272,7 +283,7 @@ def _dominant(timing):
         a[0] += 1
         a[1] += e0.elapsed_time(e1)
         a[2] += flops
-        a[3] += flops * (WINO_EXECUTED if _is_wino(cfg) else 1.0)
+        a[3] += flops * _executed(cfg)
     total = sum(a[1] for a in by.values())
     name, (n, ms, fl, xfl) = max(by.items(), key=lambda kv: kv[1][1])
     roof = mfma_roofline(name, fl / (ms * 1e-3) / 1e12, xfl / (ms * 1e-3) / 1e12)

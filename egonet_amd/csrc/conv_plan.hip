@@ -110,6 +110,7 @@ static const ConvConfig kConfigs[] = {
     {75, 12, 1, 1, 3, 0, 16, 7},   // ... no halo DMA
     {76, 12, 1, 1, 3, 0, 7, 7},    // ... only DMA + filter loads + barriers
     {77, 12, 1, 1, 3, 0, 32, 7},   // ... halo reads without bank conflicts
+    {78, 12, 1, 1, 3, 0, 64, 7},   // 70 with s_memtime stamps (tools/wino4_clk.py; `res` = the stamp buffer)
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 

@@ -54,7 +54,7 @@ constexpr int W4_LDS = W4_H1 + W4_HBYTES;             // 122 880 B
 constexpr int W4_XBYTES = 36 * 3 * 1024;              // exchange [pt][nt][lane] float4: 110 592 B
 static_assert(W4_XBYTES <= W4_LDS, "the exchange reuses the stage buffers");
 static_assert(W4_HSLOT <= 2 * W4_NW * 64, "two DMA pieces per wave cover the halo");
-constexpr int W4_UKG = W4_NW * 9 * 64;                // filter floats of one (co-tile, stage, k-group): 6912
+constexpr int W4_UKG = W4_NW * 3 * 64 * 4;            // filter floats of one (co-tile, stage, k-group): 9216 (9 of 12 used)
 constexpr unsigned W4_PAST = 0x80000000u;             // scalar byte offset past every buffer (tensors stay below 2 GB)
 }  // namespace
 
@@ -81,17 +81,17 @@ __device__ __forceinline__ void w4_landed6(float (&a)[6], float (&b)[6]) {
 __device__ __forceinline__ void w4_tie6(float (&a)[6]) {
   asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
 }
+// filter loads: dwordx4 (a burst of 20 single-dword loads per wave and stage cost every wave ~1 000 cycles of
+// issue time behind the barrier, profiles/r3_wino4_timeline_v1.txt)
 template <int OFF>
-__device__ __forceinline__ float w4_gld(u32x4 rsrc, unsigned voff, unsigned soff) {
-  float v;
-  asm volatile("buffer_load_dword %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF));
+__device__ __forceinline__ f32x4 w4_gld4(u32x4 rsrc, unsigned voff, unsigned soff) {
+  f32x4 v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF));
   return v;
 }
 template <int N>
-__device__ __forceinline__ void w4_vm_landed9(float (&b)[9]) {
-  asm volatile("s_waitcnt vmcnt(%9)"
-               : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8])
-               : "n"(N));
+__device__ __forceinline__ void w4_vm_landed3(f32x4 (&b)[3]) {
+  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N));
 }
 template <int OFF>
 __device__ __forceinline__ void w4_xwr(unsigned addr, f32x4 v) {
@@ -124,72 +124,66 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4]) {
   y[3] = __builtin_fmaf(8.f, s, q) + m[5];
 }
 
-// halo of stage parity P -> V of parity P, for this wave's (m-tile, k-group) share; hb / vw: per-lane byte bases
-template <int P>
+// halo of stage parity P -> V, for this wave's (m-tile, k-group) share and its THIRD of the frequency rows:
+// PART 0 rows {0, 5}, 1 rows {1, 2}, 2 rows {3, 4} -- 48 VALU instructions, 36 / 24 / 24 LDS reads, 12 writes each.
+// hb0: per-lane byte base in halo buffer 0 (the immediates reach both buffers); vw0: base in THIS parity's V buffer.
+template <int P, int PART>
 __device__ __forceinline__ void w4_transform(unsigned hb0, unsigned vw0) {
-  constexpr int HB = P ? W4_H1 : W4_H0;
-  constexpr int VB = P ? W4_V1 : W4_V0;
   static_assert(W4_H1 - W4_H0 + (3 * W4_PLANE + 5 * W4_XD + 1) * 16 < 65536, "halo immediates");
-  // hb0 holds W4_H0 (the immediates of both halo buffers stay below 64 K); vw0 holds THIS parity's V buffer
-  constexpr int HO = HB - W4_H0, VO = 0;
-  (void)VB;
+  constexpr int HO = P ? W4_H1 - W4_H0 : 0;
 #define W4_D(I, J) w4_lds<HO + (((J) & 3) * W4_PLANE + (I)*W4_XD + ((J) >> 2)) * 16>(hb0)
-#define W4_WR(PT, VAL) asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(vw0), "v"(VAL), "n"(VO + (PT)*1024) : "memory")
+#define W4_WR(PT, VAL) asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(vw0), "v"(VAL), "n"((PT)*1024) : "memory")
 #define W4_ROW(FI, O)                                                                                   \
   W4_WR((FI)*6 + 0, (O)[0]); W4_WR((FI)*6 + 1, (O)[1]); W4_WR((FI)*6 + 2, (O)[2]);                      \
   W4_WR((FI)*6 + 3, (O)[3]); W4_WR((FI)*6 + 4, (O)[4]); W4_WR((FI)*6 + 5, (O)[5]);
-  static_assert(VO + 35 * 1024 < 65536, "V immediates");
-  {  // frequency row 0: T0 = 4 d0 - 5 d2 + d4; row 5: T5 = 4 d1 - 5 d3 + d5 (18 + 18 reads, two batches)
-    float a[6], b[6], c[6], t[6], o[6];
-    a[0] = W4_D(0, 0); a[1] = W4_D(0, 1); a[2] = W4_D(0, 2); a[3] = W4_D(0, 3); a[4] = W4_D(0, 4); a[5] = W4_D(0, 5);
-    b[0] = W4_D(2, 0); b[1] = W4_D(2, 1); b[2] = W4_D(2, 2); b[3] = W4_D(2, 3); b[4] = W4_D(2, 4); b[5] = W4_D(2, 5);
-    c[0] = W4_D(4, 0); c[1] = W4_D(4, 1); c[2] = W4_D(4, 2); c[3] = W4_D(4, 3); c[4] = W4_D(4, 4); c[5] = W4_D(4, 5);
-    w4_landed6(a, b);
-    w4_tie6(c);
+#define W4_RD6(DST, I)                                                                                  \
+  DST[0] = W4_D(I, 0); DST[1] = W4_D(I, 1); DST[2] = W4_D(I, 2); DST[3] = W4_D(I, 3); DST[4] = W4_D(I, 4); DST[5] = W4_D(I, 5);
+  if constexpr (PART == 0) {
+    // row 0: T = 4 d0 - 5 d2 + d4; row 5: T = 4 d1 - 5 d3 + d5
+    {
+      float x[6], y[6], z[6], t[6], o[6];
+      W4_RD6(x, 0) W4_RD6(y, 2) W4_RD6(z, 4)
+      w4_landed6(x, y);
+      w4_tie6(z);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) t[j] = __builtin_fmaf(4.f, a[j], __builtin_fmaf(-5.f, b[j], c[j]));
-    w4_bt(t, o);
-    W4_ROW(0, o)
-  }
-  {  // rows 1..4 from input rows 1..4: u = d4 - 4 d2, v = d3 - 4 d1, p = d4 - d2, q = d3 - d1
-    float d1[6], d2[6], d3[6], d4[6];
-    d1[0] = W4_D(1, 0); d1[1] = W4_D(1, 1); d1[2] = W4_D(1, 2); d1[3] = W4_D(1, 3); d1[4] = W4_D(1, 4); d1[5] = W4_D(1, 5);
-    d2[0] = W4_D(2, 0); d2[1] = W4_D(2, 1); d2[2] = W4_D(2, 2); d2[3] = W4_D(2, 3); d2[4] = W4_D(2, 4); d2[5] = W4_D(2, 5);
+      for (int j = 0; j < 6; ++j) t[j] = __builtin_fmaf(4.f, x[j], __builtin_fmaf(-5.f, y[j], z[j]));
+      w4_bt(t, o);
+      W4_ROW(0, o)
+    }
+    {
+      float x[6], y[6], z[6], t[6], o[6];
+      W4_RD6(x, 1) W4_RD6(y, 3) W4_RD6(z, 5)
+      w4_landed6(x, y);
+      w4_tie6(z);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) t[j] = __builtin_fmaf(4.f, x[j], __builtin_fmaf(-5.f, y[j], z[j]));
+      w4_bt(t, o);
+      W4_ROW(5, o)
+    }
+  } else {
+    float d1[6], d2[6], d3[6], d4[6], ta[6], tb[6], o[6];
+    W4_RD6(d1, 1) W4_RD6(d2, 2) W4_RD6(d3, 3) W4_RD6(d4, 4)
     w4_landed6(d1, d2);
-    d3[0] = W4_D(3, 0); d3[1] = W4_D(3, 1); d3[2] = W4_D(3, 2); d3[3] = W4_D(3, 3); d3[4] = W4_D(3, 4); d3[5] = W4_D(3, 5);
-    d4[0] = W4_D(4, 0); d4[1] = W4_D(4, 1); d4[2] = W4_D(4, 2); d4[3] = W4_D(4, 3); d4[4] = W4_D(4, 4); d4[5] = W4_D(4, 5);
-    w4_landed6(d3, d4);
-    float t1[6], t2[6], t3[6], t4[6], o[6];
+    w4_tie6(d3);
+    w4_tie6(d4);
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      const float u = __builtin_fmaf(-4.f, d2[j], d4[j]), v = __builtin_fmaf(-4.f, d1[j], d3[j]);
-      t1[j] = u + v;
-      t2[j] = u - v;
-      const float p = d4[j] - d2[j], q = d3[j] - d1[j];
-      t3[j] = __builtin_fmaf(2.f, q, p);
-      t4[j] = __builtin_fmaf(-2.f, q, p);
+      if constexpr (PART == 1) {        // rows 1, 2: u = d4 - 4 d2, v = d3 - 4 d1
+        const float u = __builtin_fmaf(-4.f, d2[j], d4[j]), v = __builtin_fmaf(-4.f, d1[j], d3[j]);
+        ta[j] = u + v;
+        tb[j] = u - v;
+      } else {                          // rows 3, 4: p = d4 - d2, q = d3 - d1
+        const float p = d4[j] - d2[j], q = d3[j] - d1[j];
+        ta[j] = __builtin_fmaf(2.f, q, p);
+        tb[j] = __builtin_fmaf(-2.f, q, p);
+      }
     }
-    w4_bt(t1, o);
-    W4_ROW(1, o)
-    w4_bt(t2, o);
-    W4_ROW(2, o)
-    w4_bt(t3, o);
-    W4_ROW(3, o)
-    w4_bt(t4, o);
-    W4_ROW(4, o)
+    w4_bt(ta, o);
+    if constexpr (PART == 1) { W4_ROW(1, o) } else { W4_ROW(3, o) }
+    w4_bt(tb, o);
+    if constexpr (PART == 1) { W4_ROW(2, o) } else { W4_ROW(4, o) }
   }
-  {
-    float a[6], b[6], c[6], t[6], o[6];
-    a[0] = W4_D(1, 0); a[1] = W4_D(1, 1); a[2] = W4_D(1, 2); a[3] = W4_D(1, 3); a[4] = W4_D(1, 4); a[5] = W4_D(1, 5);
-    b[0] = W4_D(3, 0); b[1] = W4_D(3, 1); b[2] = W4_D(3, 2); b[3] = W4_D(3, 3); b[4] = W4_D(3, 4); b[5] = W4_D(3, 5);
-    c[0] = W4_D(5, 0); c[1] = W4_D(5, 1); c[2] = W4_D(5, 2); c[3] = W4_D(5, 3); c[4] = W4_D(5, 4); c[5] = W4_D(5, 5);
-    w4_landed6(a, b);
-    w4_tie6(c);
-#pragma unroll
-    for (int j = 0; j < 6; ++j) t[j] = __builtin_fmaf(4.f, a[j], __builtin_fmaf(-5.f, b[j], c[j]));
-    w4_bt(t, o);
-    W4_ROW(5, o)
-  }
+#undef W4_RD6
 #undef W4_D
 #undef W4_WR
 #undef W4_ROW
@@ -208,7 +202,7 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
-  const int tgrp = wave >> 2;              // transform rotation: group (s mod 3) transforms stage s
+  const int tpart = wave >> 2;             // its third of the frequency rows of the input transform
   const int tw = wave & 3;                 // its share: m-tile tw >> 1, k-group tw & 1
 
   const int C = a.Cin, Co = a.Cout;
@@ -250,7 +244,7 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
   }
   // ---- multiply: A operands V[3 wave + pl][mt][g][lane], filter block of this wave
   const float* va0 = smf + (W4_V0 / 4) + (3 * wave) * 256 + lane;
-  const unsigned uvo = (unsigned)lane * 4u;
+  const unsigned uvo = (unsigned)lane * 16u;
   // ---- exchange + output: this lane finishes tile 4 (wave & 3) + (lane >> 4) of the m-tile, co 16 (wave >> 2) + li
   const int ont = wave >> 2, okq = wave & 3;
   const unsigned xw0 = lds0 + (unsigned)((3 * wave) * 3 * 1024 + lane * 16);
@@ -261,9 +255,22 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
   const int nwork = ((nreg + 7) >> 3) * nct * 8;
   const int gsz = __builtin_amdgcn_readfirstlane((int)gridDim.x);
   const float act_lo = (a.act & EGN_ACT_MASK) == EGN_ACT_RELU ? 0.f : -__builtin_inff();
-  const bool has_res = a.res != nullptr;
+  const bool has_res = (ABL & 64) ? false : a.res != nullptr;
   const unsigned rowpitch = (unsigned)(a.Wo * Co) * 4u, colpitch = (unsigned)Co * 4u;
 
+  // ABL & 64 (tools/wino4_clk.py): s_memtime stamps of every wave into the LDS above the stage buffers, dumped into
+  // `res` at the end ([block][1 + 12 x 96] u64)
+  constexpr int W4_NTK = 96;
+  unsigned long long* sT = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(w4_smem) + W4_LDS);
+  int ntk = 0;
+#define W4_CLK()                                                                        \
+  {                                                                                     \
+    if constexpr ((ABL & 64) != 0) {                                                    \
+      if (lane == 0 && ntk < W4_NTK) sT[wave * W4_NTK + ntk] = __builtin_readcyclecounter(); \
+      ++ntk;                                                                            \
+    }                                                                                   \
+  }
+  W4_CLK()
   for (int w = blockIdx.x; w < nwork; w += gsz) {
     // item -> (region, co-tile): blocks w, w + 8, ... stay on one XCD (conv_wino.hip: wino8_grid)
     const unsigned wi = (unsigned)__builtin_amdgcn_readfirstlane(w);
@@ -288,36 +295,46 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
         doff[k] = in ? (unsigned)base + hrel[k] : EGN_OOB;
       }
     }
-#define W4_DMA(P, STAGE) /* STAGE: byte offset of the stage's channels, W4_PAST = none */                      \
+#define W4_DMA1(P, K, STAGE) /* piece K of this wave; STAGE: byte offset of the stage's channels, W4_PAST = none */ \
   if constexpr ((ABL & 16) == 0) {                                                                             \
-    w4_dma16(rxv, lds0 + (unsigned)((P) ? W4_H1 : W4_H0) + (unsigned)wave * 1024u, doff[0], (unsigned)(STAGE)); \
-    w4_dma16(rxv, lds0 + (unsigned)((P) ? W4_H1 : W4_H0) + (unsigned)(wave + W4_NW) * 1024u, doff[1],          \
+    w4_dma16(rxv, lds0 + (unsigned)((P) ? W4_H1 : W4_H0) + (unsigned)(wave + W4_NW * (K)) * 1024u, doff[K],    \
              (unsigned)(STAGE));                                                                               \
   }
+#define W4_DMA(P, STAGE) W4_DMA1(P, 0, STAGE) W4_DMA1(P, 1, STAGE)
     // filter k-group h = 2 stage + g of this wave: 9 dwords per lane, raw ISA -- the compiler's own vmcnt
     // bookkeeping does not see the LDS-DMA pieces and would wait for them with every filter wait
-    const unsigned ubase = (unsigned)(ct * S) * (2u * W4_UKG * 4u) + (unsigned)wave * (9u * 64u * 4u);
+    const unsigned ubase = (unsigned)(ct * S) * (2u * W4_UKG * 4u) + (unsigned)wave * (3u * 64u * 16u);
 #define W4_LOADB(DST, HS)                                                                                      \
   if constexpr ((ABL & 8) != 0) {                                                                              \
-    _Pragma("unroll") for (int p_ = 0; p_ < 9; ++p_) DST[p_] = (float)(lane + p_);                             \
+    _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) DST[p_] = f32x4{(float)lane, 1.f, 2.f, (float)p_};                             \
   } else {                                                                                                     \
     const unsigned so_ = (HS);        /* byte offset of the k-group, W4_PAST = none */                        \
-    DST[0] = w4_gld<0>(ruv, uvo, so_); DST[1] = w4_gld<256>(ruv, uvo, so_); DST[2] = w4_gld<512>(ruv, uvo, so_);       \
-    DST[3] = w4_gld<768>(ruv, uvo, so_); DST[4] = w4_gld<1024>(ruv, uvo, so_); DST[5] = w4_gld<1280>(ruv, uvo, so_);   \
-    DST[6] = w4_gld<1536>(ruv, uvo, so_); DST[7] = w4_gld<1792>(ruv, uvo, so_); DST[8] = w4_gld<2048>(ruv, uvo, so_);  \
+    DST[0] = w4_gld4<0>(ruv, uvo, so_); DST[1] = w4_gld4<1024>(ruv, uvo, so_); DST[2] = w4_gld4<2048>(ruv, uvo, so_); \
   }
-    float b0[9], b1[9];
+#define W4_LOADB1(DST, Q, HS)                                                                                  \
+  if constexpr ((ABL & 8) != 0) DST[Q] = f32x4{(float)lane, 1.f, 2.f, (float)(Q)};                             \
+  else DST[Q] = w4_gld4<(Q)*1024>(ruv, uvo, (HS));
+    f32x4 b0[3], b1[3];       // value p = 3 pl + nt of the k-group = b[p >> 2][p & 3]
     W4_DMA(0, 0u)
     W4_DMA(1, 32u)
     W4_LOADB(b0, ubase)
-    asm volatile("s_waitcnt vmcnt(11)" ::: "memory");   // stage 0's pieces landed (2 pieces + 9 filter loads are newer)
+    W4_CLK()      /* item top: DMA + filter loads issued */
+    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // stage 0's pieces landed (2 pieces + 3 filter loads are newer)
+    W4_CLK()      /* own pieces of stage 0 landed */
     __builtin_amdgcn_s_barrier();
+    W4_CLK()      /* everyone's */
     asm volatile("" ::: "memory");
-    if ((ABL & 1) == 0 && tgrp == 0) w4_transform<0>(hb0, vw0);
+    if constexpr ((ABL & 1) == 0) {
+      if (tpart == 0) w4_transform<0, 0>(hb0, vw0);
+      else if (tpart == 1) w4_transform<0, 1>(hb0, vw0);
+      else w4_transform<0, 2>(hb0, vw0);
+    }
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the V writes
+    W4_CLK()      /* stage 0 transformed */
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    W4_CLK()      /* K loop starts */
 
     f32x4 acc[3][3][2];
 #pragma unroll
@@ -327,16 +344,24 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) acc[pl][nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int tsel = 1;                        // group that transforms stage s + 1 during stage s
-#define W4_MUL(P, G, B)                                                                                        \
+  // 18 MFMAs of a k-group in three groups of 6 (one frequency point each); H0 / H1 / H2: the vector-memory
+  // instruction issued behind each group -- spread over the stage instead of a burst behind the barrier, where
+  // all 12 waves of the CU queue for the address unit (profiles/r3_wino4_timeline_v1.txt: 1 000 cycles per wave)
+#define W4_MUL(P, G, B, H0, H1, H2)                                                                            \
   if constexpr ((ABL & 2) == 0) {                                                                              \
     float av_[3][2];                                                                                           \
     _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)          \
         av_[pl][mt] = va0[((P) ? W4_VBYTES / 4 : 0) + ((pl * 2 + mt) * 2 + (G)) * 64];                         \
-    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) _Pragma("unroll") for (int nt = 0; nt < 3; ++nt)          \
-        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) acc[pl][nt][mt] =                                     \
-            __builtin_amdgcn_mfma_f32_16x16x4f32(av_[pl][mt], B[pl * 3 + nt], acc[pl][nt][mt], 0, 0, 0);       \
+    W4_MUL6(0, B) __builtin_amdgcn_sched_barrier(0); H0 __builtin_amdgcn_sched_barrier(0);                     \
+    W4_MUL6(1, B) __builtin_amdgcn_sched_barrier(0); H1 __builtin_amdgcn_sched_barrier(0);                     \
+    W4_MUL6(2, B) __builtin_amdgcn_sched_barrier(0); H2 __builtin_amdgcn_sched_barrier(0);                     \
+  } else {                                                                                                     \
+    H0 H1 H2                                                                                                   \
   }
+#define W4_MUL6(PL, B)                                                                                         \
+  _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)            \
+      acc[PL][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[PL][mt], B[((PL)*3 + nt) >> 2][((PL)*3 + nt) & 3], \
+                                                             acc[PL][nt][mt], 0, 0, 0);
   // vmcnt is in-order: a wait for filter loads also waits for every OLDER DMA piece.  Order of a stage: filter
   // k-group 2s landed (nothing newer in flight) | issue k-group 2s+1, THEN the DMA pieces of stage s + 2 | multiply
   // g = 0 | k-group 2s+1 landed (the 2 pieces stay in flight) | issue k-group 2s+2 | multiply g = 1 | the pieces
@@ -345,35 +370,52 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
   // buffers' ends (zeros).  The filter registers are written asynchronously behind the compiler's back: the
   // destination of a load must reach its s_waitcnt without being copied -- tools/check_wino4_isa.py asserts that
   // on the compiled ISA (tests/test_wino4_design_cpu.py).
+  // raised priority: at equal priority the SIMD's arbiter hands the transforming wave one VALU issue per MFMA of
+  // the two multiplying waves -- 48 instructions took 1 500-2 000 cycles (profiles/r3_wino4_timeline_v2.txt)
+#define W4_TRANS(P, PART)                                                                                      \
+  if ((ABL & 1) == 0 && s_ + 1 < S && tpart == (PART)) {                                                       \
+    __builtin_amdgcn_s_setprio(3);                                                                             \
+    w4_transform<1 - (P), PART>(hb0, vw0 + (unsigned)((1 - (P)) * W4_VBYTES));                                 \
+    __builtin_amdgcn_s_setprio(0);                                                                             \
+  }
+  // the transform of stage s + 1 sits at a different point of the stage for each third of the waves: two of a
+  // SIMD's three waves always have MFMAs to issue
 #define W4_STAGE(P, SI)                                                                                        \
   {                                                                                                            \
     const int s_ = (SI);                                                                                       \
-    w4_vm_landed9<0>(b0);                                                                                      \
-    W4_LOADB(b1, s_ < S ? ubase + (unsigned)(2 * s_ + 1) * (W4_UKG * 4u) : W4_PAST)                                                                \
-    W4_DMA(P, s_ + 2 < S ? (unsigned)(s_ + 2) * 32u : W4_PAST)                                                                   \
-    if ((ABL & 1) == 0 && s_ + 1 < S && tgrp == tsel) {                                                        \
-      /* the stage's critical path: beside two waves that saturate the matrix pipe a plain-priority wave gets   \
-         one VALU issue per MFMA slot (the transform alone took 5 000 cycles) */                                \
-      __builtin_amdgcn_s_setprio(3);                                                                           \
-      w4_transform<1 - (P)>(hb0, vw0 + (unsigned)((1 - (P)) * W4_VBYTES));                                     \
-      __builtin_amdgcn_s_setprio(0);                                                                           \
-    }                                                                                                          \
-    W4_MUL(P, 0, b0)                                                                                           \
-    w4_vm_landed9<2>(b1);                                                                                      \
-    W4_LOADB(b0, s_ + 1 < S ? ubase + (unsigned)(2 * s_ + 2) * (W4_UKG * 4u) : W4_PAST)                                                            \
-    W4_MUL(P, 1, b1)                                                                                           \
-    tsel = tsel == 2 ? 0 : tsel + 1;                                                                           \
-    asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");                                                \
+    const unsigned dst_ = s_ + 2 < S ? (unsigned)(s_ + 2) * 32u : W4_PAST;                                     \
+    const unsigned bn_ = s_ + 1 < S ? ubase + (unsigned)(2 * s_ + 2) * (W4_UKG * 4u) : W4_PAST;                \
+    w4_vm_landed3<0>(b0);                                                                                      \
+    W4_CLK() /* 0: filter k-group 2s landed */                                                                 \
+    W4_LOADB(b1, s_ < S ? ubase + (unsigned)(2 * s_ + 1) * (W4_UKG * 4u) : W4_PAST)                            \
+    W4_TRANS(P, 0)                                                                                             \
+    W4_CLK() /* 1: loads issued (+ transform, first third of the waves) */                                     \
+    W4_MUL(P, 0, b0, W4_DMA1(P, 0, dst_), W4_DMA1(P, 1, dst_), )                                               \
+    W4_CLK() /* 2: g = 0 multiplies and the pieces of stage s + 2 issued */                                    \
+    w4_vm_landed3<2>(b1);                                                                                      \
+    W4_CLK() /* 3: filter k-group 2s+1 landed */                                                               \
+    W4_TRANS(P, 1)                                                                                             \
+    W4_MUL(P, 1, b1, W4_LOADB1(b0, 0, bn_), W4_LOADB1(b0, 1, bn_), W4_LOADB1(b0, 2, bn_))                      \
+    W4_TRANS(P, 2)                                                                                             \
+    W4_CLK() /* 4: g = 1 multiplies and k-group 2s+2 issued (+ transforms) */                                  \
+    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                                                \
+    W4_CLK() /* 5: own pieces of stage s + 2 landed, V writes done */                                          \
     __builtin_amdgcn_s_barrier();                                                                              \
     asm volatile("" ::: "memory");                                                                             \
+    W4_CLK() /* 6: past the barrier */                                                                         \
   }
     for (int s = 0; s < S; s += 2) {     // (S is even: Cin % 16 == 0)
       W4_STAGE(0, s)
       W4_STAGE(1, s + 1)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the loads past the end
+    W4_CLK()      /* K loop done */
 #undef W4_STAGE
+#undef W4_TRANS
 #undef W4_MUL
+#undef W4_MUL6
+#undef W4_DMA1
+#undef W4_LOADB1
 #undef W4_LOADB
 #undef W4_DMA
 
@@ -406,8 +448,10 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
       w4_xwr<6 * 1024>(xw0, acc[2][0][mt]); w4_xwr<7 * 1024>(xw0, acc[2][1][mt]); w4_xwr<8 * 1024>(xw0, acc[2][2][mt]);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(0xC07F);
+      W4_CLK()    /* round: accumulators written */
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      W4_CLK()    /* round: exchange barrier passed */
       // M[i][j] = X[6 i + j]: two columns per batch (12 reads), column pass A^T right away: 24 values stay
       float yc[4][6];
 #define W4_M(I, J) w4_xrd<(I)*6 + (J)>(xr0, xr1)
@@ -440,10 +484,20 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
         }
       }
       asm volatile("" ::: "memory");
+      W4_CLK()    /* round: output transform done, stores issued */
       __builtin_amdgcn_s_barrier();      // the exchange buffer is free again (next round / next item's DMA)
       asm volatile("" ::: "memory");
+      W4_CLK()    /* round: end */
     }
   }
+  if constexpr ((ABL & 64) != 0) {
+    __syncthreads();
+    unsigned long long* out = reinterpret_cast<unsigned long long*>(const_cast<float*>(a.res)) +
+                              (size_t)blockIdx.x * (W4_NW * W4_NTK + 1);
+    for (int e = tid; e < W4_NW * W4_NTK; e += W4_NTH) out[1 + e] = sT[e];
+    if (tid == 0) out[0] = (unsigned long long)ntk;
+  }
+#undef W4_CLK
 }
 
 bool egn_conv_wino4_applies(const ConvArgs& a) {
@@ -452,7 +506,7 @@ bool egn_conv_wino4_applies(const ConvArgs& a) {
          !(a.act & EGN_ACT_RES_AFTER) &&
          ((a.act & EGN_ACT_MASK) == EGN_ACT_NONE || (a.act & EGN_ACT_MASK) == EGN_ACT_RELU);
 }
-size_t egn_conv_wino4_lds_bytes() { return W4_LDS; }
+size_t egn_conv_wino4_lds_bytes() { return W4_LDS + 12 * 96 * 8; }      // (+ the stamp area of the ABL & 64 build)
 // floats of the packed filter (engine.pack_wino4_weight): [co-tile][stage = Cin / 8][k-group][wave][9][64]
 extern "C" long long egn_wino4_weight_floats(int cout, int cin) {
   if (cout % W4_CO || cin % 8 || cin < 16) return 0;
@@ -498,6 +552,7 @@ int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, hipStream_t stream) {
     case 16: return wino4_launch<16>(a, lds, stream);
     case 7: return wino4_launch<7>(a, lds, stream);
     case 32: return wino4_launch<32>(a, lds, stream);
+    case 64: return wino4_launch<64>(a, lds, stream);
     default: return EGN_E_BADARG;
   }
 }

@@ -91,9 +91,10 @@ def pack_wino43_weight(w):
 
 def pack_wino4_weight(w):
     """[Cout,Cin,3,3] -> the Winograd F(4x4,3x3) filter U = G g G^T (float64, rounded once to fp32) in the layout
-    conv_wino4_kernel's waves load straight into MFMA B registers (csrc/conv_wino4.hip):
-    flat fp32 [co-tile = Cout/48][stage = Cin/8][k-group g][wave 0..11][p = 3 pl + nt][lane = 16 kq + li] with
-    point 3 wave + pl, co = 48 ct + 16 nt + li, ci = 8 stage + 4 g + kq."""
+    conv_wino4_kernel's waves load straight into MFMA B registers (csrc/conv_wino4.hip), three dwordx4 per wave
+    and k-group: flat fp32 [co-tile = Cout/48][stage = Cin/8][k-group g][wave 0..11][q 0..2][lane = 16 kq + li][4]
+    where value p = 4 q + r (p = 3 pl + nt < 9, the rest is padding) is point 3 wave + pl, co = 48 ct + 16 nt + li,
+    ci = 8 stage + 4 g + kq."""
     w = w.detach().to(torch.float64).cpu()
     cout, cin, kh, kw = w.shape
     assert (kh, kw) == (3, 3) and cout % 48 == 0 and cin % 8 == 0, w.shape
@@ -102,7 +103,12 @@ def pack_wino4_weight(w):
     u = torch.einsum('ia,ocab,jb->ocij', G, w, G).to(torch.float32).reshape(cout, cin, 36)
     #   co = (ct, nt, li)          ci = (stage, g, kq)        pt = (wave, pl)
     u = u.reshape(cout // 48, 3, 16, cin // 8, 2, 4, 12, 3)   # ct nt li stage g kq wave pl
-    return u.permute(0, 3, 4, 6, 7, 1, 5, 2).contiguous().reshape(-1)      # ct stage g wave pl nt kq li
+    u = u.permute(0, 3, 4, 6, 7, 1, 5, 2).contiguous()        # ct stage g wave pl nt kq li
+    ct, st = cout // 48, cin // 8
+    u = u.reshape(ct, st, 2, 12, 9, 64)                        # ... p = 3 pl + nt, lane = 16 kq + li
+    pad = torch.zeros(ct, st, 2, 12, 12, 64, dtype=torch.float32)
+    pad[:, :, :, :, :9] = u
+    return pad.reshape(ct, st, 2, 12, 3, 4, 64).permute(0, 1, 2, 3, 4, 6, 5).contiguous().reshape(-1)   # q lane r
 
 
 def pack_for_kind(w, kind):

@@ -81,9 +81,9 @@ def tune(device, args, skip=()):
     g = torch.Generator(device='cpu').manual_seed(1)
     with torch.cuda.device(device):
         x = torch.randn(n * h * wd * cs_in, device=device)
-        # one buffer serves both packings (random data: only the timing matters); the Winograd
-        # kernels read 16 floats per (co, ci)
-        w = torch.randn(max(nchunk * kh * kw * 4 * coutp * 4, cout * cin * 36), device=device) * 0.05
+        # one buffer serves every packing (random data: only the timing matters); the Winograd kernels read 16
+        # (F(2x2,3x3)) / 36 or 48 (F(4x4,3x3), conv_wino4_kernel's padded layout) floats per (co, ci)
+        w = torch.randn(max(nchunk * kh * kw * 4 * coutp * 4, cout * cin * 48), device=device) * 0.05
         sc = torch.ones(coutp, device=device)
         sh = torch.zeros(coutp, device=device)
         ny = n * ho * wo * (cout if out_nchw else cs_out)

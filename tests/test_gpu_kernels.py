@@ -43,7 +43,8 @@ def _conv_case(n, h, w, cin, cout, k, s, p, act=1, use_res=False, nchw=False, cf
         if res is not None and (act & 0x10):
             ref = res + ref
     from egonet_amd import _lib
-    pc = ops.PackedConv(wt, b, bn, wino=(cfg > 0 and _lib.lib().egn_conv_config_kind(cfg) == 1))
+    kind = _lib.lib().egn_conv_config_kind(cfg) if cfg > 0 else 0
+    pc = ops.PackedConv(wt, b, bn, wino=(kind == 1), kind=kind if kind in (2, 3) else None)
     xd = ops.nchw_to_nhwc(x.cuda())
     rd = ops.nchw_to_nhwc(res.cuda()) if res is not None else None
     y = ops.conv2d_nhwc(xd, pc, cin, s, p, act, rd, out_nchw=nchw, cfg=cfg)
@@ -170,6 +171,35 @@ def test_conv_winograd_kernels(n, h, w, cin, cout, res, act):
     assert L.egn_conv_plan_query(2, 16, 16, 35, 36, 48, 48, 3, 3, 1, 1, 0, 45, out) != 0
     assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 80, 80, 3, 3, 1, 1, 0, 51, out) != 0
     assert L.egn_wino_weight_floats(80, 48, 0) == 0 and L.egn_wino_weight_floats(48, 80, 1) == 0
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,res,act', [
+    (2, 16, 32, 16, 48, True, 1),      # one region per image, the shortest K loop (2 stages)
+    (3, 32, 64, 48, 96, False, 0),     # 4 regions x 2 co-tiles, no activation, no residual
+    (1, 64, 64, 32, 48, True, 1),      # the 64 x 64 maps of stage 2
+    (5, 32, 32, 96, 144, True, 1),     # odd batch, 3 co-tiles
+])
+def test_conv_wino4_kernel(n, h, w, cin, cout, res, act):
+    """Config 70, csrc/conv_wino4.hip: fused Winograd F(4x4,3x3) (input transform once per (tile, channel) into
+    LDS, filter from global memory into MFMA B registers; host filter transform engine.pack_wino4_weight).
+    Same oracle as the direct kernels; F(4x4,3x3) in fp32 carries ~10x the rounding error of F(2x2,3x3)
+    (transform constants up to 8, tools/wino43_error_study.py): tolerance 5e-4 on outputs of magnitude ~3."""
+    import ctypes as C
+    from egonet_amd import _lib
+    L = _lib.lib()
+    assert L.egn_conv_config_kind(70) == 3 and L.egn_conv_config_kind(71) == -1 and L.egn_conv_config_kind(78) == -1
+    assert L.egn_wino4_weight_floats(cout, cin) == (cout // 48) * (cin // 8) * 2 * 12 * 3 * 64 * 4
+    out = (C.c_int * 12)()
+    assert L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, 70, out) == 0
+    err = _conv_case(n, h, w, cin, cout, 3, 1, 1, act=act, use_res=res, cfg=70, seed=n + h + cin)
+    assert err < 5e-4, err
+    # what the planner must refuse: maps that are not whole 16 x 32 regions, Cin % 16, Cout % 48, stride 2, 1x1
+    assert L.egn_conv_plan_query(2, 8, 32, 48, 48, 48, 48, 3, 3, 1, 1, 0, 70, out) != 0
+    assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 48, 48, 3, 3, 1, 1, 0, 70, out) != 0
+    assert L.egn_conv_plan_query(2, 16, 32, 24, 24, 48, 48, 3, 3, 1, 1, 0, 70, out) != 0
+    assert L.egn_conv_plan_query(2, 16, 32, 48, 48, 64, 64, 3, 3, 1, 1, 0, 70, out) != 0
+    assert L.egn_conv_plan_query(2, 32, 64, 48, 48, 48, 48, 3, 3, 2, 1, 0, 70, out) != 0
+    assert L.egn_wino4_weight_floats(64, 48) == 0 and L.egn_wino4_weight_floats(48, 20) == 0
 
 
 @pytest.mark.parametrize('h,c,cfg', [(64, 48, 51), (32, 96, 51), (16, 192, 51), (8, 384, 56), (16, 192, 57)])

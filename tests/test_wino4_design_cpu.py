@@ -1,0 +1,124 @@
+"""conv_wino4_kernel (csrc/conv_wino4.hip) without a GPU: the algebra the kernel implements restated in numpy
+(B^T d B, A^T M A with the kernel's own instruction forms), the filter layout its waves load, the halo slot order
+that keeps the transform's LDS reads off each other's banks, and -- on the ISA hipcc produces here -- that no
+register of an asynchronous filter load is touched before its s_waitcnt (tools/check_wino4_isa.py)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+BT = np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0],
+               [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=np.float64)
+AT = np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=np.float64)
+G = np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
+              [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=np.float64)
+
+
+def bt6(t):          # w4_bt: the 12-instruction form
+    o = np.empty(6)
+    o[0] = 4 * t[0] + (-5 * t[2] + t[4])
+    u, v = -4 * t[2] + t[4], -4 * t[1] + t[3]
+    o[1], o[2] = u + v, u - v
+    p, q = t[4] - t[2], t[3] - t[1]
+    o[3], o[4] = 2 * q + p, -2 * q + p
+    o[5] = 4 * t[1] + (-5 * t[3] + t[5])
+    return o
+
+
+def at6(m):          # w4_at: the 10-instruction form
+    p, q, r, s = m[1] + m[2], m[1] - m[2], m[3] + m[4], m[3] - m[4]
+    return np.array([m[0] + p + r, 2 * s + q, 4 * r + p, 8 * s + q + m[5]])
+
+
+def test_instruction_forms_equal_the_matrices():
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        t = rng.standard_normal(6)
+        np.testing.assert_allclose(bt6(t), BT @ t, atol=1e-12)
+        np.testing.assert_allclose(at6(t), AT @ t, atol=1e-12)
+
+
+def test_thirds_of_the_input_transform_cover_b_t_d_b():
+    """PART 0 rows {0, 5}, PART 1 rows {1, 2}, PART 2 rows {3, 4} of the row pass, each followed by the column pass."""
+    rng = np.random.default_rng(1)
+    d = rng.standard_normal((6, 6))
+    V = np.empty((6, 6))
+    V[0] = bt6(4 * d[0] - 5 * d[2] + d[4])
+    V[5] = bt6(4 * d[1] - 5 * d[3] + d[5])
+    u, v = d[4] - 4 * d[2], d[3] - 4 * d[1]
+    V[1], V[2] = bt6(u + v), bt6(u - v)
+    p, q = d[4] - d[2], d[3] - d[1]
+    V[3], V[4] = bt6(p + 2 * q), bt6(p - 2 * q)
+    np.testing.assert_allclose(V, BT @ d @ BT.T, atol=1e-12)
+
+
+def test_f43_convolution_identity_and_packed_filter_layout():
+    """Y = A^T [ sum_ci (G g G^T) * (B^T d B) ] A equals the direct 3x3 correlation on a 4x4 output tile, with U read
+    back out of engine.pack_wino4_weight's layout exactly as a wave's lane does."""
+    from egonet_amd import engine
+    rng = np.random.default_rng(2)
+    cout, cin = 48, 16
+    w = rng.standard_normal((cout, cin, 3, 3))
+    x = rng.standard_normal((cin, 6, 6))
+    U = engine.pack_wino4_weight(torch.from_numpy(w)).numpy().reshape(cout // 48, cin // 8, 2, 12, 3, 64, 4)
+    M = np.zeros((cout, 6, 6))
+    for ci in range(cin):
+        Vt = BT @ x[ci] @ BT.T
+        stage, g, kq = ci // 8, (ci % 8) // 4, ci % 4
+        for co in range(cout):
+            nt, li = co // 16, co % 16
+            for pt in range(36):
+                wave, pl = pt // 3, pt % 3
+                p_ = 3 * pl + nt
+                u = U[0, stage, g, wave, p_ // 4, 16 * kq + li, p_ % 4]
+                assert abs(u - (G @ w[co, ci] @ G.T)[pt // 6, pt % 6]) < 1e-6
+                M[co, pt // 6, pt % 6] += u * Vt[pt // 6, pt % 6]
+    Y = np.einsum('ai,cij,bj->cab', AT, M, AT)
+    ref = np.zeros((cout, 4, 4))
+    for a in range(4):
+        for b in range(4):
+            ref[:, a, b] = np.einsum('ocij,cij->o', w, x[:, a:a + 3, b:b + 3])
+    np.testing.assert_allclose(Y, ref, rtol=1e-5, atol=2e-4)      # U is rounded to fp32 once
+    # padding values of the dwordx4 layout are zero
+    assert float(np.abs(U[..., 2, :, 1:]).max()) == 0.0
+
+
+def test_halo_slot_order_is_bank_conflict_free_for_the_transform_reads():
+    """Slot of pixel (y, x), channel quad q: q * 720 + (x % 4) * 180 + y * 10 + x // 4 (16 bytes each).  Lane (tile
+    (ty, tx) of an m-tile, channel kq) reads pixel (4 ty + i, 4 tx + j): for every (i, j) the 64 lanes of a wave
+    must hit 64 different 4-byte banks; every halo pixel has exactly one slot below 1440."""
+    def slot(q, y, x):
+        return q * 720 + (x % 4) * 180 + y * 10 + x // 4
+    seen = set()
+    for q in range(2):
+        for y in range(18):
+            for x in range(34):
+                s = slot(q, y, x)
+                assert 0 <= s < 1440 and s not in seen
+                seen.add(s)
+    for mt in range(2):
+        for g in range(2):
+            for i in range(6):
+                for j in range(6):
+                    banks = set()
+                    for lane in range(64):
+                        li, kq = lane & 15, lane >> 4
+                        ty, tx = 2 * mt + (li >> 3), li & 7
+                        word = slot(g, 4 * ty + i, 4 * tx + j) * 4 + kq
+                        banks.add(word % 64)
+                    assert len(banks) == 64, (mt, g, i, j, len(banks))
+
+
+@pytest.mark.skipif(shutil.which(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')) is None, reason='hipcc not installed')
+def test_filter_load_registers_reach_their_waitcnt_untouched():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_wino4_isa.py')], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert ' 0 problems' in r.stdout

@@ -4,7 +4,7 @@
 The kernel loads its MFMA B operands (the transformed filter) with raw `buffer_load_dword` instructions and
 waits for them with hand-counted `s_waitcnt vmcnt(N)`: the compiler does not know that the destination
 registers are written asynchronously.  The source is arranged so that a loaded register reaches its wait
-untouched; this script ASSERTS it on the ISA hipcc produced: between a `buffer_load_dword vN` and the
+untouched; this script ASSERTS it on the ISA hipcc produced: between a `buffer_load_dword[x4] vN` and the
 `s_waitcnt vmcnt` that retires it, no instruction may read or write vN (a register copy there would move a
 value that has not arrived).  It also checks that no scratch is used (a spill would do the same).
 
@@ -40,6 +40,14 @@ def regs_of(operand_text):
     return out
 
 
+def inflight(queue):
+    out = set()
+    for q in queue:
+        if q is not None:
+            out |= q
+    return out
+
+
 def check(path):
     text = open(path).read()
     m = re.search(r'^(_Z\d+conv_wino4_kernelILi0E\w*):', text, re.M)
@@ -54,11 +62,11 @@ def check(path):
         op, _, rest = t.partition(' ')
         if op.startswith('buffer_load') or op.startswith('buffer_store'):
             dst = None
-            if op == 'buffer_load_dword' and ' lds' not in t:
-                dst = int(re.match(r'\s*v(\d+)', rest).group(1))
+            if op.startswith('buffer_load') and ' lds' not in t:
+                dst = frozenset(regs_of(rest.split(',', 1)[0]))
                 nload += 1
             used = regs_of(rest.split(',', 1)[1] if dst is not None else rest)     # address / data operands
-            hit = used & {q for q in queue if q is not None}
+            hit = used & inflight(queue)
             if hit:
                 problems.append('%s  <- uses in-flight v%s' % (t, sorted(hit)))
             queue.append(dst)
@@ -71,7 +79,7 @@ def check(path):
                 while len(queue) > keep:
                     queue.pop(0)
             continue
-        hit = regs_of(rest) & {q for q in queue if q is not None}
+        hit = regs_of(rest) & inflight(queue)
         if hit:
             problems.append('%s  <- touches in-flight v%s' % (t, sorted(hit)))
     scratch = re.search(r'\.private_segment_fixed_size:\s*(\d+)', text)
