@@ -30,6 +30,8 @@
 //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
 // Reference: the 3x3 stride-1 convolutions of libs/model/heatmapModel/hrnet.py (BasicBlock :49-76 and the
 // branches built from it); tolerance as for the F(2x2,3x3) kernels, see tools/wino43_network_study.py.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_w4_t;
@@ -92,6 +94,10 @@ __device__ __forceinline__ f32x4 w4_gld4(u32x4 rsrc, unsigned voff, unsigned sof
 template <int N>
 __device__ __forceinline__ void w4_vm_landed3(f32x4 (&b)[3]) {
   asm volatile("s_waitcnt vmcnt(%3)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void w4_vm_landed2(f32x4 (&h)[2]) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(h[0]), "+v"(h[1]) : "n"(N));
 }
 template <int OFF>
 __device__ __forceinline__ void w4_xwr(unsigned addr, f32x4 v) {
@@ -242,6 +248,7 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
     vw0 = lds0 + (unsigned)(W4_V0 + (mt * 2 + g) * 256 + lane * 4);
     if constexpr ((ABL & 32) != 0) hb0 = lds0 + (unsigned)(W4_H0 + lane * 4);     // conflict-free reads (wrong data)
   }
+  const unsigned hw0 = lds0 + (unsigned)(W4_H0 + wave * 1024 + lane * 16);     // this lane's slot of piece `wave`
   // ---- multiply: A operands V[3 wave + pl][mt][g][lane], filter block of this wave
   const float* va0 = smf + (W4_V0 / 4) + (3 * wave) * 256 + lane;
   const unsigned uvo = (unsigned)lane * 16u;
@@ -295,12 +302,18 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
         doff[k] = in ? (unsigned)base + hrel[k] : EGN_OOB;
       }
     }
-#define W4_DMA1(P, K, STAGE) /* piece K of this wave; STAGE: byte offset of the stage's channels, W4_PAST = none */ \
-  if constexpr ((ABL & 16) == 0) {                                                                             \
-    w4_dma16(rxv, lds0 + (unsigned)((P) ? W4_H1 : W4_H0) + (unsigned)(wave + W4_NW * (K)) * 1024u, doff[K],    \
-             (unsigned)(STAGE));                                                                               \
+  // The halo goes through REGISTERS (buffer_load_dwordx4 -> ds_write_b128), not LDS-DMA: the hand-counted
+  // s_waitcnt vmcnt(N) below rely on loads returning in issue order, which holds among loads into registers --
+  // LDS-DMA loads and register loads overtake each other (with LDS-DMA pieces in the same queue the kernel was
+  // exact alone and wrong beside other streams' kernels: tools/f43_bisect.py, profiles/r3_wino4_f43_bisect.txt).
+#define W4_HLOAD(K, STAGE) /* piece K of this wave; STAGE: byte offset of the stage's channels, W4_PAST = none */ \
+  if constexpr ((ABL & 16) == 0) hreg[K] = w4_gld4<0>(rxv, doff[K], (unsigned)(STAGE));                        \
+  else hreg[K] = f32x4{1.f, 2.f, 3.f, (float)lane};
+#define W4_HSTORE(P)                                                                                           \
+  {                                                                                                            \
+    w4_xwr<(P)*W4_HBYTES>(hw0, hreg[0]);                                                                       \
+    w4_xwr<(P)*W4_HBYTES + W4_NW * 1024>(hw0, hreg[1]);                                                        \
   }
-#define W4_DMA(P, STAGE) W4_DMA1(P, 0, STAGE) W4_DMA1(P, 1, STAGE)
     // filter k-group h = 2 stage + g of this wave: 9 dwords per lane, raw ISA -- the compiler's own vmcnt
     // bookkeeping does not see the LDS-DMA pieces and would wait for them with every filter wait
     const unsigned ubase = (unsigned)(ct * S) * (2u * W4_UKG * 4u) + (unsigned)wave * (3u * 64u * 16u);
@@ -315,12 +328,17 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
   if constexpr ((ABL & 8) != 0) DST[Q] = f32x4{(float)lane, 1.f, 2.f, (float)(Q)};                             \
   else DST[Q] = w4_gld4<(Q)*1024>(ruv, uvo, (HS));
     f32x4 b0[3], b1[3];       // value p = 3 pl + nt of the k-group = b[p >> 2][p & 3]
-    W4_DMA(0, 0u)
-    W4_DMA(1, 32u)
+    f32x4 hreg[2];
+    W4_HLOAD(0, 0u)
+    W4_HLOAD(1, 0u)
     W4_LOADB(b0, ubase)
-    W4_CLK()      /* item top: DMA + filter loads issued */
-    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");    // stage 0's pieces landed (2 pieces + 3 filter loads are newer)
-    W4_CLK()      /* own pieces of stage 0 landed */
+    W4_CLK()      /* item top: halo + filter loads issued */
+    w4_vm_landed2<0>(hreg);                             // stage 0's pieces (and the first filter k-group)
+    W4_HSTORE(0)
+    W4_HLOAD(0, 32u)                                    // stage 1's pieces fly during the first transform
+    W4_HLOAD(1, 32u)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    W4_CLK()      /* own pieces of stage 0 in LDS */
     __builtin_amdgcn_s_barrier();
     W4_CLK()      /* everyone's */
     asm volatile("" ::: "memory");
@@ -330,7 +348,11 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
       else w4_transform<0, 2>(hb0, vw0);
     }
     asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the V writes
+    // this wave's pieces of stage 1 (and the filter loads before them) have landed: into LDS with them -- the
+    // first third transforms stage 1 right behind the barrier
+    w4_vm_landed2<0>(hreg);
+    W4_HSTORE(1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     W4_CLK()      /* stage 0 transformed */
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -362,14 +384,20 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
   _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)            \
       acc[PL][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[PL][mt], B[((PL)*3 + nt) >> 2][((PL)*3 + nt) & 3], \
                                                              acc[PL][nt][mt], 0, 0, 0);
-  // vmcnt is in-order: a wait for filter loads also waits for every OLDER DMA piece.  Order of a stage: filter
-  // k-group 2s landed (nothing newer in flight) | issue k-group 2s+1, THEN the DMA pieces of stage s + 2 | multiply
-  // g = 0 | k-group 2s+1 landed (the 2 pieces stay in flight) | issue k-group 2s+2 | multiply g = 1 | the pieces
-  // landed (k-group 2s+2 stays in flight) | barrier: the pieces get a whole stage to arrive.
-  // Straight-line code with CONSTANT counts: past the last stage the loads / pieces are still issued, beyond the
-  // buffers' ends (zeros).  The filter registers are written asynchronously behind the compiler's back: the
-  // destination of a load must reach its s_waitcnt without being copied -- tools/check_wino4_isa.py asserts that
-  // on the compiled ISA (tests/test_wino4_design_cpu.py).
+  // Every vector-memory wait in this kernel is s_waitcnt vmcnt(0) -- on purpose.  The first versions counted
+  // (`vmcnt(3)`: "the halo pieces have landed, the three newer filter loads may stay in flight"), which needs loads
+  // to return in issue order.  Measured (tools/f43_bisect.py, profiles/r3_wino4_f43_bisect.txt): alone on the GPU
+  // the kernel was exact; beside other streams' kernels whole-network outputs were off by up to 10 -- and ONLY the
+  // wait in which older SLOW loads (the gathered halo, HBM) sit in front of newer FAST ones (the filter, L2) had
+  // to become vmcnt(0) to make it exact again, with LDS-DMA pieces and with plain register loads alike.  So the
+  // stage is ordered such that no wait needs a count: k-group 2s+1 is issued at the top and awaited (alone in the
+  // queue) behind the g = 0 multiplies; the halo pieces of stage s + 2 and k-group 2s+2 are issued behind the
+  // MFMA groups of g = 1 and awaited together at the end of the stage.
+  // The halo goes through registers (buffer_load_dwordx4 -> ds_write_b128): 2 pieces per wave and stage.
+  // Straight-line code: past the last stage the loads are still issued, beyond the buffers' ends (zeros).  The
+  // registers are written asynchronously behind the compiler's back: the destination of a load must reach its
+  // s_waitcnt without being copied -- tools/check_wino4_isa.py asserts that on the compiled ISA
+  // (tests/test_wino4_design_cpu.py).
   // raised priority: at equal priority the SIMD's arbiter hands the transforming wave one VALU issue per MFMA of
   // the two multiplying waves -- 48 instructions took 1 500-2 000 cycles (profiles/r3_wino4_timeline_v2.txt)
 #define W4_TRANS(P, PART)                                                                                      \
@@ -390,16 +418,19 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
     W4_LOADB(b1, s_ < S ? ubase + (unsigned)(2 * s_ + 1) * (W4_UKG * 4u) : W4_PAST)                            \
     W4_TRANS(P, 0)                                                                                             \
     W4_CLK() /* 1: loads issued (+ transform, first third of the waves) */                                     \
-    W4_MUL(P, 0, b0, W4_DMA1(P, 0, dst_), W4_DMA1(P, 1, dst_), )                                               \
+    W4_MUL(P, 0, b0, , , )                                                                                     \
     W4_CLK() /* 2: g = 0 multiplies and the pieces of stage s + 2 issued */                                    \
-    w4_vm_landed3<2>(b1);                                                                                      \
+    w4_vm_landed3<0>(b1);                                                                                      \
     W4_CLK() /* 3: filter k-group 2s+1 landed */                                                               \
     W4_TRANS(P, 1)                                                                                             \
-    W4_MUL(P, 1, b1, W4_LOADB1(b0, 0, bn_), W4_LOADB1(b0, 1, bn_), W4_LOADB1(b0, 2, bn_))                      \
+    W4_MUL(P, 1, b1, W4_HLOAD(0, dst_) W4_HLOAD(1, dst_), W4_LOADB1(b0, 0, bn_) W4_LOADB1(b0, 1, bn_),         \
+           W4_LOADB1(b0, 2, bn_))                                                                              \
     W4_TRANS(P, 2)                                                                                             \
     W4_CLK() /* 4: g = 1 multiplies and k-group 2s+2 issued (+ transforms) */                                  \
-    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");                                                \
-    W4_CLK() /* 5: own pieces of stage s + 2 landed, V writes done */                                          \
+    w4_vm_landed2<0>(hreg);          /* the pieces of stage s + 2 and k-group 2s+2 */                          \
+    W4_HSTORE(P)                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+    W4_CLK() /* 5: own pieces of stage s + 2 in LDS, V writes done */                                          \
     __builtin_amdgcn_s_barrier();                                                                              \
     asm volatile("" ::: "memory");                                                                             \
     W4_CLK() /* 6: past the barrier */                                                                         \
@@ -414,10 +445,10 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
 #undef W4_TRANS
 #undef W4_MUL
 #undef W4_MUL6
-#undef W4_DMA1
+#undef W4_HLOAD
+#undef W4_HSTORE
 #undef W4_LOADB1
 #undef W4_LOADB
-#undef W4_DMA
 
     // ---- item end: per m-tile, accumulators -> LDS -> one (tile, co) per lane -> Y = A^T M A -> epilogue
     const float sc = a.scale[ct * W4_CO + ont * 16 + li];

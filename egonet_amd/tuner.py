@@ -154,6 +154,9 @@ def choose(device, args, allow_wino=False, allow_f43=False):
             return cfg
     key = shape_key(*args)
     tab = _load()
+    only = os.environ.get('EGONET_AMD_F43_MATCH', '')        # debugging: F(4x4,3x3) only for shape keys containing this
+    if only and only not in key:
+        allow_f43 = False
     if key in tab:
         return _pick(tab[key], allow_wino, allow_f43)
     if not autotune_enabled():
