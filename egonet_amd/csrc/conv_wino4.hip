@@ -391,8 +391,8 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
   // wait in which older SLOW loads (the gathered halo, HBM) sit in front of newer FAST ones (the filter, L2) had
   // to become vmcnt(0) to make it exact again, with LDS-DMA pieces and with plain register loads alike.  So the
   // stage is ordered such that no wait needs a count: k-group 2s+1 is issued at the top and awaited (alone in the
-  // queue) behind the g = 0 multiplies; the halo pieces of stage s + 2 and k-group 2s+2 are issued behind the
-  // MFMA groups of g = 1 and awaited together at the end of the stage.
+  // queue) behind the g = 0 multiplies; k-group 2s+2 is issued right there, the halo pieces of stage s + 2 behind
+  // the first MFMA groups of g = 1, and all of them are awaited together at the end of the stage.
   // The halo goes through registers (buffer_load_dwordx4 -> ds_write_b128): 2 pieces per wave and stage.
   // Straight-line code: past the last stage the loads are still issued, beyond the buffers' ends (zeros).  The
   // registers are written asynchronously behind the compiler's back: the destination of a load must reach its
@@ -422,9 +422,9 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
     W4_CLK() /* 2: g = 0 multiplies and the pieces of stage s + 2 issued */                                    \
     w4_vm_landed3<0>(b1);                                                                                      \
     W4_CLK() /* 3: filter k-group 2s+1 landed */                                                               \
+    W4_LOADB(b0, bn_)       /* (its registers are free: g = 0 is issued) a whole half stage of flight */       \
     W4_TRANS(P, 1)                                                                                             \
-    W4_MUL(P, 1, b1, W4_HLOAD(0, dst_) W4_HLOAD(1, dst_), W4_LOADB1(b0, 0, bn_) W4_LOADB1(b0, 1, bn_),         \
-           W4_LOADB1(b0, 2, bn_))                                                                              \
+    W4_MUL(P, 1, b1, W4_HLOAD(0, dst_), W4_HLOAD(1, dst_), )                                                   \
     W4_TRANS(P, 2)                                                                                             \
     W4_CLK() /* 4: g = 1 multiplies and k-group 2s+2 issued (+ transforms) */                                  \
     w4_vm_landed2<0>(hreg);          /* the pieces of stage s + 2 and k-group 2s+2 */                          \
