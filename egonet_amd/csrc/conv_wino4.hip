@@ -228,17 +228,23 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
 
   // ---- halo DMA: this wave's pieces wave and wave + 12; slot e -> (pixel = e >> 1, channel quad e & 1)
   int hyx[2];
-  unsigned hrel[2];
+  unsigned hrel[2], hws[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
+    // LOAD order pixel-major, the two channel quads of a pixel in neighbouring lanes (32 contiguous bytes, 32
+    // cache lines per instruction instead of 64); the lane stores its 16 bytes to the pixel's slot of the
+    // bank-conflict-free order above
     const int e = (wave + W4_NW * k) * 64 + lane;
-    const int hq = e / W4_QUAD, r = e - hq * W4_QUAD;
-    const int pl = r / W4_PLANE, rr = r - pl * W4_PLANE;
-    const int hy = rr / W4_XD, hx = 4 * (rr - hy * W4_XD) + pl;
-    const bool ok = e < W4_HSLOT && hx < W4_RW;
+    const int px = e >> 1, hq = e & 1;
+    const int hy = px / W4_RW, hx = px - hy * W4_RW;
+    const bool ok = px < W4_RH * W4_RW;
     hyx[k] = ok ? ((hy << 16) | hx) : -1;
     hrel[k] = ok ? (unsigned)(((hy * a.W + hx) * C + 4 * hq) * 4) : 0u;
+    // (lanes past the last pixel park their zeros in the unused tail of the buffer)
+    const int slot = ok ? hq * W4_QUAD + (hx & 3) * W4_PLANE + hy * W4_XD + (hx >> 2) : W4_HSLOT + lane;
+    hws[k] = lds0 + (unsigned)(W4_H0 + slot * 16);
   }
+  static_assert(W4_HSLOT + 64 <= W4_HBYTES / 16, "parking slots inside the halo buffer");
   // ---- transform share of this wave: lane (tile li of m-tile tw >> 1, channel 4 (tw & 1) + kq)
   unsigned hb0, vw0;
   {
@@ -248,7 +254,6 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
     vw0 = lds0 + (unsigned)(W4_V0 + (mt * 2 + g) * 256 + lane * 4);
     if constexpr ((ABL & 32) != 0) hb0 = lds0 + (unsigned)(W4_H0 + lane * 4);     // conflict-free reads (wrong data)
   }
-  const unsigned hw0 = lds0 + (unsigned)(W4_H0 + wave * 1024 + lane * 16);     // this lane's slot of piece `wave`
   // ---- multiply: A operands V[3 wave + pl][mt][g][lane], filter block of this wave
   const float* va0 = smf + (W4_V0 / 4) + (3 * wave) * 256 + lane;
   const unsigned uvo = (unsigned)lane * 16u;
@@ -311,8 +316,8 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
   else hreg[K] = f32x4{1.f, 2.f, 3.f, (float)lane};
 #define W4_HSTORE(P)                                                                                           \
   {                                                                                                            \
-    w4_xwr<(P)*W4_HBYTES>(hw0, hreg[0]);                                                                       \
-    w4_xwr<(P)*W4_HBYTES + W4_NW * 1024>(hw0, hreg[1]);                                                        \
+    w4_xwr<(P)*W4_HBYTES>(hws[0], hreg[0]);                                                                    \
+    w4_xwr<(P)*W4_HBYTES>(hws[1], hreg[1]);                                                                    \
   }
     // filter k-group h = 2 stage + g of this wave: 9 dwords per lane, raw ISA -- the compiler's own vmcnt
     // bookkeeping does not see the LDS-DMA pieces and would wait for them with every filter wait
