@@ -444,7 +444,12 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
       W4_STAGE(0, s)
       W4_STAGE(1, s + 1)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the loads past the end
+    // the loads past the end: tied to the wait -- for the compiler their registers are dead at the loop exit, and it
+    // may move arithmetic of the item end into them while the loads are still in flight (seen with another form of
+    // the item end, caught by tools/check_wino4_isa.py)
+    w4_vm_landed3<0>(b0);
+    w4_vm_landed3<0>(b1);
+    w4_vm_landed2<0>(hreg);
     W4_CLK()      /* K loop done */
 #undef W4_STAGE
 #undef W4_TRANS

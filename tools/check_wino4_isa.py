@@ -53,7 +53,8 @@ def check(path):
     m = re.search(r'^(_Z\d+conv_wino4_kernelILi0E\w*):', text, re.M)
     assert m, 'kernel symbol not found'
     body = text[m.end():text.index('s_endpgm', m.end())]
-    queue = []          # outstanding vector-memory operations, oldest first: destination VGPR or None
+    queue = []          # outstanding vector-memory operations, oldest first: destination VGPRs or None
+    lds = []            # outstanding LDS / scalar-memory operations (lgkmcnt), oldest first
     problems, nload, nwait = [], 0, 0
     for ln in body.split('\n'):
         t = ln.split(';')[0].strip()
@@ -78,8 +79,21 @@ def check(path):
                 keep = int(mm.group(1))
                 while len(queue) > keep:
                     queue.pop(0)
+            mm = re.search(r'lgkmcnt\((\d+)\)', rest)
+            if mm:                                  # LDS operations complete in order
+                keep = int(mm.group(1))
+                while len(lds) > keep:
+                    lds.pop(0)
             continue
-        hit = regs_of(rest) & inflight(queue)
+        if op.startswith('ds_read') or op.startswith('ds_write') or op.startswith('s_load') or op.startswith('s_buffer_load'):
+            dst = frozenset(regs_of(rest.split(',', 1)[0])) if op.startswith('ds_read') else None
+            used = regs_of(rest.split(',', 1)[1]) if op.startswith('ds_read') else regs_of(rest)
+            hit = used & (inflight(queue) | inflight(lds))
+            if hit:
+                problems.append('%s  <- uses in-flight v%s' % (t, sorted(hit)))
+            lds.append(dst)
+            continue
+        hit = regs_of(rest) & (inflight(queue) | inflight(lds))
         if hit:
             problems.append('%s  <- touches in-flight v%s' % (t, sorted(hit)))
     scratch = re.search(r'\.private_segment_fixed_size:\s*(\d+)', text)
