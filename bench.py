@@ -162,8 +162,14 @@ def measured_traffic(symbol):
         try:
             with open(path) as f:
                 t = json.load(f)
-            return t['kernels'][symbol]['hbm_bytes_per_launch'], os.path.relpath(path, ROOT)
-        except (OSError, KeyError, ValueError):
+            ks = t['kernels']
+            if symbol.startswith('gemm_kernel<'):
+                # csrc/gemm.hip instantiations as rocprofv3 prints them: <A K-contiguous, B K-contiguous, ...>
+                tag = {'NT': 'gemm_kernel<true, true,', 'NN': 'gemm_kernel<true, false,',
+                       'TN': 'gemm_kernel<false, false,'}[symbol[12:14]]
+                symbol = next(k for k in ks if tag in k)
+            return ks[symbol]['hbm_bytes_per_launch'], os.path.relpath(path, ROOT)
+        except (OSError, KeyError, ValueError, StopIteration):
             continue
     return None, None
 
