@@ -8,8 +8,9 @@
 // measured (profiles/r3_mfma_tax.txt): beside fp32 MFMAs an LDS read, an LDS-DMA piece or a global load costs
 // nothing, every VALU instruction costs 3-6 cycles of matrix-pipe time.  So:
 //   * the input transform V = B^T d B runs ONCE per (tile, channel) -- 144 VALU per 64 (tile, channel) pairs,
-//     written to LDS as MFMA A operands -- by ONE wave per SIMD and stage, in rotation (1.33 VALU per MFMA
-//     at a 48-channel co-tile), while the other waves multiply;
+//     written to LDS as MFMA A operands (1.33 VALU per MFMA at a 48-channel co-tile) -- in thirds (frequency rows
+//     {0,5} / {1,2} / {3,4}: 48 VALU each), every wave one third per stage, each third at a different point of the
+//     stage so that two of a SIMD's three waves always have MFMAs to issue;
 //   * the multiplying waves read A from LDS (free) and B -- the transformed filter -- straight from global
 //     memory into registers, each element by exactly one wave of the block (free, and the LDS holds no
 //     filter: 8-channel stages, one barrier per 36 MFMAs of a wave);
@@ -18,9 +19,10 @@
 //
 // Block = 16 x 32 output pixels of one image = 4 x 8 tiles of 4 x 4 pixels = 2 m-tiles (tile rows {0,1} / {2,3})
 // x 48 output channels; K stages of 8 channels (two k-groups of 4).  LDS (120 KB): two halo buffers
-// [18 x 34 pixels][8 ch] filled by LDS-DMA two stages ahead, two V buffers [36 points][m-tile][k-group][64] floats.
-// Stage s: every wave issues its 2 DMA pieces of stage s + 2 and its 9 filter loads of the next k-group; the 4
-// transforming waves turn halo s + 1 into V s + 1; all waves multiply V s; one barrier.
+// [18 x 34 pixels][8 ch] (through registers: buffer_load_dwordx4 -> ds_write_b128, two stages ahead), two V buffers
+// [36 points][m-tile][k-group][64] floats.  Stage s: every wave loads its 2 halo pieces of stage s + 2 and its
+// 2 x 3 filter dwordx4 of the next k-groups, turns its third of halo s + 1 into V s + 1 and multiplies V s; one
+// barrier.  Every vector-memory wait is vmcnt(0) -- see the note in front of W4_STAGE.
 // Item end: the accumulators go through LDS once per m-tile ([point][co sub-tile][lane] float4, 108 KB) so
 // that every lane gets all 36 points of ONE (tile, co): Y = A^T M A (100 VALU), scale / shift / residual / ReLU,
 // 16 stores of 64 B segments.
@@ -60,12 +62,6 @@ constexpr int W4_UKG = W4_NW * 3 * 64 * 4;            // filter floats of one (c
 constexpr unsigned W4_PAST = 0x80000000u;             // scalar byte offset past every buffer (tensors stay below 2 GB)
 }  // namespace
 
-__device__ __forceinline__ void w4_dma16(u32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :
-               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-               : "m0");
-}
 // one LDS dword at a VGPR byte address + immediate (see conv_wgrad_wino.hip: the compiler's ds_read2 pairing
 // costs a v_add per pair); the values are tied to w4_landed's s_waitcnt before use
 template <int OFF>
