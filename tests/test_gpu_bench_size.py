@@ -132,3 +132,23 @@ def test_w48_training_step_at_bench_batch_32_vs_oracle():
     np.testing.assert_allclose(tr.last_coords.cpu().numpy(), want_coords.numpy(), rtol=0, atol=2e-4)
     np.testing.assert_allclose(tr.last_maps.cpu().numpy(), want_maps.numpy(), rtol=0,
                                atol=1e-3 * float(want_maps.abs().max()))
+
+
+def test_f43_network_equals_f23_network_beside_other_streams(monkeypatch):
+    """The whole 64-crop forward with conv_wino4_kernel (F(4x4,3x3)) on every layer the shipped table gives it, on the
+    engine's launch LANES (kernels of other streams run beside it), against the same engine with F(4x4,3x3) kept out.
+    Guards the finding of DESIGN 3.1e: with hand-counted s_waitcnt vmcnt(N) the kernel was exact alone and off by up
+    to 10 here; with vmcnt(0) waits the difference is F(4x4,3x3)'s rounding (2.3e-5 on maps spanning +-18)."""
+    from tools.f43_bisect import run
+    monkeypatch.delenv('EGONET_AMD_LANES', raising=False)
+    x = synth.synth_crops(64, 3, 256, 256, seed=100).cuda()
+    base, n0 = run(x, {'EGONET_AMD_F43': '0'})
+    assert n0 == 0
+    worst = 0.0
+    for _ in range(3):
+        got, n = run(x, {})
+        assert n >= 100, n                       # the 64 x 64 and 32 x 32 maps' 3x3 s1 layers
+        worst = max(worst, float((got - base).abs().max()))
+    for k in ('EGONET_AMD_F43', 'EGONET_AMD_F43_MATCH'):
+        os.environ.pop(k, None)
+    assert worst < 2e-4, worst
