@@ -26,6 +26,8 @@ size_t egn_conv_stem_lds_bytes();
 int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, hipStream_t stream);          // conv_wino4.hip
 bool egn_conv_wino4_applies(const ConvArgs& a);
 size_t egn_conv_wino4_lds_bytes();
+int egn_conv_launch_fc(const ConvArgs& a, hipStream_t stream);                          // conv_fc.hip
+bool egn_conv_fc_applies(const ConvArgs& a);
 size_t egn_conv_wino_lds_bytes(int variant, int cout);
 int egn_conv_wino_stats_rows(const ConvArgs& a, int variant);
 
@@ -111,6 +113,7 @@ static const ConvConfig kConfigs[] = {
     {76, 12, 1, 1, 3, 0, 7, 7},    // ... only DMA + filter loads + barriers
     {77, 12, 1, 1, 3, 0, 32, 7},   // ... halo reads without bank conflicts
     {78, 12, 1, 1, 3, 0, 64, 7},   // 70 with s_memtime stamps (tools/wino4_clk.py; `res` = the stamp buffer)
+    {79, 4, 1, 1, 1, 0, 0, 8},     // 1x1 conv on 1 x 1 maps (the lifter's Linear layers): one 16 x 16 tile per block, K split over the waves (conv_fc.hip)
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -144,6 +147,7 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 6) { snprintf(buf, len, "conv_stem_kernel(ConvArgs)"); return 0; }
   if (c.dma == 7) { snprintf(buf, len, "void conv_wino4_kernel<%d>(ConvArgs)", c.bi); return 0; }
+  if (c.dma == 8) { snprintf(buf, len, "conv_fc_kernel(ConvArgs)"); return 0; }
   if (c.dma == 5 && (c.bi & 15) == 10) { snprintf(buf, len, "void conv_wino43_kernel<0>(ConvArgs)"); return 0; }
   if (c.dma == 5 && ((c.bi & 15) == 11 || (c.bi & 15) == 12)) {
     snprintf(buf, len, "void conv_wino9_kernel<%s, 4, 3, 0, 2>(ConvArgs)", (c.bi & 15) == 11 ? "8, 16, 1" : "8, 8, 2");
@@ -190,6 +194,7 @@ static size_t lds_stage_bytes(const ConvArgs& a, const ConvConfig& cf) {
 static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
   if (cf.dma == 6) return egn_conv_stem_lds_bytes();
   if (cf.dma == 7) return egn_conv_wino4_lds_bytes();
+  if (cf.dma == 8) return 0;
   if (cf.dma == 5) return egn_conv_wino_lds_bytes(cf.bi, a.Cout);
   if (cf.dma == 4 && cf.bi == 2) return (size_t)(3 * 336 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // chunk ring + filter
   if (cf.dma == 4) return (size_t)(2 * 3 * 192 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // 2 halo buffers + filter
@@ -207,6 +212,15 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
     a.npix = 33 * 33; a.npixp = (a.npix + 15) & ~15; a.tps = 9;
     a.tiles_x = (a.Wo + 15) / 16;
     a.tiles_y = (a.Ho + 15) / 16;
+    if (cost_out) *cost_out = 0.0;
+    return true;
+  }
+  if (cf.dma == 8) {
+    if (!egn_conv_fc_applies(a)) return false;
+    a.TH = 1; a.TW = 1; a.TNB = 16; a.HH = 1; a.HW = 1;
+    a.npix = 16; a.npixp = 16; a.tps = 1;
+    a.tiles_x = 1;
+    a.tiles_y = 1;
     if (cost_out) *cost_out = 0.0;
     return true;
   }
@@ -373,6 +387,7 @@ int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {
   const size_t lds = lds_bytes_for(a, cf);
   if (cf.dma == 6) return egn_conv_launch_stem(a, lds, stream);
   if (cf.dma == 7) return egn_conv_launch_wino4(a, lds, cf.bi, stream);
+  if (cf.dma == 8) return egn_conv_launch_fc(a, stream);
   if (cf.dma == 5) return egn_conv_launch_wino(a, lds, cf.bi, stream);
   if (cf.dma == 4) return egn_conv_launch_c48(a, lds, cf.bi == 2 ? -1 : cf.bi == 1 ? 0 : cf.wm, stream);
   if (cf.dma == 3) return EGN_E_BADARG;

@@ -87,7 +87,7 @@ int egn_conv_config_name(int cfg, char* buf, int len);
  *      inf packed [Cout/48][Cin/4][f = 6i+j][ci % 4][48] (host: engine.pack_wino43_weight)
  *   3  fused Winograd F(4x4,3x3), conv_wino4_kernel (3x3, stride 1, pad 1, Cin % 8 == 0,
  *      Cout % 48 == 0, maps of whole 16 x 32 pixel regions): the same U packed for
- *      register feeding, [Cout/48][Cin/8][k-group 2][wave 12][9][64] floats
+ *      register feeding, [Cout/48][Cin/8][k-group 2][wave 12][3][64 lanes][4] floats (9 of 12 used)
  *      (egn_wino4_weight_floats; host: engine.pack_wino4_weight)
  *  -1  not selectable (timing-ablation builds, invalid id) */
 int egn_conv_config_kind(int cfg);

@@ -173,6 +173,30 @@ def test_conv_winograd_kernels(n, h, w, cin, cout, res, act):
     assert L.egn_wino_weight_floats(80, 48, 0) == 0 and L.egn_wino_weight_floats(48, 80, 1) == 0
 
 
+@pytest.mark.parametrize('n,cin,cout,res,act,nchw', [
+    (64, 1024, 1024, True, 1, False),    # the lifter's residual-block layers at the bench batch
+    (64, 1024, 1024, False, 1, False),
+    (64, 1024, 96, False, 0, True),      # its last layer (hands over [N, C])
+    (5, 64, 48, True, 3, False),         # ragged batch, short K, LeakyReLU
+    (130, 272, 32, False, 1, False),     # batch over 128, K not a multiple of four chunks
+])
+def test_conv_fc_kernel(n, cin, cout, res, act, nchw):
+    """Config 79, csrc/conv_fc.hip: 1x1 convolution on 1 x 1 maps (Linear + BatchNorm1d + activation + residual of
+    libs/model/FCmodel.py:29-52 at inference batch sizes): one 16 x 16 output tile per block, K split over the four
+    waves.  Same oracle and tolerance as the general kernels; the planner refuses everything else."""
+    import ctypes as C
+    from egonet_amd import _lib
+    L = _lib.lib()
+    out = (C.c_int * 12)()
+    assert L.egn_conv_config_kind(79) == 0
+    assert L.egn_conv_plan_query(n, 1, 1, cin, cin, cout, cout, 1, 1, 1, 0, int(nchw), 79, out) == 0
+    err = _conv_case(n, 1, 1, cin, cout, 1, 1, 0, act=act, use_res=res, nchw=nchw, cfg=79, seed=n + cin)
+    assert err < 2e-4, err
+    assert L.egn_conv_plan_query(4, 2, 2, 64, 64, 48, 48, 1, 1, 1, 0, 0, 79, out) != 0      # a real map
+    assert L.egn_conv_plan_query(4, 1, 1, 66, 68, 48, 48, 1, 1, 1, 0, 0, 79, out) != 0      # Cin % 16
+    assert L.egn_conv_plan_query(4, 1, 1, 64, 64, 33, 33, 1, 1, 1, 0, 0, 79, out) != 0      # Cout % 16
+
+
 @pytest.mark.parametrize('n,h,w,cin,cout,res,act', [
     (2, 16, 32, 16, 48, True, 1),      # one region per image, the shortest K loop (2 stages)
     (3, 32, 64, 48, 96, False, 0),     # 4 regions x 2 co-tiles, no activation, no residual
