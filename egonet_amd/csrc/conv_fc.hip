@@ -1,6 +1,8 @@
-// conv_fc.hip -- 1x1 convolution on 1 x 1 maps = the fully connected layers of the lifter at inference batch
-// sizes (reference libs/model/FCmodel.py:29-52, 92-105: Linear + BatchNorm1d + ReLU (+ residual) on [N, C]; the
-// engine records them as 1x1 convs on [N, 1, 1, C]).  Config id 79.
+// conv_fc.hip -- 1x1 stride-1 convolution as a plain row GEMM, for FEW rows: the fully connected layers of the
+// lifter at inference batch sizes (reference libs/model/FCmodel.py:29-52, 92-105: Linear + BatchNorm1d + ReLU
+// (+ residual) on [N, C]; the engine records them as 1x1 convs on [N, 1, 1, C]) and the 1x1 convs of HRNet's fuse
+// layers on the coarse maps (libs/model/heatmapModel/hrnet.py:236-262: 384 -> 48 / 96 / 192 on 8 x 8 maps ...).
+// Rows = N * H * W pixels of the NHWC map.  Config id 79; the tuner takes it where it measures fastest.
 //
 // Why a kernel of its own: with N = 64 rows the general kernels have 8-16 output tiles for 256 CUs and walk
 // K = 1024 serially -- 50 us per 0.13 GFLOP layer, five of them on the tail of every bench step (the lifter runs
@@ -20,9 +22,10 @@ __global__ __launch_bounds__(256, 2) void conv_fc_kernel(ConvArgs a) {
   const int ntile = a.Cout >> 4;
   const int n0 = (blockIdx.x % ntile) * 16, m0 = (blockIdx.x / ntile) * 16;
   const int nchunk = a.nchunk;
+  const int rows = a.N * a.H * a.W;
 
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.x), 0, (unsigned)((size_t)a.N * a.cs_in * 4), 0x00020000);
+      const_cast<float*>(a.x), 0, (unsigned)((size_t)rows * a.cs_in * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.w), 0, (unsigned)((size_t)nchunk * EGN_CKQ * a.CoutP * 16), 0x00020000);
   // lane (row m0 + li, k lanes 4 kq .. 4 kq + 3 of a chunk) / lane (channel n0 + li, the same k lanes)
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void conv_fc_kernel(ConvArgs a) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = m0 + 4 * kq + r;
-    if (row >= a.N) continue;
+    if (row >= rows) continue;
     const size_t o = (size_t)row * pitch + n0 + li;
     float v = __builtin_fmaf(acc[r], sc, sh);
     const float rs = a.res ? a.res[o] : 0.f;
@@ -73,14 +76,15 @@ __global__ __launch_bounds__(256, 2) void conv_fc_kernel(ConvArgs a) {
 }
 
 bool egn_conv_fc_applies(const ConvArgs& a) {
-  return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == 1 && a.W == 1 && a.Cin % EGN_CK == 0 &&
-         a.cs_in >= a.Cin && a.cs_in % 4 == 0 && a.Cout % 16 == 0 && a.CoutP == a.Cout &&
-         (a.out_nchw || a.cs_out >= a.Cout) && a.stats == nullptr;
+  const bool one = a.H == 1 && a.W == 1;
+  return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.Cin % EGN_CK == 0 && a.cs_in >= a.Cin &&
+         a.cs_in % 4 == 0 && a.Cout % 16 == 0 && a.CoutP == a.Cout && (a.out_nchw ? one : a.cs_out >= a.Cout) &&
+         a.stats == nullptr && (double)a.N * a.H * a.W * a.cs_in * 4.0 < 2147483648.0;
 }
 
 int egn_conv_launch_fc(const ConvArgs& a, hipStream_t stream) {
   if (!egn_conv_fc_applies(a)) return EGN_E_BADARG;
-  const int grid = (a.Cout / 16) * ((a.N + 15) / 16);
+  const int grid = (a.Cout / 16) * ((a.N * a.H * a.W + 15) / 16);
   hipLaunchKernelGGL(conv_fc_kernel, dim3(grid), dim3(256), 0, stream, a);
   return (int)hipGetLastError();
 }

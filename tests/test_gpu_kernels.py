@@ -192,7 +192,11 @@ def test_conv_fc_kernel(n, cin, cout, res, act, nchw):
     assert L.egn_conv_plan_query(n, 1, 1, cin, cin, cout, cout, 1, 1, 1, 0, int(nchw), 79, out) == 0
     err = _conv_case(n, 1, 1, cin, cout, 1, 1, 0, act=act, use_res=res, nchw=nchw, cfg=79, seed=n + cin)
     assert err < 2e-4, err
-    assert L.egn_conv_plan_query(4, 2, 2, 64, 64, 48, 48, 1, 1, 1, 0, 0, 79, out) != 0      # a real map
+    # ... and the 1x1 convs of the fuse layers on the coarse maps: rows = N * H * W
+    err = _conv_case(3, 8, 8, 384, 96, 1, 1, 0, act=0, use_res=False, cfg=79, seed=5)
+    assert err < 2e-4, err
+    assert L.egn_conv_plan_query(4, 2, 2, 64, 64, 48, 48, 1, 1, 1, 0, 1, 79, out) != 0      # NCHW output of a real map
+    assert L.egn_conv_plan_query(4, 2, 2, 64, 64, 48, 48, 3, 3, 1, 1, 0, 79, out) != 0      # not 1x1
     assert L.egn_conv_plan_query(4, 1, 1, 66, 68, 48, 48, 1, 1, 1, 0, 0, 79, out) != 0      # Cin % 16
     assert L.egn_conv_plan_query(4, 1, 1, 64, 64, 33, 33, 1, 1, 1, 0, 0, 79, out) != 0      # Cout % 16
 
