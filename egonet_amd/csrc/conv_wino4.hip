@@ -43,9 +43,11 @@ constexpr int W4_NW = 12, W4_NTH = 64 * W4_NW;
 constexpr int W4_CO = 48;
 // Halo of the 16 x 32 region: 18 x 34 pixels x 8 channels, in 16-byte slots (one pixel, one channel quad) ordered
 // [quad][x mod 4][y][x div 4 (pitch 10)]: the transform's lane (tile (ty, tx), channel kq) reads pixel (4 ty + i,
-// 4 tx + j) at slot 40 ty + tx + const(i, j) -- the 16 tiles of an m-tile land on 16 different slots mod 16, the
-// wave read on 64 different banks.  (Pixel-major order put them on 8 banks: the transform alone took 5 000 cycles
-// per stage, profiles/r3_wino4_ablations.txt.)  The DMA lanes gather their pixels accordingly.
+// 4 tx + j) at slot 40 ty + tx + const(i, j) -- the 16 tiles of an m-tile land on 16 different slots mod 16: at most
+// two lanes per bank under the ds_read_b32 rule (32-lane groups, bank = dword mod 32; SQ_LDS_BANK_CONFLICT agrees,
+// profiles/r3_pmc_sq_wino4.txt).  Pixel-major order put all 16 tiles of a group on ONE bank: the transform alone
+// took 5 000 cycles per stage (profiles/r3_wino4_ablations.txt).  8-byte channel-pair planes would be conflict free.
+// The loads fetch pixel-major (coalesced) and each lane stores its 16 bytes to the pixel's slot.
 constexpr int W4_RH = 18, W4_RW = 34;
 constexpr int W4_XD = 10;                             // slots per row and plane (9 used)
 constexpr int W4_PLANE = W4_RH * W4_XD;               // 180
