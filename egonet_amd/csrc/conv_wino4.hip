@@ -41,25 +41,27 @@ typedef __attribute__((address_space(3))) void* lds_ptr_w4_t;
 namespace {
 constexpr int W4_NW = 12, W4_NTH = 64 * W4_NW;
 constexpr int W4_CO = 48;
-// Halo of the 16 x 32 region: 18 x 34 pixels x 8 channels, in 16-byte slots (one pixel, one channel quad) ordered
-// [quad][x mod 4][y][x div 4 (pitch 10)]: the transform's lane (tile (ty, tx), channel kq) reads pixel (4 ty + i,
-// 4 tx + j) at slot 40 ty + tx + const(i, j) -- the 16 tiles of an m-tile land on 16 different slots mod 16: at most
-// two lanes per bank under the ds_read_b32 rule (32-lane groups, bank = dword mod 32; SQ_LDS_BANK_CONFLICT agrees,
-// profiles/r3_pmc_sq_wino4.txt).  Pixel-major order put all 16 tiles of a group on ONE bank: the transform alone
-// took 5 000 cycles per stage (profiles/r3_wino4_ablations.txt).  8-byte channel-pair planes would be conflict free.
-// The loads fetch pixel-major (coalesced) and each lane stores its 16 bytes to the pixel's slot.
+// Halo of the 16 x 32 region: 18 x 34 pixels x 8 channels, in 8-byte slots (one pixel, one channel PAIR) ordered
+// [pair 0..3][x mod 4][y][x div 4 (pitch 10)]: the transform's lane (tile (ty, tx), channel kq of k-group g) reads
+// pixel (4 ty + i, 4 tx + j) at slot (2 g + kq / 2) * 720 + 40 ty + tx + const(i, j), dword kq & 1.  ds_read_b32 is
+// banked per 32-lane group on dword mod 32 (MI355X_MICROARCH.md): a group = 16 tiles x 2 channels of ONE pair plane,
+// dword = 2 (40 ty + tx) + kq + const -> 32 different banks.  History (profiles/r3_wino4_ablations.txt,
+// r3_pmc_sq_wino4.txt): pixel-major order put all 16 tiles of a group on one bank (the transform alone took 5 000
+// cycles per stage); 16-byte quad planes left a 2-way conflict (SQ_LDS_BANK_CONFLICT 3.9 M cycles per launch).
+// The loads fetch pixel-major (32 contiguous bytes per pixel) and each lane stores its two channel pairs.
 constexpr int W4_RH = 18, W4_RW = 34;
 constexpr int W4_XD = 10;                             // slots per row and plane (9 used)
 constexpr int W4_PLANE = W4_RH * W4_XD;               // 180
-constexpr int W4_QUAD = 4 * W4_PLANE;                 // 720 slots per channel quad
-constexpr int W4_HSLOT = 2 * W4_QUAD;                 // 1440 16-byte DMA slots
+constexpr int W4_PAIR = 4 * W4_PLANE;                 // 720 8-byte slots per channel pair
+constexpr int W4_HSLOT = 4 * W4_PAIR;                 // 2880 slots = 23 040 B of the 24 KB buffer
 constexpr int W4_HBYTES = 2 * W4_NW * 1024;           // every wave issues 2 whole pieces: 24 KB
 constexpr int W4_VBYTES = 36 * 1024;                  // [pt][mt][g][lane] floats
 constexpr int W4_V0 = 0, W4_V1 = W4_VBYTES, W4_H0 = 2 * W4_VBYTES, W4_H1 = W4_H0 + W4_HBYTES;
 constexpr int W4_LDS = W4_H1 + W4_HBYTES;             // 122 880 B
 constexpr int W4_XBYTES = 36 * 3 * 1024;              // exchange [pt][nt][lane] float4: 110 592 B
 static_assert(W4_XBYTES <= W4_LDS, "the exchange reuses the stage buffers");
-static_assert(W4_HSLOT <= 2 * W4_NW * 64, "two DMA pieces per wave cover the halo");
+static_assert(W4_HSLOT * 8 + 1024 <= W4_HBYTES, "the halo and the parking slots of the idle load lanes fit the buffer");
+static_assert(2 * W4_RH * W4_RW <= 2 * W4_NW * 64, "two load pieces per wave cover the halo");
 constexpr int W4_UKG = W4_NW * 3 * 64 * 4;            // filter floats of one (co-tile, stage, k-group): 9216 (9 of 12 used)
 constexpr unsigned W4_PAST = 0x80000000u;             // scalar byte offset past every buffer (tensors stay below 2 GB)
 }  // namespace
@@ -101,6 +103,12 @@ template <int OFF>
 __device__ __forceinline__ void w4_xwr(unsigned addr, f32x4 v) {
   asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
 }
+template <int OFF>
+__device__ __forceinline__ void w4_xwr2(unsigned addr, float a, float b) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {a, b};
+  asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
 template <int PT>
 __device__ __forceinline__ float w4_xrd(unsigned xr0, unsigned xr1) {
   if constexpr (PT < 18) return w4_lds<PT * 3072>(xr0);
@@ -133,9 +141,9 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4]) {
 // hb0: per-lane byte base in halo buffer 0 (the immediates reach both buffers); vw0: base in THIS parity's V buffer.
 template <int P, int PART>
 __device__ __forceinline__ void w4_transform(unsigned hb0, unsigned vw0) {
-  static_assert(W4_H1 - W4_H0 + (3 * W4_PLANE + 5 * W4_XD + 1) * 16 < 65536, "halo immediates");
+  static_assert(W4_H1 - W4_H0 + (3 * W4_PLANE + 5 * W4_XD + 1) * 8 < 65536, "halo immediates");
   constexpr int HO = P ? W4_H1 - W4_H0 : 0;
-#define W4_D(I, J) w4_lds<HO + (((J) & 3) * W4_PLANE + (I)*W4_XD + ((J) >> 2)) * 16>(hb0)
+#define W4_D(I, J) w4_lds<HO + (((J) & 3) * W4_PLANE + (I)*W4_XD + ((J) >> 2)) * 8>(hb0)
 #define W4_WR(PT, VAL) asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(vw0), "v"(VAL), "n"((PT)*1024) : "memory")
 #define W4_ROW(FI, O)                                                                                   \
   W4_WR((FI)*6 + 0, (O)[0]); W4_WR((FI)*6 + 1, (O)[1]); W4_WR((FI)*6 + 2, (O)[2]);                      \
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
 
   // ---- halo DMA: this wave's pieces wave and wave + 12; slot e -> (pixel = e >> 1, channel quad e & 1)
   int hyx[2];
-  unsigned hrel[2], hws[2];
+  unsigned hrel[2], hws[2], hws2[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     // LOAD order pixel-major, the two channel quads of a pixel in neighbouring lanes (32 contiguous bytes, 32
@@ -239,16 +247,17 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
     hyx[k] = ok ? ((hy << 16) | hx) : -1;
     hrel[k] = ok ? (unsigned)(((hy * a.W + hx) * C + 4 * hq) * 4) : 0u;
     // (lanes past the last pixel park their zeros in the unused tail of the buffer)
-    const int slot = ok ? hq * W4_QUAD + (hx & 3) * W4_PLANE + hy * W4_XD + (hx >> 2) : W4_HSLOT + lane;
-    hws[k] = lds0 + (unsigned)(W4_H0 + slot * 16);
+    // channels 4 hq, 4 hq + 1 -> pair plane 2 hq, channels 4 hq + 2, + 3 -> pair plane 2 hq + 1
+    const int slot = 2 * hq * W4_PAIR + (hx & 3) * W4_PLANE + hy * W4_XD + (hx >> 2);
+    hws[k] = lds0 + (unsigned)(W4_H0 + (ok ? slot * 8 : W4_HSLOT * 8 + lane * 8));
+    hws2[k] = lds0 + (unsigned)(W4_H0 + (ok ? (slot + W4_PAIR) * 8 : W4_HSLOT * 8 + 512 + lane * 8));
   }
-  static_assert(W4_HSLOT + 64 <= W4_HBYTES / 16, "parking slots inside the halo buffer");
   // ---- transform share of this wave: lane (tile li of m-tile tw >> 1, channel 4 (tw & 1) + kq)
   unsigned hb0, vw0;
   {
     const int mt = tw >> 1, g = tw & 1;
     const int ty = 2 * mt + (li >> 3), tx = li & 7;
-    hb0 = lds0 + (unsigned)(W4_H0 + (g * W4_QUAD + 4 * W4_XD * ty + tx) * 16 + kq * 4);
+    hb0 = lds0 + (unsigned)(W4_H0 + ((2 * g + (kq >> 1)) * W4_PAIR + 4 * W4_XD * ty + tx) * 8 + (kq & 1) * 4);
     vw0 = lds0 + (unsigned)(W4_V0 + (mt * 2 + g) * 256 + lane * 4);
     if constexpr ((ABL & 32) != 0) hb0 = lds0 + (unsigned)(W4_H0 + lane * 4);     // conflict-free reads (wrong data)
   }
@@ -314,8 +323,10 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
   else hreg[K] = f32x4{1.f, 2.f, 3.f, (float)lane};
 #define W4_HSTORE(P)                                                                                           \
   {                                                                                                            \
-    w4_xwr<(P)*W4_HBYTES>(hws[0], hreg[0]);                                                                    \
-    w4_xwr<(P)*W4_HBYTES>(hws[1], hreg[1]);                                                                    \
+    w4_xwr2<(P)*W4_HBYTES>(hws[0], hreg[0][0], hreg[0][1]);                                                    \
+    w4_xwr2<(P)*W4_HBYTES>(hws2[0], hreg[0][2], hreg[0][3]);                                                   \
+    w4_xwr2<(P)*W4_HBYTES>(hws[1], hreg[1][0], hreg[1][1]);                                                    \
+    w4_xwr2<(P)*W4_HBYTES>(hws2[1], hreg[1][2], hreg[1][3]);                                                   \
   }
     // filter k-group h = 2 stage + g of this wave: 9 dwords per lane, raw ISA -- the compiler's own vmcnt
     // bookkeeping does not see the LDS-DMA pieces and would wait for them with every filter wait

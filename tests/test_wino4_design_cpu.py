@@ -90,38 +90,32 @@ def test_f43_convolution_identity_and_packed_filter_layout():
     assert float(np.abs(U[..., 2, :, 1:]).max()) == 0.0
 
 
-def test_halo_slot_order_spreads_the_transform_reads():
-    """Slot of pixel (y, x), channel quad q: q * 720 + (x % 4) * 180 + y * 10 + x // 4 (16 bytes each).  Lane (tile
-    (ty, tx) of an m-tile, channel kq) reads pixel (4 ty + i, 4 tx + j): for every (i, j) the 64 lanes of a wave hit
-    64 different dwords mod 64 (16 tiles on 16 slots mod 16), i.e. at most 2 lanes per bank under the hardware's rule
-    for ds_read_b32 (32-lane groups, bank = dword mod 32); every halo pixel has exactly one slot below 1440."""
-    def slot(q, y, x):
-        return q * 720 + (x % 4) * 180 + y * 10 + x // 4
+def test_halo_slot_order_is_bank_conflict_free_for_the_transform_reads():
+    """8-byte slot of pixel (y, x), channel pair p: p * 720 + (x % 4) * 180 + y * 10 + x // 4.  Lane (tile (ty, tx) of
+    an m-tile, channel kq of k-group g) reads dword kq & 1 of pair 2 g + kq // 2 at pixel (4 ty + i, 4 tx + j).  The
+    hardware banks ds_read_b32 per 32-lane group on dword mod 32 (MI355X_MICROARCH.md): for every (i, j) each group
+    must hit 32 different banks; every (pixel, pair) has exactly one slot below 2880."""
+    def slot(p, y, x):
+        return p * 720 + (x % 4) * 180 + y * 10 + x // 4
     seen = set()
-    for q in range(2):
+    for p in range(4):
         for y in range(18):
             for x in range(34):
-                s = slot(q, y, x)
-                assert 0 <= s < 1440 and s not in seen
+                s = slot(p, y, x)
+                assert 0 <= s < 2880 and s not in seen
                 seen.add(s)
     for mt in range(2):
         for g in range(2):
             for i in range(6):
                 for j in range(6):
-                    banks = set()
-                    for lane in range(64):
-                        li, kq = lane & 15, lane >> 4
-                        ty, tx = 2 * mt + (li >> 3), li & 7
-                        word = slot(g, 4 * ty + i, 4 * tx + j) * 4 + kq
-                        banks.add(word % 64)
-                    assert len(banks) == 64, (mt, g, i, j, len(banks))
-                    for half in (range(0, 32), range(32, 64)):         # the rule of MI355X_MICROARCH.md for ds_read_b32
-                        per = {}
+                    for half in (range(0, 32), range(32, 64)):
+                        banks = set()
                         for lane in half:
                             li, kq = lane & 15, lane >> 4
                             ty, tx = 2 * mt + (li >> 3), li & 7
-                            per.setdefault((slot(g, 4 * ty + i, 4 * tx + j) * 4 + kq) % 32, set()).add(lane)
-                        assert max(len(v) for v in per.values()) <= 2
+                            dword = slot(2 * g + kq // 2, 4 * ty + i, 4 * tx + j) * 2 + (kq & 1)
+                            banks.add(dword % 32)
+                        assert len(banks) == 32, (mt, g, i, j, len(banks))
 
 
 @pytest.mark.skipif(shutil.which(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')) is None, reason='hipcc not installed')
