@@ -71,3 +71,27 @@ def test_every_table_entry_plans_for_its_shape():
         alt = tuner._pick(ent, allow_wino=False, allow_f43=False)
         assert alt == 0 or L.egn_conv_config_kind(alt) == 0, (key, alt)
     assert n70 >= 8 and n79 >= 15, (n70, n79)
+
+
+def test_row_gemm_kernel_reads_the_standard_filter_pack():
+    """conv_fc_kernel's operand addressing restated in numpy: lane (channel n0 + li, k lanes 4 kq .. 4 kq + 3 of chunk c)
+    reads the float4 at ((c * 4 + kq) * CoutP + n0 + li) of engine.pack_conv_weight's layout; the four waves take
+    chunks c = wave, wave + 4, ... and their partial tiles are summed w0 + w1 + w2 + w3."""
+    import numpy as np
+    import torch
+    from egonet_amd import engine
+    rng = np.random.default_rng(3)
+    rows, cin, cout = 20, 80, 48
+    w = rng.standard_normal((cout, cin, 1, 1)).astype(np.float32)
+    x = rng.standard_normal((rows, cin)).astype(np.float32)
+    wp = engine.pack_conv_weight(torch.from_numpy(w)).numpy().reshape(cin // 16, 1, 4, cout, 4)   # chunk, tap, quad, co, e
+    y = np.zeros((rows, cout), np.float64)
+    for wave in range(4):
+        part = np.zeros((rows, cout), np.float64)
+        for c in range(wave, cin // 16, 4):
+            for kq in range(4):
+                for e in range(4):
+                    k = 16 * c + 4 * kq + e
+                    part += np.outer(x[:, k], wp[c, 0, kq, :, e])
+        y += part
+    np.testing.assert_allclose(y, x.astype(np.float64) @ w[:, :, 0, 0].astype(np.float64).T, rtol=0, atol=1e-5)
