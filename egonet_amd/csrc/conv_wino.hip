@@ -1170,9 +1170,10 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_wino9_kernel(ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0x0106);                \
   }
       // ---- this wave's two rows of V = B^T d B: ta = X - Y, tb = Z + sigma W, then the column transform.
-      // Plain arithmetic (the file is built with -fno-slp-vectorize: v_pk_add_f32 costs more than two adds
-      // beside MFMAs): the scheduler sinks each V row to its first use, so the MFMAs of row 0 start while row
-      // 1 is still being formed -- asm wrappers pinned all 64 instructions in front of the first MFMA.
+      // Plain arithmetic: the scheduler sinks each V row to its first use, so the MFMAs of row 0 start while row
+      // 1 is still being formed -- asm wrappers pinned all 64 instructions in front of the first MFMA.  (The SLP
+      // pass packs 6-8 of the 80 operations of a K step into v_pk_*_f32; forcing scalar instructions measured
+      // no difference here or in conv_wino4.hip.)
       const float4* hb_ = sH + par * BUF;
       vk_t V[8];
       constexpr int TOPP = 2;                                   // DMA pieces issued at the top of a K step ...
