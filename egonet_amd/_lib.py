@@ -37,6 +37,7 @@ SIGNATURES = {
     'egn_conv_config_info': (_i, [_i, C.POINTER(_i), C.POINTER(_i)]),
     'egn_conv_config_name': (_i, [_i, C.c_char_p, _i]),
     'egn_conv_config_kind': (_i, [_i]),
+    'egn_probe_build': (_i, []),
     'egn_wino_weight_floats': (C.c_long, [_i, _i, _i]),
     'egn_wino4_weight_floats': (C.c_longlong, [_i, _i]),
     'egn_wino_pack_weight_f32': (_i, [_p, _i, _i, _i, _p, _p]),

@@ -34,13 +34,26 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
+PROBES_OUT = os.path.join(os.path.dirname(HERE), 'tools', '_build', 'libegonet_hip_probes.so')
+
+
+def build(force=False, verbose=True, probes=False):
+    """``probes``: the -DEGN_PROBES build for tools/ (timing-ablation / s_memtime-stamp builds and the kernel
+    families that were measured and retired) -> tools/_build/libegonet_hip_probes.so; select it with
+    EGONET_AMD_LIB=<that path>.  The product library never contains those kernels."""
+    out = PROBES_OUT if probes else OUT
+    if probes:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        if not force and os.path.isfile(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in
+                                                     sources() + glob.glob(os.path.join(CSRC, '*.h'))):
+            return out
+    elif not force and not needs_build():
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    tmp = OUT + '.tmp'
+    tmp = out + '.tmp'
     cmd = [hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-shared', '-fPIC',
-           '-Wno-unused-result', '-Wno-unused-value', '-o', tmp] + sources()
+           '-Wno-unused-result', '-Wno-unused-value', '-Wno-inline-asm'] + (['-DEGN_PROBES'] if probes else []) + \
+        ['-o', tmp] + sources()
     if verbose:
         print(' '.join(cmd), flush=True)
     try:
@@ -50,13 +63,12 @@ def build(force=False, verbose=True):
     except Exception:
         if os.path.exists(tmp):
             os.remove(tmp)
-        if os.path.exists(OUT):
-            os.remove(OUT)
+        if os.path.exists(out):
+            os.remove(out)
         raise
-    os.replace(tmp, OUT)
-    return OUT
+    os.replace(tmp, out)
+    return out
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
-    print(OUT)
+    print(build(force='--force' in sys.argv, probes='--probes' in sys.argv))

@@ -361,7 +361,9 @@ __global__ __launch_bounds__(64 * WAVES, 1) void conv_c48_kernel(ConvArgs a) {
   c48_body<WAVES, false>(a);
 }
 // the register-resident-filter variant (config 43)
+#ifdef EGN_PROBES   // cfg 43 (register-resident filter): measured, never selected -- probe builds only
 __global__ __launch_bounds__(256, 1) void conv_c48r_kernel(ConvArgs a) { c48_body<4, true>(a); }
+#endif
 
 
 // ---------------------------------------------------------------------------------------------
@@ -661,6 +663,7 @@ int egn_conv_launch_c48(const ConvArgs& a, size_t lds, int waves, hipStream_t st
     hipLaunchKernelGGL(conv_c48t_kernel, dim3(grid), dim3(512), lds, stream, a);
     return (int)hipGetLastError();
   }
+#ifdef EGN_PROBES
   if (waves == 0) {  // register-resident filter
     static bool raised[EGN_MAX_DEVICES];
     if (egn_first_use_on_device(raised)) {
@@ -670,5 +673,7 @@ int egn_conv_launch_c48(const ConvArgs& a, size_t lds, int waves, hipStream_t st
     hipLaunchKernelGGL(conv_c48r_kernel, dim3(grid), dim3(256), lds, stream, a);
     return (int)hipGetLastError();
   }
-  return waves == 8 ? c48_launch<8>(a, lds, grid, stream) : c48_launch<4>(a, lds, grid, stream);
+  if (waves == 4) return c48_launch<4>(a, lds, grid, stream);       // cfg 41: never selected either
+#endif
+  return waves == 8 ? c48_launch<8>(a, lds, grid, stream) : EGN_E_BADARG;
 }

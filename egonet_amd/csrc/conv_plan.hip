@@ -23,8 +23,8 @@ int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t
 int egn_conv_launch_stem(const ConvArgs& a, size_t lds, hipStream_t stream);   // conv_stem.hip
 bool egn_conv_stem_applies(const ConvArgs& a);
 size_t egn_conv_stem_lds_bytes();
-int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, hipStream_t stream);          // conv_wino4.hip
-bool egn_conv_wino4_applies(const ConvArgs& a);
+int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, int geo, hipStream_t stream);          // conv_wino4.hip
+bool egn_conv_wino4_applies(const ConvArgs& a, int geo);
 size_t egn_conv_wino4_lds_bytes();
 int egn_conv_launch_fc(const ConvArgs& a, hipStream_t stream);                          // conv_fc.hip
 bool egn_conv_fc_applies(const ConvArgs& a);
@@ -114,6 +114,8 @@ static const ConvConfig kConfigs[] = {
     {77, 12, 1, 1, 3, 0, 32, 7},   // ... halo reads without bank conflicts
     {78, 12, 1, 1, 3, 0, 64, 7},   // 70 with s_memtime stamps (tools/wino4_clk.py; `res` = the stamp buffer)
     {79, 4, 1, 1, 1, 0, 0, 8},     // 1x1 conv on 1 x 1 maps (the lifter's Linear layers): one 16 x 16 tile per block, K split over the waves (conv_fc.hip)
+    {80, 12, 1, 1, 3, 1, 0, 7},    // conv_wino4b_kernel: F(4x4,3x3) on 16 x 16 pixel regions, 16-channel stages (ai = geometry 1); filter kind 3
+    {81, 12, 1, 1, 3, 1, 64, 7},   // 80 with s_memtime stamps (tools/wino4_clk.py)
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -130,14 +132,35 @@ extern "C" int egn_conv_config_info(int cfg, int* tile_m, int* tile_n) {
 
 // 0 = direct kernels (wpack from egn_pack_conv_weight_f32), 1 = Winograd kernels (wpack from
 // egn_wino_pack_weight_f32), -1 = not selectable (timing ablations, invalid ids)
+// Families that were measured and lost (cfg 41 / 43: 4-wave and register-filter forms of conv_c48.hip; 45 / 46: the
+// 4-wave Winograd kernel; 65: the first F(4x4,3x3) kernel; 67 / 68: two 4-wave blocks per CU) exist only in probe
+// builds (-DEGN_PROBES: python -m egonet_amd.build --probes, used by tools/); the product library neither compiles
+// nor launches them, and the timing-ablation / stamp builds (WRONG RESULTS) likewise.
+static bool probe_only(const ConvConfig& c) {
+  if (c.dma == 4) return c.id == 41 || c.id == 43;
+  if (c.dma == 5) return (c.bi >> 4) != 0 || (c.bi & 15) <= 1 || (c.bi & 15) >= 10;
+  if (c.dma == 7) return c.bi != 0;
+  return false;
+}
 extern "C" int egn_conv_config_kind(int cfg) {
   if (cfg < 1 || cfg > kNumConfigs) return -1;
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 3) return -1;  // retired ids
+#ifndef EGN_PROBES
+  if (probe_only(c)) return -1;
+#endif
   if (c.dma == 7) return c.bi ? -1 : 3;   // F(4x4,3x3) filter in the register-feed layout (engine.pack_wino4_weight)
   if (c.dma != 5) return 0;
   if (c.bi >> 4) return -1;
   return (c.bi & 15) == 10 ? 2 : 1;     // 2: F(4x4,3x3) filter (engine.pack_wino43_weight)
+}
+// 1 = a probe build (ablation / stamp / retired configurations can be launched through egn_conv2d_f32(cfg))
+extern "C" int egn_probe_build(void) {
+#ifdef EGN_PROBES
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 // kernel symbol of a config as rocprofv3 prints it (lets bench.py line its
@@ -146,7 +169,7 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (cfg < 1 || cfg > kNumConfigs || !buf || len < 8) return EGN_E_BADARG;
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 6) { snprintf(buf, len, "conv_stem_kernel(ConvArgs)"); return 0; }
-  if (c.dma == 7) { snprintf(buf, len, "void conv_wino4_kernel<%d>(ConvArgs)", c.bi); return 0; }
+  if (c.dma == 7) { snprintf(buf, len, "void conv_wino4%s_kernel<%d>(ConvArgs)", c.ai ? "b" : "", c.bi); return 0; }
   if (c.dma == 8) { snprintf(buf, len, "conv_fc_kernel(ConvArgs)"); return 0; }
   if (c.dma == 5 && (c.bi & 15) == 10) { snprintf(buf, len, "void conv_wino43_kernel<0>(ConvArgs)"); return 0; }
   if (c.dma == 5 && ((c.bi & 15) == 11 || (c.bi & 15) == 12)) {
@@ -206,6 +229,9 @@ static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
 // to the per-lane staging depth (ai / bi dwordx4 loads per stage).
 static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, double* cost_out) {
   if (cf.dma == 3) return false;  // retired ids
+#ifndef EGN_PROBES
+  if (probe_only(cf)) return false;   // never planned by the product library
+#endif
   if (cf.dma == 6) {
     if (!egn_conv_stem_applies(a)) return false;
     a.TH = 16; a.TW = 16; a.TNB = 1; a.HH = 33; a.HW = 33;
@@ -225,11 +251,11 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
     return true;
   }
   if (cf.dma == 7) {
-    // conv_wino4.hip: 16 x 32 pixel regions of whole-region maps, 8-channel stages, 48-channel co-tiles
-    if (!egn_conv_wino4_applies(a)) return false;
-    a.TH = 16; a.TW = 32; a.TNB = 1; a.HH = 18; a.HW = 34;
-    a.npix = 18 * 34; a.npixp = (a.npix + 15) & ~15; a.tps = 36;
-    a.tiles_x = a.Wo / 32;
+    // conv_wino4.hip: 16 x 32 (ai = 0) / 16 x 16 (ai = 1) pixel regions of whole-region maps, 48-channel co-tiles
+    if (!egn_conv_wino4_applies(a, cf.ai)) return false;
+    a.TH = 16; a.TW = cf.ai ? 16 : 32; a.TNB = 1; a.HH = 18; a.HW = a.TW + 2;
+    a.npix = 18 * a.HW; a.npixp = (a.npix + 15) & ~15; a.tps = 36;
+    a.tiles_x = a.Wo / a.TW;
     a.tiles_y = a.Ho / 16;
     if (cost_out) *cost_out = 0.0;
     return true;
@@ -384,9 +410,12 @@ int egn_conv_stats_rows(const ConvArgs& a, int cfg_id) {
 int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {
   if (cfg_id < 1 || cfg_id > kNumConfigs) return EGN_E_BADARG;
   const ConvConfig& cf = kConfigs[cfg_id - 1];
+#ifndef EGN_PROBES
+  if (egn_conv_config_kind(cfg_id) < 0) return EGN_E_BADARG;   // ablation / stamp / retired ids: probe builds only
+#endif
   const size_t lds = lds_bytes_for(a, cf);
   if (cf.dma == 6) return egn_conv_launch_stem(a, lds, stream);
-  if (cf.dma == 7) return egn_conv_launch_wino4(a, lds, cf.bi, stream);
+  if (cf.dma == 7) return egn_conv_launch_wino4(a, lds, cf.bi, cf.ai, stream);
   if (cf.dma == 8) return egn_conv_launch_fc(a, stream);
   if (cf.dma == 5) return egn_conv_launch_wino(a, lds, cf.bi, stream);
   if (cf.dma == 4) return egn_conv_launch_c48(a, lds, cf.bi == 2 ? -1 : cf.bi == 1 ? 0 : cf.wm, stream);

@@ -1871,17 +1871,23 @@ int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t
   const int act = a.act & EGN_ACT_MASK;
   if ((act != EGN_ACT_NONE && act != EGN_ACT_RELU) || (a.act & EGN_ACT_RES_AFTER)) return EGN_E_BADARG;
   switch (variant) {
-    case 1: return wino_launch<8, 8, 4>(a, lds, stream);
+    // what the shipped table / the tuner can select (egn_conv_config_kind >= 0 in the product build)
     case 2: return wino8_launch<16, 16, 1>(a, lds, stream);
     case 3: return wino8_launch<8, 8, 4>(a, lds, stream);
     case 4: return wino8_launch<8, 8, 2, 0, 4>(a, lds, stream);
     case 5: return wino8_launch<8, 16, 1, 0, 4>(a, lds, stream);
-    case 10: return a.stats ? EGN_E_BADARG : wino43_launch<0>(a, lds, stream);
-    case 0x1a: return wino43_launch<1>(a, lds, stream);           // s_memtime stamps (tools/wino_clk.py)
     case 6: return wino9_launch<16, 16, 1>(a, lds, stream);
     case 7: return wino9_launch<8, 8, 4>(a, lds, stream);
     case 8: return wino9_launch<8, 8, 2, 4>(a, lds, stream);
     case 9: return wino9_launch<8, 16, 1, 4>(a, lds, stream);
+#ifdef EGN_PROBES
+    // -DEGN_PROBES (python -m egonet_amd.build --probes; tools/ only): the families measured and retired -- the
+    // 4-wave kernel (cfg 45 / 46), the first F(4x4,3x3) kernel (65), two 4-wave blocks per CU (67 / 68) -- and the
+    // timing-ablation / s_memtime-stamp builds (WRONG RESULTS; 47-50, 53-55, 58, 63, 66, 69)
+    case 0: return wino_launch<16, 16, 1>(a, lds, stream);
+    case 1: return wino_launch<8, 8, 4>(a, lds, stream);
+    case 10: return a.stats ? EGN_E_BADARG : wino43_launch<0>(a, lds, stream);
+    case 0x1a: return wino43_launch<1>(a, lds, stream);           // s_memtime stamps (tools/wino_clk.py)
     case 11: return wino9_launch<8, 16, 1, 4, 2>(a, lds, stream);   // 8-channel stages, two blocks per CU
     case 12: return wino9_launch<8, 8, 2, 4, 2>(a, lds, stream);
     case 0x12: return wino8_launch<16, 16, 1, 16>(a, lds, stream);
@@ -1894,7 +1900,8 @@ int egn_conv_launch_wino(const ConvArgs& a, size_t lds, int variant, hipStream_t
     case 0x20: return wino_launch<16, 16, 1, 7>(a, lds, stream);
     case 0x30: return wino_launch<16, 16, 1, 3>(a, lds, stream);
     case 0x40: return wino_launch<16, 16, 1, 11>(a, lds, stream);
-    default: return wino_launch<16, 16, 1>(a, lds, stream);
+#endif
+    default: return EGN_E_BADARG;
   }
 }
 

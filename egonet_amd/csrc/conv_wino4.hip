@@ -30,6 +30,14 @@
 // Matrices (Lavin & Gray, points 0, +-1, +-2, inf), filter transform on the host (engine.pack_wino4_weight):
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// Two geometries of the same body (template parameter GEO) [round 4]:
+//   GEO 0  conv_wino4_kernel   16 x 32 pixel regions (2 m-tiles of 16 tiles), 8-channel stages  -- as described above;
+//   GEO 1  conv_wino4b_kernel  16 x 16 pixel regions (ONE m-tile), 16-channel stages: the same 36 MFMAs, 48 transform
+//          instructions and 2 halo pieces per wave and stage, the same filter layout (a stage reads four consecutive
+//          k-groups instead of two) and LDS budget, but twice as many items per layer -- the 16 x 16 maps of the
+//          192-channel branch are 256 items at 64 crops (two-image regions would be 128: half the chip), and small
+//          batches (BASELINE configs[4]'s 16-crop shard) fill the CUs.  A "k-group pair" (8 channels x 1 m-tile) takes
+//          the place of GEO 0's k-group (4 channels x 2 m-tiles) in the stage schedule.
 // Reference: the 3x3 stride-1 convolutions of libs/model/heatmapModel/hrnet.py (BasicBlock :49-76 and the
 // branches built from it); tolerance as for the F(2x2,3x3) kernels, see tools/wino43_network_study.py.
 #include <stdlib.h>
@@ -49,19 +57,32 @@ constexpr int W4_CO = 48;
 // r3_pmc_sq_wino4.txt): pixel-major order put all 16 tiles of a group on one bank (the transform alone took 5 000
 // cycles per stage); 16-byte quad planes left a 2-way conflict (SQ_LDS_BANK_CONFLICT 3.9 M cycles per launch).
 // The loads fetch pixel-major (32 contiguous bytes per pixel) and each lane stores its two channel pairs.
-constexpr int W4_RH = 18, W4_RW = 34;
-constexpr int W4_XD = 10;                             // slots per row and plane (9 used)
-constexpr int W4_PLANE = W4_RH * W4_XD;               // 180
-constexpr int W4_PAIR = 4 * W4_PLANE;                 // 720 8-byte slots per channel pair
-constexpr int W4_HSLOT = 4 * W4_PAIR;                 // 2880 slots = 23 040 B of the 24 KB buffer
+template <int GEO>
+struct W4G {
+  static constexpr int RH = 18, RW = GEO ? 18 : 34;     // halo pixels of a region
+  static constexpr int XD = GEO ? 5 : 10;               // slots per row and plane (x div 4: 0..4 / 0..8)
+  static constexpr int PLANE = RH * XD;                 // 90 / 180
+  static constexpr int PAIR = 4 * PLANE;                // 8-byte slots per channel pair: 360 / 720
+  static constexpr int QPP = GEO ? 4 : 2;               // channel quads per pixel and stage (16 / 8 channels)
+  static constexpr int HSLOT = 2 * QPP * PAIR;          // 2880 slots = 23 040 B of the 24 KB buffer (both)
+  static constexpr int SBYTES = 16 * QPP;               // bytes of a pixel's channels of one stage
+  static constexpr int NMT = GEO ? 1 : 2;               // m-tiles of a region
+  static constexpr int NKK = GEO ? 2 : 1;               // k-groups multiplied per filter wait ("k-group pair")
+  static constexpr int TWX = GEO ? 4 : 8;               // tiles per region row
+  static constexpr int RGW = GEO ? 16 : 32;             // region width in pixels
+};
+// GEO 1 (tests/test_wino4_design_cpu.py): slot (4 XD ty + tx) -> dword 40 ty + 2 tx + (kq & 1): ty 0..3 -> banks
+// +0, +8, +16, +24 -- 32 different banks per 32-lane group again.
 constexpr int W4_HBYTES = 2 * W4_NW * 1024;           // every wave issues 2 whole pieces: 24 KB
-constexpr int W4_VBYTES = 36 * 1024;                  // [pt][mt][g][lane] floats
+constexpr int W4_VBYTES = 36 * 1024;                  // [pt][mt][g][lane] floats (GEO 1: [pt][g 0..3][lane])
 constexpr int W4_V0 = 0, W4_V1 = W4_VBYTES, W4_H0 = 2 * W4_VBYTES, W4_H1 = W4_H0 + W4_HBYTES;
 constexpr int W4_LDS = W4_H1 + W4_HBYTES;             // 122 880 B
 constexpr int W4_XBYTES = 36 * 3 * 1024;              // exchange [pt][nt][lane] float4: 110 592 B
 static_assert(W4_XBYTES <= W4_LDS, "the exchange reuses the stage buffers");
-static_assert(W4_HSLOT * 8 + 1024 <= W4_HBYTES, "the halo and the parking slots of the idle load lanes fit the buffer");
-static_assert(2 * W4_RH * W4_RW <= 2 * W4_NW * 64, "two load pieces per wave cover the halo");
+static_assert(W4G<0>::HSLOT * 8 + 1024 <= W4_HBYTES && W4G<1>::HSLOT * 8 + 1024 <= W4_HBYTES,
+              "the halo and the parking slots of the idle load lanes fit the buffer");
+static_assert(W4G<0>::QPP * W4G<0>::RH * W4G<0>::RW <= 2 * W4_NW * 64 && W4G<1>::QPP * W4G<1>::RH * W4G<1>::RW <= 2 * W4_NW * 64,
+              "two load pieces per wave cover the halo");
 constexpr int W4_UKG = W4_NW * 3 * 64 * 4;            // filter floats of one (co-tile, stage, k-group): 9216 (9 of 12 used)
 constexpr unsigned W4_PAST = 0x80000000u;             // scalar byte offset past every buffer (tensors stay below 2 GB)
 }  // namespace
@@ -98,6 +119,14 @@ __device__ __forceinline__ void w4_vm_landed3(f32x4 (&b)[3]) {
 template <int N>
 __device__ __forceinline__ void w4_vm_landed2(f32x4 (&h)[2]) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(h[0]), "+v"(h[1]) : "n"(N));
+}
+// the filter registers of a wait group (one k-group: 3 dwordx4; GEO 1's k-group pair: 6), tied to the s_waitcnt
+__device__ __forceinline__ void w4_vm_landedB(f32x4 (&b)[1][3]) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]));
+}
+__device__ __forceinline__ void w4_vm_landedB(f32x4 (&b)[2][3]) {
+  asm volatile("s_waitcnt vmcnt(0)"
+               : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]));
 }
 template <int OFF>
 __device__ __forceinline__ void w4_xwr(unsigned addr, f32x4 v) {
@@ -139,11 +168,12 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4]) {
 // halo of stage parity P -> V, for this wave's (m-tile, k-group) share and its THIRD of the frequency rows:
 // PART 0 rows {0, 5}, 1 rows {1, 2}, 2 rows {3, 4} -- 48 VALU instructions, 36 / 24 / 24 LDS reads, 12 writes each.
 // hb0: per-lane byte base in halo buffer 0 (the immediates reach both buffers); vw0: base in THIS parity's V buffer.
-template <int P, int PART>
+template <int P, int PART, int GEO>
 __device__ __forceinline__ void w4_transform(unsigned hb0, unsigned vw0) {
-  static_assert(W4_H1 - W4_H0 + (3 * W4_PLANE + 5 * W4_XD + 1) * 8 < 65536, "halo immediates");
+  typedef W4G<GEO> Q;
+  static_assert(W4_H1 - W4_H0 + (3 * Q::PLANE + 5 * Q::XD + 1) * 8 < 65536, "halo immediates");
   constexpr int HO = P ? W4_H1 - W4_H0 : 0;
-#define W4_D(I, J) w4_lds<HO + (((J) & 3) * W4_PLANE + (I)*W4_XD + ((J) >> 2)) * 8>(hb0)
+#define W4_D(I, J) w4_lds<HO + (((J) & 3) * Q::PLANE + (I)*Q::XD + ((J) >> 2)) * 8>(hb0)
 #define W4_WR(PT, VAL) asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(vw0), "v"(VAL), "n"((PT)*1024) : "memory")
 #define W4_ROW(FI, O)                                                                                   \
   W4_WR((FI)*6 + 0, (O)[0]); W4_WR((FI)*6 + 1, (O)[1]); W4_WR((FI)*6 + 2, (O)[2]);                      \
@@ -201,11 +231,12 @@ __device__ __forceinline__ void w4_transform(unsigned hb0, unsigned vw0) {
 #undef W4_ROW
 }
 
-// ABL != 0: timing ablations (WRONG RESULTS; configs 71.., tools/wino_probe.py only): bit 0 no input transform,
-// bit 1 no MFMAs, bit 2 no exchange / output transform / stores, bit 3 no filter loads, bit 4 no halo DMA,
-// bit 5 bank-conflict-free halo reads
-template <int ABL>
-__global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
+// ABL != 0: timing ablations (WRONG RESULTS; probe builds only -- -DEGN_PROBES, tools/wino_probe.py): bit 0 no input
+// transform, bit 1 no MFMAs, bit 2 no exchange / output transform / stores, bit 3 no filter loads, bit 4 no halo DMA,
+// bit 5 bank-conflict-free halo reads, bit 6 s_memtime stamps (tools/wino4_clk.py)
+template <int ABL, int GEO>
+__device__ __forceinline__ void w4_body(const ConvArgs& a) {
+  typedef W4G<GEO> Q;
   extern __shared__ float4 w4_smem[];
   const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(lds_ptr_w4_t)w4_smem;
   const float* smf = reinterpret_cast<const float*>(w4_smem);
@@ -215,53 +246,53 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
   const int tpart = wave >> 2;             // its third of the frequency rows of the input transform
-  const int tw = wave & 3;                 // its share: m-tile tw >> 1, k-group tw & 1
+  const int tw = wave & 3;                 // its share: GEO 0 m-tile tw >> 1, k-group tw & 1; GEO 1 k-group tw
 
   const int C = a.Cin, Co = a.Cout;
   const int nct = Co / W4_CO;
-  const int S = C >> 3;                    // stages of 8 channels
+  const int S = C / (4 * Q::QPP);          // stages of 8 (GEO 0) / 16 (GEO 1) channels
 
   const unsigned long long xaddr = reinterpret_cast<unsigned long long>(a.x);
   const unsigned long long uaddr = reinterpret_cast<unsigned long long>(a.w);
   const u32x4 rxv = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, (unsigned)((size_t)a.N * a.H * a.W * C * 4),
                      0x00020000u};
-  const u32x4 ruv = {(unsigned)uaddr, (unsigned)(uaddr >> 32) & 0xffffu, (unsigned)((size_t)nct * S * 2 * W4_UKG * 4),
+  const u32x4 ruv = {(unsigned)uaddr, (unsigned)(uaddr >> 32) & 0xffffu, (unsigned)((size_t)nct * (C >> 2) * W4_UKG * 4),
                      0x00020000u};
   const unsigned out_bytes = (unsigned)((size_t)a.N * a.Ho * a.Wo * Co * 4);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, out_bytes, 0x00020000);
 
-  // ---- halo DMA: this wave's pieces wave and wave + 12; slot e -> (pixel = e >> 1, channel quad e & 1)
+  // ---- halo loads: this wave's pieces wave and wave + 12; element e -> (pixel = e / QPP, channel quad e % QPP)
   int hyx[2];
   unsigned hrel[2], hws[2], hws2[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    // LOAD order pixel-major, the two channel quads of a pixel in neighbouring lanes (32 contiguous bytes, 32
-    // cache lines per instruction instead of 64); the lane stores its 16 bytes to the pixel's slot of the
+    // LOAD order pixel-major, the channel quads of a pixel in neighbouring lanes (32 / 64 contiguous bytes: 32 or
+    // 16 cache lines per instruction instead of 64); the lane stores its 16 bytes to the pixel's slots of the
     // bank-conflict-free order above
     const int e = (wave + W4_NW * k) * 64 + lane;
-    const int px = e >> 1, hq = e & 1;
-    const int hy = px / W4_RW, hx = px - hy * W4_RW;
-    const bool ok = px < W4_RH * W4_RW;
+    const int px = e / Q::QPP, hq = e % Q::QPP;
+    const int hy = px / Q::RW, hx = px - hy * Q::RW;
+    const bool ok = px < Q::RH * Q::RW;
     hyx[k] = ok ? ((hy << 16) | hx) : -1;
     hrel[k] = ok ? (unsigned)(((hy * a.W + hx) * C + 4 * hq) * 4) : 0u;
     // (lanes past the last pixel park their zeros in the unused tail of the buffer)
     // channels 4 hq, 4 hq + 1 -> pair plane 2 hq, channels 4 hq + 2, + 3 -> pair plane 2 hq + 1
-    const int slot = 2 * hq * W4_PAIR + (hx & 3) * W4_PLANE + hy * W4_XD + (hx >> 2);
-    hws[k] = lds0 + (unsigned)(W4_H0 + (ok ? slot * 8 : W4_HSLOT * 8 + lane * 8));
-    hws2[k] = lds0 + (unsigned)(W4_H0 + (ok ? (slot + W4_PAIR) * 8 : W4_HSLOT * 8 + 512 + lane * 8));
+    const int slot = 2 * hq * Q::PAIR + (hx & 3) * Q::PLANE + hy * Q::XD + (hx >> 2);
+    hws[k] = lds0 + (unsigned)(W4_H0 + (ok ? slot * 8 : Q::HSLOT * 8 + lane * 8));
+    hws2[k] = lds0 + (unsigned)(W4_H0 + (ok ? (slot + Q::PAIR) * 8 : Q::HSLOT * 8 + 512 + lane * 8));
   }
-  // ---- transform share of this wave: lane (tile li of m-tile tw >> 1, channel 4 (tw & 1) + kq)
+  // ---- transform share of this wave: lane (tile li of its m-tile, channel 4 g + kq of the stage)
   unsigned hb0, vw0;
   {
-    const int mt = tw >> 1, g = tw & 1;
-    const int ty = 2 * mt + (li >> 3), tx = li & 7;
-    hb0 = lds0 + (unsigned)(W4_H0 + ((2 * g + (kq >> 1)) * W4_PAIR + 4 * W4_XD * ty + tx) * 8 + (kq & 1) * 4);
-    vw0 = lds0 + (unsigned)(W4_V0 + (mt * 2 + g) * 256 + lane * 4);
+    const int g = GEO ? tw : (tw & 1);
+    const int ty = GEO ? (li >> 2) : (2 * (tw >> 1) + (li >> 3)), tx = GEO ? (li & 3) : (li & 7);
+    hb0 = lds0 + (unsigned)(W4_H0 + ((2 * g + (kq >> 1)) * Q::PAIR + 4 * Q::XD * ty + tx) * 8 + (kq & 1) * 4);
+    vw0 = lds0 + (unsigned)(W4_V0 + tw * 256 + lane * 4);        // V[pt][mt * 2 + g | g][lane]
     if constexpr ((ABL & 32) != 0) hb0 = lds0 + (unsigned)(W4_H0 + lane * 4);     // conflict-free reads (wrong data)
   }
-  // ---- multiply: A operands V[3 wave + pl][mt][g][lane], filter block of this wave
+  // ---- multiply: A operands V[3 wave + pl][.][lane], filter block of this wave
   const float* va0 = smf + (W4_V0 / 4) + (3 * wave) * 256 + lane;
   const unsigned uvo = (unsigned)lane * 16u;
   // ---- exchange + output: this lane finishes tile 4 (wave & 3) + (lane >> 4) of the m-tile, co 16 (wave >> 2) + li
@@ -301,7 +332,7 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
     const unsigned n_ = w4_udiv((unsigned)reg, a.mg_txy);
     const unsigned r_ = (unsigned)reg - n_ * (unsigned)regs_xy;
     const unsigned ry_ = w4_udiv(r_, a.mg_tx);
-    const int n = (int)n_, y0 = (int)ry_ * 16, x0 = (int)(r_ - ry_ * (unsigned)regs_x) * 32;
+    const int n = (int)n_, y0 = (int)ry_ * 16, x0 = (int)(r_ - ry_ * (unsigned)regs_x) * Q::RGW;
 
     // halo offsets of the item (stage 0): uniform base + per-lane relative offset, zero padding by OOB offsets
     unsigned doff[2];
@@ -314,10 +345,8 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
         doff[k] = in ? (unsigned)base + hrel[k] : EGN_OOB;
       }
     }
-  // The halo goes through REGISTERS (buffer_load_dwordx4 -> ds_write_b128), not LDS-DMA: the hand-counted
-  // s_waitcnt vmcnt(N) below rely on loads returning in issue order, which holds among loads into registers --
-  // LDS-DMA loads and register loads overtake each other (with LDS-DMA pieces in the same queue the kernel was
-  // exact alone and wrong beside other streams' kernels: tools/f43_bisect.py, profiles/r3_wino4_f43_bisect.txt).
+  // The halo goes through REGISTERS (buffer_load_dwordx4 -> ds_write_b64), not LDS-DMA, and every vector-memory
+  // wait of the kernel is vmcnt(0): see the note in front of W4_STAGE.
 #define W4_HLOAD(K, STAGE) /* piece K of this wave; STAGE: byte offset of the stage's channels, W4_PAST = none */ \
   if constexpr ((ABL & 16) == 0) hreg[K] = w4_gld4<0>(rxv, doff[K], (unsigned)(STAGE));                        \
   else hreg[K] = f32x4{1.f, 2.f, 3.f, (float)lane};
@@ -328,38 +357,43 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
     w4_xwr2<(P)*W4_HBYTES>(hws[1], hreg[1][0], hreg[1][1]);                                                    \
     w4_xwr2<(P)*W4_HBYTES>(hws2[1], hreg[1][2], hreg[1][3]);                                                   \
   }
-    // filter k-group h = 2 stage + g of this wave: 9 dwords per lane, raw ISA -- the compiler's own vmcnt
-    // bookkeeping does not see the LDS-DMA pieces and would wait for them with every filter wait
-    const unsigned ubase = (unsigned)(ct * S) * (2u * W4_UKG * 4u) + (unsigned)wave * (3u * 64u * 16u);
+    // filter of this wave: k-group h (4 channels) = [co-tile][h][wave][3 x dwordx4 per lane] (engine.pack_wino4_weight);
+    // a wait group is one k-group (GEO 0: x 2 m-tiles) or two consecutive ones (GEO 1).  Raw ISA -- the waits are
+    // mine (tools/check_wino4_isa.py checks that no load's destination is touched before its wait)
+    const unsigned ubase = (unsigned)(ct * (C >> 2)) * (W4_UKG * 4u) + (unsigned)wave * (3u * 64u * 16u);
 #define W4_LOADB(DST, HS)                                                                                      \
   if constexpr ((ABL & 8) != 0) {                                                                              \
-    _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) DST[p_] = f32x4{(float)lane, 1.f, 2.f, (float)p_};                             \
+    _Pragma("unroll") for (int k_ = 0; k_ < Q::NKK; ++k_)                                                      \
+    _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) DST[k_][p_] = f32x4{(float)lane, 1.f, 2.f, (float)p_};    \
   } else {                                                                                                     \
-    const unsigned so_ = (HS);        /* byte offset of the k-group, W4_PAST = none */                        \
-    DST[0] = w4_gld4<0>(ruv, uvo, so_); DST[1] = w4_gld4<1024>(ruv, uvo, so_); DST[2] = w4_gld4<2048>(ruv, uvo, so_); \
+    const unsigned so_ = (HS);        /* byte offset of the wait group, W4_PAST = none */                      \
+    DST[0][0] = w4_gld4<0>(ruv, uvo, so_); DST[0][1] = w4_gld4<1024>(ruv, uvo, so_); DST[0][2] = w4_gld4<2048>(ruv, uvo, so_); \
+    if constexpr (Q::NKK == 2) {                                                                               \
+      const unsigned so1_ = so_ + W4_UKG * 4u;                                                                 \
+      DST[Q::NKK - 1][0] = w4_gld4<0>(ruv, uvo, so1_); DST[Q::NKK - 1][1] = w4_gld4<1024>(ruv, uvo, so1_);     \
+      DST[Q::NKK - 1][2] = w4_gld4<2048>(ruv, uvo, so1_);                                                      \
+    }                                                                                                          \
   }
-#define W4_LOADB1(DST, Q, HS)                                                                                  \
-  if constexpr ((ABL & 8) != 0) DST[Q] = f32x4{(float)lane, 1.f, 2.f, (float)(Q)};                             \
-  else DST[Q] = w4_gld4<(Q)*1024>(ruv, uvo, (HS));
-    f32x4 b0[3], b1[3];       // value p = 3 pl + nt of the k-group = b[p >> 2][p & 3]
+    constexpr unsigned WGB = (unsigned)Q::NKK * W4_UKG * 4u;       // filter bytes between consecutive wait groups
+    f32x4 b0[Q::NKK][3], b1[Q::NKK][3];       // value p = 3 pl + nt of a k-group = b[kk][p >> 2][p & 3]
     f32x4 hreg[2];
     W4_HLOAD(0, 0u)
     W4_HLOAD(1, 0u)
     W4_LOADB(b0, ubase)
     W4_CLK()      /* item top: halo + filter loads issued */
-    w4_vm_landed2<0>(hreg);                             // stage 0's pieces (and the first filter k-group)
+    w4_vm_landed2<0>(hreg);                             // stage 0's pieces (and the first filter wait group)
     W4_HSTORE(0)
-    W4_HLOAD(0, 32u)                                    // stage 1's pieces fly during the first transform
-    W4_HLOAD(1, 32u)
+    W4_HLOAD(0, (unsigned)Q::SBYTES)                    // stage 1's pieces fly during the first transform
+    W4_HLOAD(1, (unsigned)Q::SBYTES)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     W4_CLK()      /* own pieces of stage 0 in LDS */
     __builtin_amdgcn_s_barrier();
     W4_CLK()      /* everyone's */
     asm volatile("" ::: "memory");
     if constexpr ((ABL & 1) == 0) {
-      if (tpart == 0) w4_transform<0, 0>(hb0, vw0);
-      else if (tpart == 1) w4_transform<0, 1>(hb0, vw0);
-      else w4_transform<0, 2>(hb0, vw0);
+      if (tpart == 0) w4_transform<0, 0, GEO>(hb0, vw0);
+      else if (tpart == 1) w4_transform<0, 1, GEO>(hb0, vw0);
+      else w4_transform<0, 2, GEO>(hb0, vw0);
     }
     asm volatile("" ::: "memory");
     // this wave's pieces of stage 1 (and the filter loads before them) have landed: into LDS with them -- the
@@ -372,42 +406,50 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
     asm volatile("" ::: "memory");
     W4_CLK()      /* K loop starts */
 
-    f32x4 acc[3][3][2];
+    f32x4 acc[3][3][Q::NMT];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
       for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) acc[pl][nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < Q::NMT; ++mt) acc[pl][nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // 18 MFMAs of a k-group in three groups of 6 (one frequency point each); H0 / H1 / H2: the vector-memory
+  // 18 MFMAs of a wait group in three groups of 6 (one frequency point each); H0 / H1 / H2: the vector-memory
   // instruction issued behind each group -- spread over the stage instead of a burst behind the barrier, where
-  // all 12 waves of the CU queue for the address unit (profiles/r3_wino4_timeline_v1.txt: 1 000 cycles per wave)
+  // all 12 waves of the CU queue for the address unit (profiles/r3_wino4_timeline_v1.txt: 1 000 cycles per wave).
+  // A operands of point pl: GEO 0 the two m-tiles of k-group G, GEO 1 the k-groups 2 G, 2 G + 1 of the one m-tile.
 #define W4_MUL(P, G, B, H0, H1, H2)                                                                            \
   if constexpr ((ABL & 2) == 0) {                                                                              \
     float av_[3][2];                                                                                           \
-    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)          \
-        av_[pl][mt] = va0[((P) ? W4_VBYTES / 4 : 0) + ((pl * 2 + mt) * 2 + (G)) * 64];                         \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) _Pragma("unroll") for (int x_ = 0; x_ < 2; ++x_)          \
+        av_[pl][x_] = va0[((P) ? W4_VBYTES / 4 : 0) + (GEO ? (pl * 4 + 2 * (G) + x_) : ((pl * 2 + x_) * 2 + (G))) * 64]; \
     W4_MUL6(0, B) __builtin_amdgcn_sched_barrier(0); H0 __builtin_amdgcn_sched_barrier(0);                     \
     W4_MUL6(1, B) __builtin_amdgcn_sched_barrier(0); H1 __builtin_amdgcn_sched_barrier(0);                     \
     W4_MUL6(2, B) __builtin_amdgcn_sched_barrier(0); H2 __builtin_amdgcn_sched_barrier(0);                     \
   } else {                                                                                                     \
     H0 H1 H2                                                                                                   \
   }
+  // (GEO 1 adds two k-groups into one accumulator: k-group outermost, so that three other MFMAs lie between them)
 #define W4_MUL6(PL, B)                                                                                         \
-  _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)            \
-      acc[PL][nt][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[PL][mt], B[((PL)*3 + nt) >> 2][((PL)*3 + nt) & 3], \
-                                                             acc[PL][nt][mt], 0, 0, 0);
+  if constexpr (GEO == 0) {                                                                                    \
+    _Pragma("unroll") for (int nt = 0; nt < 3; ++nt) _Pragma("unroll") for (int mt = 0; mt < 2; ++mt)          \
+        acc[PL][nt][mt % Q::NMT] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[PL][mt], B[0][((PL)*3 + nt) >> 2][((PL)*3 + nt) & 3], \
+                                                               acc[PL][nt][mt % Q::NMT], 0, 0, 0);             \
+  } else {                                                                                                     \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int nt = 0; nt < 3; ++nt)          \
+        acc[PL][nt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_[PL][kk], B[kk % Q::NKK][((PL)*3 + nt) >> 2][((PL)*3 + nt) & 3], \
+                                                              acc[PL][nt][0], 0, 0, 0);                        \
+  }
   // Every vector-memory wait in this kernel is s_waitcnt vmcnt(0) -- on purpose.  The first versions counted
   // (`vmcnt(3)`: "the halo pieces have landed, the three newer filter loads may stay in flight"), which needs loads
   // to return in issue order.  Measured (tools/f43_bisect.py, profiles/r3_wino4_f43_bisect.txt): alone on the GPU
   // the kernel was exact; beside other streams' kernels whole-network outputs were off by up to 10 -- and ONLY the
   // wait in which older SLOW loads (the gathered halo, HBM) sit in front of newer FAST ones (the filter, L2) had
   // to become vmcnt(0) to make it exact again, with LDS-DMA pieces and with plain register loads alike.  So the
-  // stage is ordered such that no wait needs a count: k-group 2s+1 is issued at the top and awaited (alone in the
-  // queue) behind the g = 0 multiplies; k-group 2s+2 is issued right there, the halo pieces of stage s + 2 behind
-  // the first MFMA groups of g = 1, and all of them are awaited together at the end of the stage.
-  // The halo goes through registers (buffer_load_dwordx4 -> ds_write_b128): 2 pieces per wave and stage.
+  // stage is ordered such that no wait needs a count: wait group 2s+1 is issued at the top and awaited (alone in the
+  // queue) behind the G = 0 multiplies; wait group 2s+2 is issued right there, the halo pieces of stage s + 2 behind
+  // the first MFMA groups of G = 1, and all of them are awaited together at the end of the stage.
+  // The halo goes through registers (buffer_load_dwordx4 -> ds_write_b64): 2 pieces per wave and stage.
   // Straight-line code: past the last stage the loads are still issued, beyond the buffers' ends (zeros).  The
   // registers are written asynchronously behind the compiler's back: the destination of a load must reach its
   // s_waitcnt without being copied -- tools/check_wino4_isa.py asserts that on the compiled ISA
@@ -417,7 +459,7 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
 #define W4_TRANS(P, PART)                                                                                      \
   if ((ABL & 1) == 0 && s_ + 1 < S && tpart == (PART)) {                                                       \
     __builtin_amdgcn_s_setprio(3);                                                                             \
-    w4_transform<1 - (P), PART>(hb0, vw0 + (unsigned)((1 - (P)) * W4_VBYTES));                                 \
+    w4_transform<1 - (P), PART, GEO>(hb0, vw0 + (unsigned)((1 - (P)) * W4_VBYTES));                            \
     __builtin_amdgcn_s_setprio(0);                                                                             \
   }
   // the transform of stage s + 1 sits at a different point of the stage for each third of the waves: two of a
@@ -425,23 +467,23 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
 #define W4_STAGE(P, SI)                                                                                        \
   {                                                                                                            \
     const int s_ = (SI);                                                                                       \
-    const unsigned dst_ = s_ + 2 < S ? (unsigned)(s_ + 2) * 32u : W4_PAST;                                     \
-    const unsigned bn_ = s_ + 1 < S ? ubase + (unsigned)(2 * s_ + 2) * (W4_UKG * 4u) : W4_PAST;                \
-    w4_vm_landed3<0>(b0);                                                                                      \
-    W4_CLK() /* 0: filter k-group 2s landed */                                                                 \
-    W4_LOADB(b1, s_ < S ? ubase + (unsigned)(2 * s_ + 1) * (W4_UKG * 4u) : W4_PAST)                            \
+    const unsigned dst_ = s_ + 2 < S ? (unsigned)(s_ + 2) * (unsigned)Q::SBYTES : W4_PAST;                     \
+    const unsigned bn_ = s_ + 1 < S ? ubase + (unsigned)(2 * s_ + 2) * WGB : W4_PAST;                          \
+    w4_vm_landedB(b0);                                                                                         \
+    W4_CLK() /* 0: filter wait group 2s landed */                                                              \
+    W4_LOADB(b1, s_ < S ? ubase + (unsigned)(2 * s_ + 1) * WGB : W4_PAST)                                      \
     W4_TRANS(P, 0)                                                                                             \
     W4_CLK() /* 1: loads issued (+ transform, first third of the waves) */                                     \
     W4_MUL(P, 0, b0, , , )                                                                                     \
-    W4_CLK() /* 2: g = 0 multiplies and the pieces of stage s + 2 issued */                                    \
-    w4_vm_landed3<0>(b1);                                                                                      \
-    W4_CLK() /* 3: filter k-group 2s+1 landed */                                                               \
-    W4_LOADB(b0, bn_)       /* (its registers are free: g = 0 is issued) a whole half stage of flight */       \
+    W4_CLK() /* 2: G = 0 multiplies issued */                                                                  \
+    w4_vm_landedB(b1);                                                                                         \
+    W4_CLK() /* 3: filter wait group 2s+1 landed */                                                            \
+    W4_LOADB(b0, bn_)       /* (its registers are free: G = 0 is issued) a whole half stage of flight */       \
     W4_TRANS(P, 1)                                                                                             \
     W4_MUL(P, 1, b1, W4_HLOAD(0, dst_), W4_HLOAD(1, dst_), )                                                   \
     W4_TRANS(P, 2)                                                                                             \
-    W4_CLK() /* 4: g = 1 multiplies and k-group 2s+2 issued (+ transforms) */                                  \
-    w4_vm_landed2<0>(hreg);          /* the pieces of stage s + 2 and k-group 2s+2 */                          \
+    W4_CLK() /* 4: G = 1 multiplies and wait group 2s+2 issued (+ transforms) */                               \
+    w4_vm_landed2<0>(hreg);          /* the pieces of stage s + 2 and wait group 2s+2 */                       \
     W4_HSTORE(P)                                                                                               \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
     W4_CLK() /* 5: own pieces of stage s + 2 in LDS, V writes done */                                          \
@@ -449,15 +491,18 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
     asm volatile("" ::: "memory");                                                                             \
     W4_CLK() /* 6: past the barrier */                                                                         \
   }
-    for (int s = 0; s < S; s += 2) {     // (S is even: Cin % 16 == 0)
+    for (int s = 0; s + 1 < S; s += 2) {     // (GEO 0: S is even, Cin % 16 == 0)
       W4_STAGE(0, s)
       W4_STAGE(1, s + 1)
+    }
+    if constexpr (GEO == 1) {
+      if (S & 1) W4_STAGE(0, S - 1)          // 48 / 16 = 3 stages: the odd one (every item starts at parity 0)
     }
     // the loads past the end: tied to the wait -- for the compiler their registers are dead at the loop exit, and it
     // may move arithmetic of the item end into them while the loads are still in flight (seen with another form of
     // the item end, caught by tools/check_wino4_isa.py)
-    w4_vm_landed3<0>(b0);
-    w4_vm_landed3<0>(b1);
+    w4_vm_landedB(b0);
+    w4_vm_landedB(b1);
     w4_vm_landed2<0>(hreg);
     W4_CLK()      /* K loop done */
 #undef W4_STAGE
@@ -466,7 +511,6 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
 #undef W4_MUL6
 #undef W4_HLOAD
 #undef W4_HSTORE
-#undef W4_LOADB1
 #undef W4_LOADB
 
     // ---- item end: per m-tile, accumulators -> LDS -> one (tile, co) per lane -> Y = A^T M A -> epilogue
@@ -477,14 +521,17 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-        for (int nt = 0; nt < 3; ++nt) t += acc[pl][nt][0] + acc[pl][nt][1];
+        for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < Q::NMT; ++mt) t += acc[pl][nt][mt];
       if (t[0] + t[1] + t[2] + t[3] == 12345.f) a.y[tid] = t[0];
       continue;
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < Q::NMT; ++mt) {
       // this lane's output tile of the round: tile 4 okq + kq of m-tile mt, channel 16 ont + li
-      const int tile = 4 * okq + kq, ty = 2 * mt + (tile >> 3), tx = tile & 7;
+      const int tile = 4 * okq + kq;
+      const int ty = GEO ? (tile >> 2) : (2 * mt + (tile >> 3)), tx = GEO ? (tile & 3) : (tile & 7);
       const unsigned vo = (unsigned)((((n * a.Ho + y0 + 4 * ty) * a.Wo + x0 + 4 * tx) * Co + ct * W4_CO + ont * 16 + li) * 4);
       float rv[4][4];
 #pragma unroll
@@ -550,14 +597,19 @@ __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) {
 #undef W4_CLK
 }
 
-bool egn_conv_wino4_applies(const ConvArgs& a) {
+template <int ABL>
+__global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) { w4_body<ABL, 0>(a); }
+template <int ABL>
+__global__ __launch_bounds__(W4_NTH, 1) void conv_wino4b_kernel(ConvArgs a) { w4_body<ABL, 1>(a); }
+
+bool egn_conv_wino4_applies(const ConvArgs& a, int geo) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 16 == 0 && a.cs_in == a.Cin &&
-         a.Cout % W4_CO == 0 && a.cs_out == a.Cout && !a.out_nchw && a.Ho % 16 == 0 && a.Wo % 32 == 0 &&
+         a.Cout % W4_CO == 0 && a.cs_out == a.Cout && !a.out_nchw && a.Ho % 16 == 0 && a.Wo % (geo ? 16 : 32) == 0 &&
          !(a.act & EGN_ACT_RES_AFTER) &&
          ((a.act & EGN_ACT_MASK) == EGN_ACT_NONE || (a.act & EGN_ACT_MASK) == EGN_ACT_RELU);
 }
 size_t egn_conv_wino4_lds_bytes() { return W4_LDS + 12 * 96 * 8; }      // (+ the stamp area of the ABL & 64 build)
-// floats of the packed filter (engine.pack_wino4_weight): [co-tile][stage = Cin / 8][k-group][wave][9][64]
+// floats of the packed filter (engine.pack_wino4_weight): [co-tile][k-group = Cin / 4][wave][9 of 12][64]
 extern "C" long long egn_wino4_weight_floats(int cout, int cin) {
   if (cout % W4_CO || cin % 8 || cin < 16) return 0;
   return (long long)(cout / W4_CO) * (cin / 8) * 2 * W4_UKG;
@@ -565,13 +617,14 @@ extern "C" long long egn_wino4_weight_floats(int cout, int cin) {
 
 static unsigned w4_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
-template <int ABL>
+template <int ABL, int GEO>
 static int wino4_launch(ConvArgs a, size_t lds, hipStream_t stream) {
   static bool raised[EGN_MAX_DEVICES];
   static int cus = 0;
+  auto kern = GEO ? &conv_wino4b_kernel<ABL> : &conv_wino4_kernel<ABL>;
   if (egn_first_use_on_device(raised)) {
-    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino4_kernel<ABL>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 512));
   }
   if (!cus) {
     int dev = 0;
@@ -580,29 +633,44 @@ static int wino4_launch(ConvArgs a, size_t lds, hipStream_t stream) {
     if (cus <= 0) cus = 256;
   }
   const int nct = a.Cout / W4_CO;
+  const int nreg = a.tiles_x * a.tiles_y * a.N;
+  const int nwork = ((nreg + 7) / 8) * 8 * nct;
+  // the item index divisions run as one multiply-high each: exact while x * d < 2^32 (x = the dividend's range)
+  if ((unsigned long long)nwork * (unsigned)(8 * nct) >= 0x100000000ull ||
+      (unsigned long long)(nreg + 8) * (unsigned)(a.tiles_x * a.tiles_y) >= 0x100000000ull)
+    return EGN_E_BADARG;
   a.mg_nct = w4_magic(nct);
   a.mg_txy = w4_magic(a.tiles_x * a.tiles_y);
   a.mg_tx = w4_magic(a.tiles_x);
-  const int nreg = a.tiles_x * a.tiles_y * a.N;
-  const int nwork = ((nreg + 7) / 8) * 8 * nct;
   int cap = cus / (8 * nct) * (8 * nct);              // one 120 KB block per CU, whole XCD rounds
   if (cap <= 0) cap = 8 * nct;
   const int grid = nwork < cap ? nwork : cap;
-  hipLaunchKernelGGL(conv_wino4_kernel<ABL>, dim3(grid), dim3(W4_NTH), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(W4_NTH), lds, stream, a);
   return (int)hipGetLastError();
 }
-int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, hipStream_t stream) {
-  if (!egn_conv_wino4_applies(a) || a.stats) return EGN_E_BADARG;
+int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, int geo, hipStream_t stream) {
+  if (!egn_conv_wino4_applies(a, geo) || a.stats) return EGN_E_BADARG;
+  if (geo) {
+    switch (abl) {
+      case 0: return wino4_launch<0, 1>(a, lds, stream);
+#ifdef EGN_PROBES
+      case 64: return wino4_launch<64, 1>(a, lds, stream);
+#endif
+      default: return EGN_E_BADARG;
+    }
+  }
   switch (abl) {
-    case 0: return wino4_launch<0>(a, lds, stream);
-    case 1: return wino4_launch<1>(a, lds, stream);
-    case 2: return wino4_launch<2>(a, lds, stream);
-    case 4: return wino4_launch<4>(a, lds, stream);
-    case 8: return wino4_launch<8>(a, lds, stream);
-    case 16: return wino4_launch<16>(a, lds, stream);
-    case 7: return wino4_launch<7>(a, lds, stream);
-    case 32: return wino4_launch<32>(a, lds, stream);
-    case 64: return wino4_launch<64>(a, lds, stream);
+    case 0: return wino4_launch<0, 0>(a, lds, stream);
+#ifdef EGN_PROBES       // timing ablations / stamp builds: tools/ only (python -m egonet_amd.build --probes)
+    case 1: return wino4_launch<1, 0>(a, lds, stream);
+    case 2: return wino4_launch<2, 0>(a, lds, stream);
+    case 4: return wino4_launch<4, 0>(a, lds, stream);
+    case 8: return wino4_launch<8, 0>(a, lds, stream);
+    case 16: return wino4_launch<16, 0>(a, lds, stream);
+    case 7: return wino4_launch<7, 0>(a, lds, stream);
+    case 32: return wino4_launch<32, 0>(a, lds, stream);
+    case 64: return wino4_launch<64, 0>(a, lds, stream);
+#endif
     default: return EGN_E_BADARG;
   }
 }

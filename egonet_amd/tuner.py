@@ -121,13 +121,15 @@ def _pick(entry, allow_wino, allow_f43=False):
     return min(fit, key=fit.get) if fit else 0
 
 
-def _forced_wino(args, kind=1):
-    """EGONET_AMD_WINO=1 / =43: the Winograd F(2x2,3x3) / F(4x4,3x3) configuration for every shape one plans
-    for (parity tests pin the kernel families on the same fixtures); returns 0 if none does."""
+def _forced_wino(args, kind=1, order=None):
+    """EGONET_AMD_WINO=1 / =43 / =43b: the Winograd F(2x2,3x3) / F(4x4,3x3) configuration for every shape one plans
+    for (parity tests pin the kernel families on the same fixtures); returns 0 if none does.  ``order``: the ids to
+    try first (=43 prefers conv_wino4_kernel's 16 x 32 regions, cfg 70, and takes conv_wino4b_kernel, cfg 80, for the
+    maps only it plans; =43b prefers cfg 80 everywhere)."""
     n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, has_res, out_nchw = args
     L = _lib.lib()
     out = (C.c_int * 12)()
-    for cfg in range(L.egn_conv_num_configs(), 0, -1):
+    for cfg in list(order or ()) + list(range(L.egn_conv_num_configs(), 0, -1)):
         if L.egn_conv_config_kind(cfg) == kind and L.egn_conv_plan_query(
                 n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, int(out_nchw), cfg, out) == 0:
             return cfg
@@ -137,18 +139,19 @@ def _forced_wino(args, kind=1):
 def choose(device, args, allow_wino=False, allow_f43=False):
     """``allow_wino`` / ``allow_f43``: the caller packs the filter for whatever configuration kind comes back
     (egn_conv_config_kind 1 / 2).  EGONET_AMD_WINO=0 never returns a Winograd configuration, =1 always the
-    F(2x2,3x3) one where it plans, =43 the F(4x4,3x3) one where it plans (else F(2x2,3x3)); EGONET_AMD_F43=0
-    keeps F(4x4,3x3) out; default: whichever measured fastest."""
+    F(2x2,3x3) one where it plans, =43 / =43b an F(4x4,3x3) one where one plans (cfg 70 / cfg 80 first; else
+    F(2x2,3x3)); EGONET_AMD_F43=0 keeps F(4x4,3x3) out; default: whichever measured fastest."""
     mode = os.environ.get('EGONET_AMD_WINO', '')
     if os.environ.get('EGONET_AMD_F43', '1') == '0' or mode in ('0', '1'):
         allow_f43 = False
     if mode == '0':
         allow_wino = False
-    elif mode == '43' and allow_f43:
-        cfg = _forced_wino(args, 3) or _forced_wino(args, 2) or (_forced_wino(args, 1) if allow_wino else 0)
+    elif mode in ('43', '43b') and allow_f43:
+        cfg = _forced_wino(args, 3, (70, 80) if mode == '43' else (80, 70)) or _forced_wino(args, 2) or \
+            (_forced_wino(args, 1) if allow_wino else 0)
         if cfg:
             return cfg
-    elif mode in ('1', '43') and allow_wino:
+    elif mode in ('1', '43', '43b') and allow_wino:
         cfg = _forced_wino(args)
         if cfg:
             return cfg

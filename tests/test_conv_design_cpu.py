@@ -106,12 +106,19 @@ def test_planner_limits():
 
 
 def test_filter_resident_configs_plan_only_the_48_channel_3x3_layers():
-    """Configs 41 / 42 / 43 (csrc/conv_c48.hip): fixed 8x16 tile, filter (82 944 B) + two
-    48-channel halo buffers (2 x 36 864 B) in LDS, refused for every other layer.  43 = four
-    waves that copy the whole filter into registers."""
+    """Config 42 (csrc/conv_c48.hip): fixed 8x16 tile, filter (82 944 B) + two 48-channel halo buffers
+    (2 x 36 864 B) in LDS, refused for every other layer.  41 (four waves) and 43 (four waves that copy the whole
+    filter into registers) were measured and never selected: since round 4 they exist in probe builds only
+    (-DEGN_PROBES) -- the product library refuses to plan them."""
     L = _lib.lib()
     assert L.egn_conv_num_configs() >= 44
-    for cfg, waves in ((41, 4), (42, 8), (43, 4)):
+    probes = bool(L.egn_probe_build())
+    out = (C.c_int * 12)()
+    if not probes:
+        for cfg in (41, 43):
+            assert L.egn_conv_config_kind(cfg) == -1
+            assert L.egn_conv_plan_query(64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0, cfg, out) != 0
+    for cfg, waves in (((41, 4), (42, 8), (43, 4)) if probes else ((42, 8),)):
         plan = _plan((64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0), cfg=cfg)
         cfg_id, wm, wn, mt, nt, th, tw, tnb, tps, lds = plan[:10]
         assert (cfg_id, wm, wn, mt, nt) == (cfg, waves, 1, 8 // waves, 3)
@@ -147,11 +154,14 @@ def test_tall_tile_filter_resident_config():
 
 
 def test_winograd_configs_plan_and_kinds():
-    """Configs 45 / 46 (csrc/conv_wino.hip): fused Winograd F(2x2,3x3).  Fixed tiles (16 x 16 of one
-    image / four 8 x 8 images), two U slabs (2 x 49 152 B) + two quad-plane halo buffers in LDS."""
+    """Configs 45 / 46 (csrc/conv_wino.hip, the 4-wave kernel: probe builds only since round 4) and 51.. (the
+    8-wave kernels): fused Winograd F(2x2,3x3).  Fixed tiles (16 x 16 of one image / four 8 x 8 images), two U slabs
+    (2 x 49 152 B) + two quad-plane halo buffers in LDS."""
     L = _lib.lib()
+    probes = bool(L.egn_probe_build())
+    k4 = 1 if probes else -1
     assert [L.egn_conv_config_kind(c) for c in (0, 1, 44, 45, 46, 47, 51, 52, 53, 999)] == \
-        [-1, 0, 0, 1, 1, -1, 1, 1, -1, -1]
+        [-1, 0, 0, k4, k4, -1, 1, 1, -1, -1]
     # the 8-wave variants: exact-size halo planes (no padding to whole 512-thread pieces) + the
     # [waves][2][48] double table of the BatchNorm partial sums (training)
     p8 = _plan((64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0), cfg=51)
@@ -164,9 +174,12 @@ def test_winograd_configs_plan_and_kinds():
     p4 = _plan((32, 16, 16, 192, 192, 192, 192, 3, 3, 1, 1, 0), cfg=57)
     assert p4[5:8] == [8, 16, 1] and p4[10] * p4[11] == 256
     assert L.egn_conv_plan_query(64, 16, 16, 192, 192, 192, 192, 3, 3, 1, 1, 0, 56, (C.c_int * 12)()) != 0
+    if not probes:       # the product library refuses the retired 4-wave family; the rest of this test is about it
+        assert L.egn_conv_plan_query(64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0, 45, (C.c_int * 12)()) != 0
+        assert L.egn_conv_plan_query(64, 8, 8, 384, 384, 384, 384, 3, 3, 1, 1, 0, 46, (C.c_int * 12)()) != 0
     for cfg, shape, tile in ((45, (64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0), [16, 16, 1]),
                              (45, (64, 16, 16, 192, 192, 192, 192, 3, 3, 1, 1, 0), [16, 16, 1]),
-                             (46, (64, 8, 8, 384, 384, 384, 384, 3, 3, 1, 1, 0), [8, 8, 4])):
+                             (46, (64, 8, 8, 384, 384, 384, 384, 3, 3, 1, 1, 0), [8, 8, 4])) if probes else ():
         plan = _plan(shape, cfg=cfg)
         assert plan[0] == cfg and plan[5:8] == tile
         assert plan[9] == 2 * 49152 + 2 * 1792 * 16 and plan[9] <= 160 * 1024 - 512
@@ -179,7 +192,10 @@ def test_winograd_configs_plan_and_kinds():
                 (64, 63, 64, 48, 48, 48, 48, 3, 3, 1, 1, 0),          # odd map
                 (64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 1)):         # NCHW output
         assert L.egn_conv_plan_query(*bad, 45, out) != 0
+        if bad[5] != 64:
+            assert L.egn_conv_plan_query(*bad, 59, out) != 0      # conv_wino9_kernel: the same rules (64 = 2 x 32 plans)
     assert L.egn_conv_plan_query(64, 16, 16, 192, 192, 192, 192, 3, 3, 1, 1, 0, 46, out) != 0   # 46: 8x8 maps only
+    assert L.egn_conv_plan_query(64, 16, 16, 192, 192, 192, 192, 3, 3, 1, 1, 0, 60, out) != 0   # 60 likewise
     name = C.create_string_buffer(96)
     assert L.egn_conv_config_name(45, name, 96) == 0 and name.value == b'void conv_wino_kernel<16, 16, 1, 0>(ConvArgs)'
     assert L.egn_wino_weight_floats(96, 48, 0) == 96 * 48 * 16 and L.egn_wino_weight_floats(40, 48, 0) == 0

@@ -144,13 +144,16 @@ def test_conv_stem_kernel(n, h, w, act):
     (2, 64, 64, 64, 64, False, 1),     # the 64-channel stem / layer1 3x3 convs of every model
 ])
 def test_conv_winograd_kernels(n, h, w, cin, cout, res, act):
-    """Configs 45 / 46 (4 waves) and 51 / 52 (8 waves, frequency halves + partial exchange) of
-    csrc/conv_wino.hip: fused Winograd F(2x2,3x3); the filter transform runs on the device
-    (egn_wino_pack_weight_f32).  Same oracle and tolerance as the direct kernels."""
+    """Configs 51 / 52 (8 waves, frequency halves + partial exchange), 56 / 57, 59..62 of csrc/conv_wino.hip: fused
+    Winograd F(2x2,3x3); the filter transform runs on the device (egn_wino_pack_weight_f32).  Same oracle and tolerance
+    as the direct kernels.  45 / 46 (the 4-wave kernel) and 67 / 68 (two 4-wave blocks per CU) were measured and
+    retired: they are tested when the library under test is a probe build (-DEGN_PROBES), refused otherwise."""
     import ctypes as C
     from egonet_amd import _lib
     L = _lib.lib()
-    assert [L.egn_conv_config_kind(c) for c in (44, 45, 46, 51, 52, 56, 57, 59, 60, 61, 62, 67, 68)] == [0] + [1] * 12
+    probes = bool(L.egn_probe_build())
+    assert [L.egn_conv_config_kind(c) for c in (44, 51, 52, 56, 57, 59, 60, 61, 62)] == [0] + [1] * 8
+    assert [L.egn_conv_config_kind(c) for c in (45, 46, 67, 68)] == [1 if probes else -1] * 4
     assert L.egn_conv_config_kind(47) == -1 and L.egn_conv_config_kind(53) == -1     # timing ablations: never selectable
     assert L.egn_conv_config_kind(58) == -1 and L.egn_conv_config_kind(63) == -1     # stamp builds neither
     out = (C.c_int * 12)()
@@ -159,16 +162,17 @@ def test_conv_winograd_kernels(n, h, w, cin, cout, res, act):
     # 67 / 68 = conv_wino9_kernel with 8-channel stages (two 4-wave blocks per CU) on the tiles of 62 / 61
     for cfg in (45, 46, 51, 52, 56, 57, 59, 60, 61, 62, 67, 68):
         rc = L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, cfg, out)
-        if (cfg in (46, 52, 56, 60, 61, 68) and (h > 8 or w > 8)) or (cfg in (45, 46) and cout % 48):
+        if (cfg in (46, 52, 56, 60, 61, 68) and (h > 8 or w > 8)) or (cfg in (45, 46) and cout % 48) or \
+                (cfg in (45, 46, 67, 68) and not probes):
             assert rc != 0
             continue
         assert rc == 0
         err = _conv_case(n, h, w, cin, cout, 3, 1, 1, act=act, use_res=res, cfg=cfg, seed=n + h + cin)
         assert err < 2e-4, (cfg, err)
     # what the planner must refuse: stride 2, 1x1, padded channel strides, Cout not a multiple of 48
-    assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 48, 48, 3, 3, 2, 1, 0, 45, out) != 0
-    assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 48, 48, 1, 1, 1, 0, 0, 45, out) != 0
-    assert L.egn_conv_plan_query(2, 16, 16, 35, 36, 48, 48, 3, 3, 1, 1, 0, 45, out) != 0
+    assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 48, 48, 3, 3, 2, 1, 0, 59, out) != 0
+    assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 48, 48, 1, 1, 1, 0, 0, 59, out) != 0
+    assert L.egn_conv_plan_query(2, 16, 16, 35, 36, 48, 48, 3, 3, 1, 1, 0, 59, out) != 0
     assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 80, 80, 3, 3, 1, 1, 0, 51, out) != 0
     assert L.egn_wino_weight_floats(80, 48, 0) == 0 and L.egn_wino_weight_floats(48, 80, 1) == 0
 
@@ -228,6 +232,50 @@ def test_conv_wino4_kernel(n, h, w, cin, cout, res, act):
     assert L.egn_conv_plan_query(2, 16, 32, 48, 48, 64, 64, 3, 3, 1, 1, 0, 70, out) != 0
     assert L.egn_conv_plan_query(2, 32, 64, 48, 48, 48, 48, 3, 3, 2, 1, 0, 70, out) != 0
     assert L.egn_wino4_weight_floats(64, 48) == 0 and L.egn_wino4_weight_floats(48, 20) == 0
+    # the product library refuses to launch an ablation / stamp build through the C ABI
+    if not L.egn_probe_build():
+        import torch
+        t = torch.zeros(1 << 20, device='cuda')
+        for bad_cfg in (71, 76, 78, 47, 65):
+            assert L.egn_conv2d_f32(_lib.ptr(t), _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), None, _lib.ptr(t), 1, 16, 32, 16, 16,
+                                    48, 48, 3, 3, 1, 1, 1, 0, bad_cfg, _lib.current_stream()) != 0, bad_cfg
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,res,act', [
+    (2, 16, 16, 16, 48, True, 1),      # one region per image, ONE 16-channel stage (the odd-stage tail alone)
+    (3, 16, 16, 192, 192, True, 1),    # the 16 x 16 maps of the 192-channel branch: 12 stages, 4 co-tiles
+    (2, 64, 64, 48, 48, True, 1),      # 3 stages (odd): pair loop + tail; 16 regions per image
+    (3, 32, 48, 32, 96, False, 0),     # 2 x 3 regions, 2 co-tiles, no activation, no residual
+    (70, 16, 16, 48, 96, True, 1),     # more work items than one round of persistent blocks (2 items per block)
+    (5, 32, 32, 96, 144, False, 1),    # odd batch, 3 co-tiles, 6 stages
+])
+def test_conv_wino4b_kernel(n, h, w, cin, cout, res, act):
+    """Config 80, conv_wino4b_kernel: the F(4x4,3x3) body of csrc/conv_wino4.hip on 16 x 16 pixel regions with
+    16-channel stages (one m-tile, k-group pairs) -- the geometry that gives the 16 x 16 maps (hrnet.py:68-92 at
+    192 channels) and small batches enough work items.  Same filter pack, oracle and tolerance as config 70."""
+    import ctypes as C
+    from egonet_amd import _lib
+    L = _lib.lib()
+    assert L.egn_conv_config_kind(80) == 3 and L.egn_conv_config_kind(81) == -1
+    out = (C.c_int * 12)()
+    assert L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, 80, out) == 0
+    assert list(out)[5:8] == [16, 16, 1] and out[10] == n * (h // 16) * (w // 16)
+    err = _conv_case(n, h, w, cin, cout, 3, 1, 1, act=act, use_res=res, cfg=80, seed=n + h + cin)
+    assert err < 5e-4, err
+    # agreement with the 16 x 32 geometry where both plan: the same arithmetic per output -- bit-identical
+    if w % 32 == 0:
+        import torch
+        from egonet_amd import ops
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(n, h, w, cin, generator=g).cuda()
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+        pc = ops.PackedConv(wt, None, None, kind=3)
+        ya = ops.conv2d_nhwc(x, pc, cin, 1, 1, 1, None, cfg=70)
+        yb = ops.conv2d_nhwc(x, pc, cin, 1, 1, 1, None, cfg=80)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb)
+    assert L.egn_conv_plan_query(2, 8, 8, 48, 48, 48, 48, 3, 3, 1, 1, 0, 80, out) != 0
+    assert L.egn_conv_plan_query(2, 16, 24, 48, 48, 48, 48, 3, 3, 1, 1, 0, 80, out) != 0
 
 
 @pytest.mark.parametrize('h,c,cfg', [(64, 48, 51), (32, 96, 51), (16, 192, 51), (8, 384, 56), (16, 192, 57)])

@@ -46,12 +46,29 @@ def test_hrnet_tiny_vs_reference_outputs(name):
     assert np.array_equal(maps.reshape(maps.shape[0], maps.shape[1], -1).argmax(axis=2), idx_ref)
 
 
-@pytest.mark.parametrize('wino', ['1', '0'])
+def _kind_counts(net):
+    """{filter kind: launches} and {cfg: launches} over the conv launches of the programs the engine has built."""
+    from egonet_amd import _lib
+    L = _lib.lib()
+    kinds, cfgs = {}, {}
+    for prog in net._hip_engine().programs.values():
+        for m in prog.meta:
+            if m['kind'] == 'conv':
+                k = L.egn_conv_config_kind(m['cfg']) if m['cfg'] > 0 else 0
+                kinds[k] = kinds.get(k, 0) + 1
+                cfgs[m['cfg']] = cfgs.get(m['cfg'], 0) + 1
+    return kinds, cfgs
+
+
+@pytest.mark.parametrize('wino', ['43', '43b', '1', '0'])
 @pytest.mark.parametrize('head', ['coordinates', 'heatmap'])
 def test_hrnet_w48_vs_reference_outputs(head, wino, monkeypatch):
-    """The headline model: HRNet-W48 @256x256, 4 crops, both heads + decode -- once with the fused
-    Winograd kernels on every 3x3 s1 layer they plan for (EGONET_AMD_WINO=1, csrc/conv_wino.hip),
-    once with the direct kernels only (=0): both kernel families meet the reference's bar."""
+    """The headline model: HRNet-W48 @256x256, 4 crops, both heads + decode, against the REFERENCE's own outputs --
+    with the fused Winograd F(4x4,3x3) kernels forced onto every 3x3 s1 layer they plan for (EGONET_AMD_WINO=43:
+    conv_wino4_kernel on the 64 x 64 / 32 x 32 maps + conv_wino4b_kernel on the 16 x 16 maps; =43b:
+    conv_wino4b_kernel on all three -- the bench's default kernels), with the F(2x2,3x3) kernels
+    (=1, csrc/conv_wino.hip), and with the direct kernels only (=0): every kernel family meets the reference's bar,
+    arg-max indices and hard predictions bit-exact."""
     from egonet_amd.common import img_proc
     monkeypatch.setenv('EGONET_AMD_WINO', wino)
     g = golden('hrnet_w48_outputs.npz')
@@ -61,6 +78,19 @@ def test_hrnet_w48_vs_reference_outputs(head, wino, monkeypatch):
     x = synth.synth_crops(4, 3, 256, 256, seed=11)
     with torch.no_grad():
         out = net(x.cuda())
+    kinds, cfgs = _kind_counts(net)
+    if wino in ('43', '43b'):
+        # 3x3 s1 layers of the 48 / 96 / 192-channel branches (+ the 256 -> 48 transition): F(4x4,3x3); the 384-channel
+        # 8 x 8 maps and the 64-channel layers: F(2x2,3x3)
+        assert kinds.get(3, 0) >= 180 and kinds.get(1, 0) >= 20, kinds
+        if wino == '43':
+            assert cfgs.get(70, 0) >= 100 and cfgs.get(80, 0) >= 50, cfgs
+        else:
+            assert cfgs.get(80, 0) >= 180 and cfgs.get(70, 0) == 0, cfgs
+    elif wino == '1':
+        assert kinds.get(1, 0) >= 200 and 3 not in kinds and 2 not in kinds, kinds
+    else:
+        assert set(kinds) == {0}, kinds
     maps_d = out[0] if isinstance(out, tuple) else out
     maps = maps_d.cpu().numpy()
     assert maps.shape == (4, 33, 64, 64)
@@ -203,15 +233,24 @@ def test_hrnet_other_heads_vs_reference_outputs(tag):
         assert np.array_equal(out.cpu().numpy().reshape(out.shape[0], out.shape[1], -1).argmax(axis=2), idx_ref)
 
 
-def test_egonet_w48_pipeline_vs_reference_outputs(tmp_path):
+@pytest.mark.parametrize('mode', ['table', 'f43'])
+def test_egonet_w48_pipeline_vs_reference_outputs(tmp_path, mode, monkeypatch):
     """BASELINE config 5 at full size on one GPU: HRNet-W48 (coordinates head) -> x256 -> crop affine
     -> lifter -> pose solve -> KITTI result lines for 16 crops of 4 frames, against the REFERENCE's
     own CPU run (tests/golden/egonet_w48_pipeline.npz, tools/inference.py:135-199 minus file I/O).
     get_keypoints is called the way the reference calls it -- eval mode, autograd enabled
-    (libs/model/egonet.py:434) -- and must run the HIP program (launch counter)."""
+    (libs/model/egonet.py:434) -- and must run the HIP program (launch counter).
+    mode 'table': the SHIPPED tile table, autotuning off -- configs[4]'s per-GPU shard runs a reproducible
+    selection with no shape left to the cost model; mode 'f43': the F(4x4,3x3) kernels forced
+    onto every layer they plan for (>= 180 launches of filter kind 3)."""
     from egonet_amd import _lib
     from egonet_amd.model.egonet import EgoNet
     import json
+    monkeypatch.setenv('EGONET_AMD_AUTOTUNE', '0')
+    if mode == 'f43':
+        monkeypatch.setenv('EGONET_AMD_WINO', '43')
+    else:
+        monkeypatch.delenv('EGONET_AMD_WINO', raising=False)
     g = golden('egonet_w48_pipeline.npz')
     cfg = configs.w48_config('coordinates')
     ego = EgoNet(cfg, pre_trained=False)
@@ -235,6 +274,13 @@ def test_egonet_w48_pipeline_vs_reference_outputs(tmp_path):
     rec = ego.get_keypoints(crops, records)                 # no torch.no_grad() around it
     nops = sum(1 for m in ego.HC._hip_engine().program(crops.cuda()).meta if m['kind'] not in ('fork', 'join'))
     assert L.egn_launch_count() - before >= nops > 300
+    kinds, cfgs = _kind_counts(ego.HC)
+    if mode == 'f43':
+        assert kinds.get(3, 0) >= 180 and cfgs.get(70, 0) >= 100, (kinds, cfgs)
+    else:
+        # every conv shape of the 16-crop program has a MEASURED entry in tuned/gfx950.json: nothing falls back to
+        # the cost model (cfg 0), nothing is autotuned on the box
+        assert cfgs.get(0, 0) == 0, 'shapes left to the cost model: %d launches' % cfgs.get(0, 0)
     rec = ego.lift_2d_to_3d(rec)
     kp2d = np.concatenate([np.concatenate(rec[p]['kpts_2d_pred']) for p in paths])
     kp3d = np.concatenate([rec[p]['kpts_3d_pred'] for p in paths])

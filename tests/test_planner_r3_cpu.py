@@ -18,10 +18,19 @@ def _plans(L, n, h, w, cin, cs_in, cout, cs_out, k, s, p, nchw, cfg):
 
 def test_kinds_and_names():
     L = _lib.lib()
-    assert [L.egn_conv_config_kind(c) for c in (59, 64, 65, 67, 70, 79)] == [1, 0, 2, 1, 3, 0]
-    assert all(L.egn_conv_config_kind(c) == -1 for c in (58, 63, 66, 69, 71, 72, 73, 74, 75, 76, 77, 78))   # stamps / ablations
+    probes = bool(L.egn_probe_build())
+    # 65 (first F(4x4,3x3) kernel) and 67 (two 4-wave blocks per CU) were measured and retired: probe builds only
+    assert [L.egn_conv_config_kind(c) for c in (59, 64, 65, 67, 70, 79, 80)] == \
+        ([1, 0, 2, 1, 3, 0, 3] if probes else [1, 0, -1, -1, 3, 0, 3])
+    assert all(L.egn_conv_config_kind(c) == -1 for c in (58, 63, 66, 69, 71, 72, 73, 74, 75, 76, 77, 78, 81))   # stamps / ablations
+    if not probes:
+        # ... and the product library neither plans nor launches them
+        for cfg in (41, 43, 45, 46, 47, 53, 58, 63, 65, 66, 67, 68, 69, 71, 72, 76, 78, 81):
+            assert not _plans(L, 64, 64, 64, 48, 48, 48, 48, 3, 1, 1, 0, cfg), cfg
+            assert L.egn_conv2d_f32(None, None, None, None, None, None, 64, 64, 64, 48, 48, 48, 48, 3, 3, 1, 1, 1, 0, cfg,
+                                    None) != 0, cfg
     buf = C.create_string_buffer(128)
-    for cfg, sym in ((64, 'conv_stem_kernel'), (70, 'conv_wino4_kernel<0>'), (79, 'conv_fc_kernel'),
+    for cfg, sym in ((64, 'conv_stem_kernel'), (70, 'conv_wino4_kernel<0>'), (80, 'conv_wino4b_kernel<0>'), (79, 'conv_fc_kernel'),
                      (59, 'conv_wino9_kernel<16, 16, 1, 8, 3, 0, 4>'), (67, 'conv_wino9_kernel<8, 16, 1, 4, 3, 0, 2>')):
         assert L.egn_conv_config_name(cfg, buf, 128) == 0 and sym in buf.value.decode(), (cfg, buf.value)
 
@@ -41,6 +50,16 @@ def test_stem_wino4_and_fc_rules():
                 (64, 64, 64, 48, 52, 48, 48, 3, 1, 1), (64, 64, 64, 48, 48, 48, 48, 1, 1, 0)):
         assert not _plans(L, *bad, 0, 70), bad
     assert L.egn_wino4_weight_floats(96, 48) == 2 * 6 * 2 * 12 * 3 * 64 * 4
+    # ... conv_wino4b_kernel (cfg 80): whole 16 x 16 regions -- the 16 x 16 maps of the 192-channel branch plan
+    assert _plans(L, 64, 16, 16, 192, 192, 192, 192, 3, 1, 1, 0, 80)
+    assert _plans(L, 16, 64, 64, 48, 48, 48, 48, 3, 1, 1, 0, 80) and _plans(L, 3, 32, 48, 16, 16, 96, 96, 3, 1, 1, 0, 80)
+    for bad in ((64, 8, 8, 384, 384, 384, 384, 3, 1, 1), (64, 24, 16, 48, 48, 48, 48, 3, 1, 1),
+                (64, 16, 16, 24, 24, 48, 48, 3, 1, 1), (64, 16, 16, 192, 192, 64, 64, 3, 1, 1),
+                (64, 16, 16, 192, 192, 192, 192, 3, 2, 1)):
+        assert not _plans(L, *bad, 0, 80), bad
+    out = (C.c_int * 12)()
+    assert L.egn_conv_plan_query(64, 16, 16, 192, 192, 192, 192, 3, 3, 1, 1, 0, 80, out) == 0
+    assert list(out)[5:8] == [16, 16, 1] and out[10] * out[11] == 64 * 4      # one region per image x 4 co-tiles = 256 items
     # row GEMM: 1x1 s1 p0, Cin % 16, Cout % 16; NCHW output only for 1 x 1 maps
     assert _plans(L, 64, 1, 1, 1024, 1024, 1024, 1024, 1, 1, 0, 0, 79)
     assert _plans(L, 64, 1, 1, 1024, 1024, 96, 96, 1, 1, 0, 1, 79)

@@ -48,10 +48,13 @@ def inflight(queue):
     return out
 
 
-def check(path):
+KERNELS = ('conv_wino4_kernel', 'conv_wino4b_kernel')       # the two geometries of the body (GEO 0 / 1), product builds
+
+
+def check(path, kernel='conv_wino4_kernel'):
     text = open(path).read()
-    m = re.search(r'^(_Z\d+conv_wino4_kernelILi0E\w*):', text, re.M)
-    assert m, 'kernel symbol not found'
+    m = re.search(r'^(_Z\d+%sILi0E\w*):' % kernel, text, re.M)
+    assert m, 'kernel symbol not found: ' + kernel
     body = text[m.end():text.index('s_endpgm', m.end())]
     queue = []          # outstanding vector-memory operations, oldest first: destination VGPRs or None
     lds = []            # outstanding LDS / scalar-memory operations (lgkmcnt), oldest first
@@ -96,16 +99,19 @@ def check(path):
         hit = regs_of(rest) & (inflight(queue) | inflight(lds))
         if hit:
             problems.append('%s  <- touches in-flight v%s' % (t, sorted(hit)))
-    scratch = re.search(r'\.private_segment_fixed_size:\s*(\d+)', text)
-    if scratch and int(scratch.group(1)) != 0:
-        problems.append('scratch in use: %s bytes per lane' % scratch.group(1))
+    for scratch in re.finditer(r'\.private_segment_fixed_size:\s*(\d+)', text):
+        if int(scratch.group(1)) != 0:
+            problems.append('scratch in use: %s bytes per lane' % scratch.group(1))
     return problems, nload, nwait
 
 
 if __name__ == '__main__':
     path = sys.argv[1] if len(sys.argv) > 1 else compile_isa()
-    problems, nload, nwait = check(path)
-    print('%d filter / residual loads, %d vmcnt waits, %d problems' % (nload, nwait, len(problems)))
-    for p in problems[:40]:
-        print('  ' + p)
-    sys.exit(1 if problems else 0)
+    bad = 0
+    for kern in KERNELS:
+        problems, nload, nwait = check(path, kern)
+        print('%s: %d filter / residual loads, %d vmcnt waits, %d problems' % (kern, nload, nwait, len(problems)))
+        for p in problems[:40]:
+            print('  ' + p)
+        bad += len(problems)
+    sys.exit(1 if bad else 0)
