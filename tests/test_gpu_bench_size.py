@@ -64,7 +64,7 @@ def test_w48_forward_and_decode_at_bench_batch_64_vs_oracle():
     wino = {s: n for s, n in syms.items() if 'wino' in s}
     assert sum(wino.values()) >= 200, syms                         # the 3x3 s1 layers run the Winograd family
     # ... and it is what the committed bench line of this round reports
-    lines = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r3_bench_n1*.json')))
+    lines = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r4_bench_n1*.json')))
     if lines:
         with open(lines[-1]) as f:
             rep = json.load(f)
@@ -85,10 +85,36 @@ def test_w48_forward_and_decode_at_bench_batch_64_vs_oracle():
     got_idx = idx.cpu().numpy().astype(np.int64)
     differ = np.argwhere(got_idx != widx)
     flat = want.reshape(64, 33, -1)
+    gflat = maps.reshape(64, 33, -1)
+    ties = []
     for n, k in differ:
-        assert flat[n, k, got_idx[n, k]] >= wmax[n, k, 0] - 1e-4, (n, k, flat[n, k, got_idx[n, k]], wmax[n, k, 0])
+        top2 = np.sort(flat[n, k])[-2:]
+        ties.append(dict(n=int(n), k=int(k), oracle_idx=int(widx[n, k]), hip_idx=int(got_idx[n, k]),
+                         oracle_top2_gap=float(top2[1] - top2[0]),
+                         oracle_at_hip_idx=float(flat[n, k, got_idx[n, k]]), oracle_max=float(wmax[n, k, 0]),
+                         hip_at_oracle_idx=float(gflat[n, k, widx[n, k]]), hip_max=float(gflat[n, k, got_idx[n, k]])))
+    kinds = {}
+    for c in cfgs_:
+        kd = _lib.lib().egn_conv_config_kind(c) if c > 0 else 0
+        kinds[kd] = kinds.get(kd, 0) + 1
+    report = dict(maps=64 * 33, exact=64 * 33 - len(differ), ties=ties, conv_launches_by_filter_kind=kinds,
+                  max_abs_map_error=float(np.abs(maps - want).max()))
+    print('arg-max vs the CPU oracle at 64 crops (shipped table): %s' % json.dumps(report))
+    out_dir = os.path.join(ROOT, 'gpurun_out', 'parity')
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, 'argmax_ties_64.json'), 'w') as f:
+            json.dump(report, f, indent=1)
+    except OSError:
+        pass
+    assert kinds.get(3, 0) >= 180, kinds                 # the default dominant kernels ARE the F(4x4,3x3) ones
+    # arg-max indices: bit exact.  Where the ORACLE's own two largest values are closer than fp32 noise of
+    # a 300-layer network (1e-4 on maps spanning +-20) the index is not defined by the mathematics; such
+    # maps must still pick one of the tied maxima, and there may be at most a handful of them -- each one is
+    # listed above (and in gpurun_out/parity/argmax_ties_64.json -> profiles/) with the oracle's top-2 gap
+    for t in ties:
+        assert t['oracle_at_hip_idx'] >= t['oracle_max'] - 1e-4 and t['oracle_top2_gap'] <= 1e-4, t
     assert len(differ) <= 3, len(differ)
-    print('arg-max: %d of %d maps exact, %d oracle ties' % (64 * 33 - len(differ), 64 * 33, len(differ)))
     np.testing.assert_allclose(mx.cpu().numpy(), wmax, rtol=0, atol=5e-4)
     sxy, _ = decode_oracle.soft_arg_max(want)
     np.testing.assert_allclose(xy.cpu().numpy(), sxy, rtol=0, atol=1e-3)
