@@ -116,10 +116,6 @@ static const ConvConfig kConfigs[] = {
     {79, 4, 1, 1, 1, 0, 0, 8},     // 1x1 conv on 1 x 1 maps (the lifter's Linear layers): one 16 x 16 tile per block, K split over the waves (conv_fc.hip)
     {80, 12, 1, 1, 3, 1, 0, 7},    // conv_wino4b_kernel: F(4x4,3x3) on 16 x 16 pixel regions, 16-channel stages (ai = geometry 1); filter kind 3
     {81, 12, 1, 1, 3, 1, 64, 7},   // 80 with s_memtime stamps (tools/wino4_clk.py)
-    // stage-schedule studies of conv_wino4.hip (probe builds; CORRECT results): bi = 128 / 256 / 384 = schedule 0 / 1 / 2
-    {82, 12, 1, 1, 3, 0, 128, 7}, {83, 12, 1, 1, 3, 0, 256, 7}, {84, 12, 1, 1, 3, 0, 384, 7},
-    {85, 12, 1, 1, 3, 1, 128, 7}, {86, 12, 1, 1, 3, 1, 256, 7}, {87, 12, 1, 1, 3, 1, 384, 7},
-    {88, 12, 1, 1, 3, 0, 384 + 64, 7}, {89, 12, 1, 1, 3, 1, 384 + 64, 7},      // schedule 2 with s_memtime stamps
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 

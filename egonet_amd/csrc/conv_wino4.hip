@@ -48,9 +48,6 @@ typedef __attribute__((address_space(3))) void* lds_ptr_w4_t;
 
 namespace {
 constexpr int W4_NW = 12, W4_NTH = 64 * W4_NW;
-#ifndef W4_SCHED
-#define W4_SCHED 0               // stage schedule of the product build (see w4_body)
-#endif
 constexpr int W4_CO = 48;
 // Halo of the 16 x 32 region: 18 x 34 pixels x 8 channels, in 8-byte slots (one pixel, one channel PAIR) ordered
 // [pair 0..3][x mod 4][y][x div 4 (pitch 10)]: the transform's lane (tile (ty, tx), channel kq of k-group g) reads
@@ -234,90 +231,14 @@ __device__ __forceinline__ void w4_transform(unsigned hb0, unsigned vw0) {
 #undef W4_ROW
 }
 
-// The same transform in three STEPS that a wave weaves between its own MFMA groups (schedule 2 of w4_body).  Each
-// step issues its LDS reads, waits for them and computes -- only 12 values (t.ta, t.tb) stay live between the steps
-// (reads kept in flight across the MFMA groups cost 24-36 more registers: the kernel spilled):
-//   PART 0:     [18 reads, 12 VALU] [12 VALU + 6 writes, 18 reads, 12 VALU] [12 VALU + 6 writes]
-//   PART 1, 2:  [24 reads, 24 VALU] [12 VALU + 6 writes]                    [12 VALU + 6 writes]
-struct W4T { float ta[6], tb[6]; };
-template <int P, int PART, int GEO, int STEP>
-__device__ __forceinline__ void w4_tstep(unsigned hb0, unsigned vw0, W4T& t) {
-  typedef W4G<GEO> Q;
-  constexpr int HO = P ? W4_H1 - W4_H0 : 0;
-#define W4_D(I, J) w4_lds<HO + (((J) & 3) * Q::PLANE + (I)*Q::XD + ((J) >> 2)) * 8>(hb0)
-#define W4_WR(PT, VAL) asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(vw0), "v"(VAL), "n"((PT)*1024) : "memory")
-#define W4_ROW(FI, O)                                                                                   \
-  W4_WR((FI)*6 + 0, (O)[0]); W4_WR((FI)*6 + 1, (O)[1]); W4_WR((FI)*6 + 2, (O)[2]);                      \
-  W4_WR((FI)*6 + 3, (O)[3]); W4_WR((FI)*6 + 4, (O)[4]); W4_WR((FI)*6 + 5, (O)[5]);
-#define W4_RD6(DST, I)                                                                                  \
-  DST[0] = W4_D(I, 0); DST[1] = W4_D(I, 1); DST[2] = W4_D(I, 2); DST[3] = W4_D(I, 3); DST[4] = W4_D(I, 4); DST[5] = W4_D(I, 5);
-  if constexpr (PART == 0) {
-    if constexpr (STEP == 1) {
-      float x[6], y[6], z[6];
-      W4_RD6(x, 0) W4_RD6(y, 2) W4_RD6(z, 4)
-      w4_landed6(x, y);
-      w4_tie6(z);
-#pragma unroll
-      for (int j = 0; j < 6; ++j) t.ta[j] = __builtin_fmaf(4.f, x[j], __builtin_fmaf(-5.f, y[j], z[j]));
-    } else if constexpr (STEP == 2) {
-      float x[6], y[6], z[6], o[6];
-      W4_RD6(x, 1) W4_RD6(y, 3) W4_RD6(z, 5)
-      w4_bt(t.ta, o);                        // (under the reads' latency)
-      W4_ROW(0, o)
-      w4_landed6(x, y);
-      w4_tie6(z);
-#pragma unroll
-      for (int j = 0; j < 6; ++j) t.tb[j] = __builtin_fmaf(4.f, x[j], __builtin_fmaf(-5.f, y[j], z[j]));
-    } else {
-      float o[6];
-      w4_bt(t.tb, o);
-      W4_ROW(5, o)
-    }
-  } else {
-    if constexpr (STEP == 1) {
-      float d1[6], d2[6], d3[6], d4[6];
-      W4_RD6(d1, 1) W4_RD6(d2, 2) W4_RD6(d3, 3) W4_RD6(d4, 4)
-      w4_landed6(d1, d2);
-      w4_tie6(d3);
-      w4_tie6(d4);
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        if constexpr (PART == 1) {        // rows 1, 2: u = d4 - 4 d2, v = d3 - 4 d1
-          const float u = __builtin_fmaf(-4.f, d2[j], d4[j]), v = __builtin_fmaf(-4.f, d1[j], d3[j]);
-          t.ta[j] = u + v;
-          t.tb[j] = u - v;
-        } else {                          // rows 3, 4: p = d4 - d2, q = d3 - d1
-          const float p = d4[j] - d2[j], q = d3[j] - d1[j];
-          t.ta[j] = __builtin_fmaf(2.f, q, p);
-          t.tb[j] = __builtin_fmaf(-2.f, q, p);
-        }
-      }
-    } else if constexpr (STEP == 2) {
-      float o[6];
-      w4_bt(t.ta, o);
-      if constexpr (PART == 1) { W4_ROW(1, o) } else { W4_ROW(3, o) }
-    } else {
-      float o[6];
-      w4_bt(t.tb, o);
-      if constexpr (PART == 1) { W4_ROW(2, o) } else { W4_ROW(4, o) }
-    }
-  }
-#undef W4_RD6
-#undef W4_D
-#undef W4_WR
-#undef W4_ROW
-}
-
 // ABL != 0: timing ablations (WRONG RESULTS; probe builds only -- -DEGN_PROBES, tools/wino_probe.py): bit 0 no input
 // transform, bit 1 no MFMAs, bit 2 no exchange / output transform / stores, bit 3 no filter loads, bit 4 no halo DMA,
 // bit 5 bank-conflict-free halo reads, bit 6 s_memtime stamps (tools/wino4_clk.py).
-// Bits 7-8: the stage SCHEDULE (correct results; W4_SCHED picks the product's): 0 = round 3's (transform thirds at the
-// top / middle / END of the stage), 1 = third 2 moved to the middle, 2 = every wave weaves its third between its OWN
-// first MFMA groups (w4_tstep; three copies of the K loop, one per third).
+// (Round 4 also measured two other stage schedules -- the last transform third moved to mid-stage: no change; every
+// wave weaving its third between its own MFMA groups: 20-35 % slower -- profiles/r4_wino4_experiments.txt.)
 template <int ABL, int GEO>
 __device__ __forceinline__ void w4_body(const ConvArgs& a) {
   typedef W4G<GEO> Q;
-  constexpr int SCH = (ABL >> 7) & 3 ? ((ABL >> 7) & 3) - 1 : W4_SCHED;      // bits 7-8: 1 + schedule (0 = the default)
   extern __shared__ float4 w4_smem[];
   const unsigned lds0 = (unsigned)(__UINTPTR_TYPE__)(lds_ptr_w4_t)w4_smem;
   const float* smf = reinterpret_cast<const float*>(w4_smem);
@@ -561,9 +482,8 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
     W4_CLK() /* 3: filter wait group 2s+1 landed */                                                            \
     W4_LOADB(b0, bn_)       /* (its registers are free: G = 0 is issued) a whole half stage of flight */       \
     W4_TRANS(P, 1)                                                                                             \
-    if constexpr (SCH == 1) { W4_TRANS(P, 2) }                                                                 \
     W4_MUL(P, 1, b1, W4_HLOAD(0, dst_), W4_HLOAD(1, dst_), )                                                   \
-    if constexpr (SCH == 0) { W4_TRANS(P, 2) }                                                                 \
+    W4_TRANS(P, 2)                                                                                             \
     W4_CLK() /* 4: G = 1 multiplies and wait group 2s+2 issued (+ transforms) */                               \
     w4_vm_landed2<0>(hreg);          /* the pieces of stage s + 2 and wait group 2s+2 */                       \
     W4_HSTORE(P)                                                                                               \
@@ -573,61 +493,12 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
     asm volatile("" ::: "memory");                                                                             \
     W4_CLK() /* 6: past the barrier */                                                                         \
   }
-  // Schedule 2: the wave's third of the transform of stage s + 1 in steps behind its own first MFMA groups.  In the
-  // last stage the steps run on the zero halo "past the end" (W4_PAST) into the idle V buffer: straight-line code.
-#define W4_TS(P, PART, STEP)                                                                                   \
-  if constexpr ((ABL & 1) == 0) {                                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    w4_tstep<1 - (P), PART, GEO, STEP>(hb0, vw0 + (unsigned)((1 - (P)) * W4_VBYTES), tt_);                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-  }
-#define W4_STAGE2(P, SI, PART)                                                                                 \
-  {                                                                                                            \
-    const int s_ = (SI);                                                                                       \
-    const unsigned dst_ = s_ + 2 < S ? (unsigned)(s_ + 2) * (unsigned)Q::SBYTES : W4_PAST;                     \
-    const unsigned bn_ = s_ + 1 < S ? ubase + (unsigned)(2 * s_ + 2) * WGB : W4_PAST;                          \
-    W4T tt_;                                                                                                   \
-    w4_vm_landedB(b0);                                                                                         \
-    W4_CLK() /* 0 */                                                                                           \
-    W4_LOADB(b1, s_ < S ? ubase + (unsigned)(2 * s_ + 1) * WGB : W4_PAST)                                      \
-    W4_CLK() /* 1: loads issued */                                                                             \
-    W4_MUL(P, 0, b0, W4_TS(P, PART, 1), W4_TS(P, PART, 2), W4_TS(P, PART, 3))                                  \
-    W4_CLK() /* 2: G = 0 multiplies issued, transform third done */                                            \
-    w4_vm_landedB(b1);                                                                                         \
-    W4_CLK() /* 3 */                                                                                           \
-    W4_LOADB(b0, bn_)                                                                                          \
-    W4_MUL(P, 1, b1, W4_HLOAD(0, dst_), W4_HLOAD(1, dst_), )                                                   \
-    W4_CLK() /* 4 */                                                                                           \
-    w4_vm_landed2<0>(hreg);                                                                                    \
-    W4_HSTORE(P)                                                                                               \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
-    W4_CLK() /* 5 */                                                                                           \
-    __builtin_amdgcn_s_barrier();                                                                              \
-    asm volatile("" ::: "memory");                                                                             \
-    W4_CLK() /* 6 */                                                                                           \
-  }
-#define W4_KLOOP2(PART)                                                                                        \
-  {                                                                                                            \
-    for (int s = 0; s + 1 < S; s += 2) {                                                                       \
-      W4_STAGE2(0, s, PART)                                                                                    \
-      W4_STAGE2(1, s + 1, PART)                                                                                \
-    }                                                                                                          \
-    if constexpr (GEO == 1) {                                                                                  \
-      if (S & 1) W4_STAGE2(0, S - 1, PART)                                                                     \
-    }                                                                                                          \
-  }
-    if constexpr (SCH == 2) {
-      if (tpart == 0) W4_KLOOP2(0)
-      else if (tpart == 1) W4_KLOOP2(1)
-      else W4_KLOOP2(2)
-    } else {
-      for (int s = 0; s + 1 < S; s += 2) {     // (GEO 0: S is even, Cin % 16 == 0)
-        W4_STAGE(0, s)
-        W4_STAGE(1, s + 1)
-      }
-      if constexpr (GEO == 1) {
-        if (S & 1) W4_STAGE(0, S - 1)          // 48 / 16 = 3 stages: the odd one (every item starts at parity 0)
-      }
+    for (int s = 0; s + 1 < S; s += 2) {     // (GEO 0: S is even, Cin % 16 == 0)
+      W4_STAGE(0, s)
+      W4_STAGE(1, s + 1)
+    }
+    if constexpr (GEO == 1) {
+      if (S & 1) W4_STAGE(0, S - 1)          // 48 / 16 = 3 stages: the odd one (every item starts at parity 0)
     }
     // the loads past the end: tied to the wait -- for the compiler their registers are dead at the loop exit, and it
     // may move arithmetic of the item end into them while the loads are still in flight (seen with another form of
@@ -636,9 +507,6 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
     w4_vm_landedB(b1);
     w4_vm_landed2<0>(hreg);
     W4_CLK()      /* K loop done */
-#undef W4_KLOOP2
-#undef W4_STAGE2
-#undef W4_TS
 #undef W4_STAGE
 #undef W4_TRANS
 #undef W4_MUL
@@ -789,10 +657,6 @@ int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, int geo, hipStream_t 
       case 0: return wino4_launch<0, 1>(a, lds, stream);
 #ifdef EGN_PROBES
       case 64: return wino4_launch<64, 1>(a, lds, stream);
-      case 128: return wino4_launch<128, 1>(a, lds, stream);      // schedules 0 / 1 / 2 (correct results)
-      case 256: return wino4_launch<256, 1>(a, lds, stream);
-      case 384: return wino4_launch<384, 1>(a, lds, stream);
-      case 384 + 64: return wino4_launch<384 + 64, 1>(a, lds, stream);
 #endif
       default: return EGN_E_BADARG;
     }
@@ -808,10 +672,6 @@ int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, int geo, hipStream_t 
     case 7: return wino4_launch<7, 0>(a, lds, stream);
     case 32: return wino4_launch<32, 0>(a, lds, stream);
     case 64: return wino4_launch<64, 0>(a, lds, stream);
-    case 128: return wino4_launch<128, 0>(a, lds, stream);        // schedules 0 / 1 / 2 (correct results)
-    case 256: return wino4_launch<256, 0>(a, lds, stream);
-    case 384: return wino4_launch<384, 0>(a, lds, stream);
-    case 384 + 64: return wino4_launch<384 + 64, 0>(a, lds, stream);
 #endif
     default: return EGN_E_BADARG;
   }

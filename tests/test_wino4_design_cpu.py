@@ -118,6 +118,71 @@ def test_halo_slot_order_is_bank_conflict_free_for_the_transform_reads():
                         assert len(banks) == 32, (mt, g, i, j, len(banks))
 
 
+def test_halo_slot_order_of_the_16x16_region_geometry():
+    """conv_wino4b_kernel (GEO 1): 18 x 18 halo pixels x 16 channels = 8 channel-pair planes,
+    slot = p * 360 + (x % 4) * 90 + y * 5 + x // 4.  Lane (tile (ty, tx) of the 4 x 4 tiles, channel kq of k-group g) reads
+    dword kq & 1 of pair 2 g + kq // 2 at pixel (4 ty + i, 4 tx + j): dword = 40 ty + 2 tx + (kq & 1) + const -- ty adds
+    8 banks, so every 32-lane group hits 32 different banks for every (i, j); the load lane of element
+    e = (wave + 12 k) * 64 + lane fetches pixel e // 4, channel quad e % 4 and stores pairs 2 q, 2 q + 1."""
+    def slot(p, y, x):
+        return p * 360 + (x % 4) * 90 + y * 5 + x // 4
+    seen = set()
+    for p in range(8):
+        for y in range(18):
+            for x in range(18):
+                s = slot(p, y, x)
+                assert 0 <= s < 2880 and s not in seen
+                seen.add(s)
+    assert len(seen) == 8 * 18 * 18
+    for g in range(4):
+        for i in range(6):
+            for j in range(6):
+                for half in (range(0, 32), range(32, 64)):
+                    banks = set()
+                    for lane in half:
+                        li, kq = lane & 15, lane >> 4
+                        ty, tx = li >> 2, li & 3
+                        banks.add((slot(2 * g + kq // 2, 4 * ty + i, 4 * tx + j) * 2 + (kq & 1)) % 32)
+                    assert len(banks) == 32, (g, i, j, len(banks))
+    # the two load pieces of the 12 waves cover every (pixel, quad) exactly once
+    got = set()
+    for k in range(2):
+        for wave in range(12):
+            for lane in range(64):
+                e = (wave + 12 * k) * 64 + lane
+                px, q = e // 4, e % 4
+                if px < 18 * 18:
+                    got.add((px, q))
+    assert len(got) == 18 * 18 * 4
+
+
+def test_wino4b_reads_the_same_filter_pack_in_k_group_pairs():
+    """GEO 1 walks engine.pack_wino4_weight's layout as [co-tile][k-group h = Cin / 4][wave][3 x 64 x 4]: stage s (16
+    channels) = k-groups 4 s .. 4 s + 3, wait group G = the pair (4 s + 2 G, 4 s + 2 G + 1); the byte offset of k-group
+    h is h * 36 864 -- the same bytes GEO 0 addresses as [stage = Cin / 8][g]."""
+    from egonet_amd import engine
+    rng = np.random.default_rng(5)
+    cout, cin = 48, 32
+    w = rng.standard_normal((cout, cin, 3, 3))
+    flat = engine.pack_wino4_weight(torch.from_numpy(w)).numpy()
+    a = flat.reshape(cout // 48, cin // 8, 2, 12, 3, 64, 4)                 # GEO 0 view
+    b = flat.reshape(cout // 48, cin // 4, 12, 3, 64, 4)                    # GEO 1 view: linear k-group index
+    for h in range(cin // 4):
+        assert np.array_equal(b[0, h], a[0, h // 2, h % 2])
+    assert flat.size == (cout // 48) * (cin // 4) * 9216
+    # channel of lane (kq) in k-group h: ci = 4 h + kq
+    U = np.einsum('ia,ocab,jb->ocij', G, w, G)
+    for h in (0, 3, 7):
+        for wave in (0, 5, 11):
+            for p_ in range(9):
+                pl, nt = p_ // 3, p_ % 3
+                for kq in range(4):
+                    for li in (0, 7, 15):
+                        got = b[0, h, wave, p_ // 4, 16 * kq + li, p_ % 4]
+                        pt = 3 * wave + pl
+                        assert abs(got - U[16 * nt + li, 4 * h + kq, pt // 6, pt % 6]) < 1e-6
+
+
 @pytest.mark.skipif(shutil.which(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')) is None, reason='hipcc not installed')
 def test_filter_load_registers_reach_their_waitcnt_untouched():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_wino4_isa.py')], capture_output=True, text=True,
