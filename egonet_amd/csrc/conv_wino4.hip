@@ -60,11 +60,16 @@ constexpr int W4_CO = 48;
 template <int GEO>
 struct W4G {
   static constexpr int RH = 18, RW = GEO ? 18 : 34;     // halo pixels of a region
+  static constexpr int RWP = GEO ? 20 : 40;             // load-element row pitch: a 16-lane store group = 4 / 8 ALIGNED pixels
   static constexpr int XD = GEO ? 5 : 10;               // slots per row and plane (x div 4: 0..4 / 0..8)
-  static constexpr int PLANE = RH * XD;                 // 90 / 180
-  static constexpr int PAIR = 4 * PLANE;                // 8-byte slots per channel pair: 360 / 720
+  // plane / pair pitches carry a bank skew for the halo STORES (ds_write_b64 is served in groups of 16 lanes: 8 pixels x
+  // 2 quads, GEO 1: 4 pixels x 4 quads; without the skew the quads of a pixel fell on one bank: 2- / 4-way conflicts).
+  // GEO 0: pixel x -> 8 (x & 3) + 2 (x >> 2) dwords, quad -> + 4: 32 banks.  GEO 1: pixel -> 2 (x & 3), quad -> 8 q.
+  // The transform's READS are per (i, j) and per pair plane: they only see XD (bank-free as before).
+  static constexpr int PLANE = GEO ? 97 : RH * XD;      // >= RH * XD = 90 / 180; 2 PLANE mod 32 = 2 / 8 dwords
+  static constexpr int PAIR = GEO ? 394 : 4 * PLANE + 1;  // 8-byte slots per channel pair; 4 PAIR mod 32 = 8 / 4 dwords
   static constexpr int QPP = GEO ? 4 : 2;               // channel quads per pixel and stage (16 / 8 channels)
-  static constexpr int HSLOT = 2 * QPP * PAIR;          // 2880 slots = 23 040 B of the 24 KB buffer (both)
+  static constexpr int HSLOT = 2 * QPP * PAIR;          // 2884 / 3152 slots of the 26 KB buffer
   static constexpr int SBYTES = 16 * QPP;               // bytes of a pixel's channels of one stage
   static constexpr int NMT = GEO ? 1 : 2;               // m-tiles of a region
   static constexpr int NKK = GEO ? 2 : 1;               // k-groups multiplied per filter wait ("k-group pair")
@@ -73,15 +78,15 @@ struct W4G {
 };
 // GEO 1 (tests/test_wino4_design_cpu.py): slot (4 XD ty + tx) -> dword 40 ty + 2 tx + (kq & 1): ty 0..3 -> banks
 // +0, +8, +16, +24 -- 32 different banks per 32-lane group again.
-constexpr int W4_HBYTES = 2 * W4_NW * 1024;           // every wave issues 2 whole pieces: 24 KB
+constexpr int W4_HBYTES = 26 * 1024;                  // halo slots (<= 25 216 B) + 1 KB parking for the idle load lanes
 constexpr int W4_VBYTES = 36 * 1024;                  // [pt][mt][g][lane] floats (GEO 1: [pt][g 0..3][lane])
 constexpr int W4_V0 = 0, W4_V1 = W4_VBYTES, W4_H0 = 2 * W4_VBYTES, W4_H1 = W4_H0 + W4_HBYTES;
-constexpr int W4_LDS = W4_H1 + W4_HBYTES;             // 122 880 B
+constexpr int W4_LDS = W4_H1 + W4_HBYTES;             // 126 976 B
 constexpr int W4_XBYTES = 36 * 3 * 1024;              // exchange [pt][nt][lane] float4: 110 592 B
 static_assert(W4_XBYTES <= W4_LDS, "the exchange reuses the stage buffers");
 static_assert(W4G<0>::HSLOT * 8 + 1024 <= W4_HBYTES && W4G<1>::HSLOT * 8 + 1024 <= W4_HBYTES,
               "the halo and the parking slots of the idle load lanes fit the buffer");
-static_assert(W4G<0>::QPP * W4G<0>::RH * W4G<0>::RW <= 2 * W4_NW * 64 && W4G<1>::QPP * W4G<1>::RH * W4G<1>::RW <= 2 * W4_NW * 64,
+static_assert(W4G<0>::QPP * W4G<0>::RH * W4G<0>::RWP <= 2 * W4_NW * 64 && W4G<1>::QPP * W4G<1>::RH * W4G<1>::RWP <= 2 * W4_NW * 64,
               "two load pieces per wave cover the halo");
 constexpr int W4_UKG = W4_NW * 3 * 64 * 4;            // filter floats of one (co-tile, stage, k-group): 9216 (9 of 12 used)
 constexpr unsigned W4_PAST = 0x80000000u;             // scalar byte offset past every buffer (tensors stay below 2 GB)
@@ -275,8 +280,8 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
     // bank-conflict-free order above
     const int e = (wave + W4_NW * k) * 64 + lane;
     const int px = e / Q::QPP, hq = e % Q::QPP;
-    const int hy = px / Q::RW, hx = px - hy * Q::RW;
-    const bool ok = px < Q::RH * Q::RW;
+    const int hy = px / Q::RWP, hx = px - hy * Q::RWP;          // (rows padded to whole store groups)
+    const bool ok = hy < Q::RH && hx < Q::RW;
     hyx[k] = ok ? ((hy << 16) | hx) : -1;
     hrel[k] = ok ? (unsigned)(((hy * a.W + hx) * C + 4 * hq) * 4) : 0u;
     // (lanes past the last pixel park their zeros in the unused tail of the buffer)
@@ -299,8 +304,14 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
   const unsigned uvo = (unsigned)lane * 16u;
   // ---- exchange + output: this lane finishes tile 4 (wave & 3) + (lane >> 4) of the m-tile, co 16 (wave >> 2) + li
   const int ont = wave >> 2, okq = wave & 3;
+  // exchange [point][co sub-tile][writer lane] float4 (the C fragment: tiles 4 kq_w .. + 3 of channel li_w).  The reader
+  // takes ONE dword of 16 writer slots (li = 0..15): a stride of 4 dwords puts li and li + 8 on one bank (2-way conflict
+  // on all 36 reads of a round).  So writers with li >= 8 store their float4 rotated by two dwords (two ds_write_b64
+  // with swapped offsets -- no extra instruction), and the reader looks at dword (kq + 2 (li >> 3)) & 3.
+  const unsigned xhi = (unsigned)(li >> 3);
   const unsigned xw0 = lds0 + (unsigned)((3 * wave) * 3 * 1024 + lane * 16);
-  const unsigned xr0 = lds0 + (unsigned)((ont * 64 + okq * 16 + li) * 16 + kq * 4);
+  const unsigned xwa = xw0 + 8u * xhi, xwb = xw0 + 8u - 8u * xhi;           // elements (0, 1) / (2, 3) of the fragment
+  const unsigned xr0 = lds0 + (unsigned)((ont * 64 + okq * 16 + li) * 16) + (((unsigned)kq + 2u * xhi) & 3u) * 4u;
 
   const int regs_x = a.tiles_x, regs_xy = a.tiles_x * a.tiles_y;
   const int nreg = regs_xy * a.N;
@@ -542,9 +553,11 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
         for (int ob = 0; ob < 4; ++ob)
           rv[oa][ob] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                                      rr, has_res ? vo : EGN_OOB, oa * rowpitch + ob * colpitch, 0));
-      w4_xwr<0 * 1024>(xw0, acc[0][0][mt]); w4_xwr<1 * 1024>(xw0, acc[0][1][mt]); w4_xwr<2 * 1024>(xw0, acc[0][2][mt]);
-      w4_xwr<3 * 1024>(xw0, acc[1][0][mt]); w4_xwr<4 * 1024>(xw0, acc[1][1][mt]); w4_xwr<5 * 1024>(xw0, acc[1][2][mt]);
-      w4_xwr<6 * 1024>(xw0, acc[2][0][mt]); w4_xwr<7 * 1024>(xw0, acc[2][1][mt]); w4_xwr<8 * 1024>(xw0, acc[2][2][mt]);
+#define W4_XW(SL, V) w4_xwr2<(SL)*1024>(xwa, (V)[0], (V)[1]); w4_xwr2<(SL)*1024>(xwb, (V)[2], (V)[3]);
+      W4_XW(0, acc[0][0][mt]) W4_XW(1, acc[0][1][mt]) W4_XW(2, acc[0][2][mt])
+      W4_XW(3, acc[1][0][mt]) W4_XW(4, acc[1][1][mt]) W4_XW(5, acc[1][2][mt])
+      W4_XW(6, acc[2][0][mt]) W4_XW(7, acc[2][1][mt]) W4_XW(8, acc[2][2][mt])
+#undef W4_XW
       asm volatile("" ::: "memory");
       __builtin_amdgcn_s_waitcnt(0xC07F);
       W4_CLK()    /* round: accumulators written */

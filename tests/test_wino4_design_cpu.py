@@ -91,18 +91,19 @@ def test_f43_convolution_identity_and_packed_filter_layout():
 
 
 def test_halo_slot_order_is_bank_conflict_free_for_the_transform_reads():
-    """8-byte slot of pixel (y, x), channel pair p: p * 720 + (x % 4) * 180 + y * 10 + x // 4.  Lane (tile (ty, tx) of
+    """8-byte slot of pixel (y, x), channel pair p: p * 721 + (x % 4) * 180 + y * 10 + x // 4 (the odd pair pitch is the
+    bank skew of the halo STORES, see test_halo_stores_are_bank_conflict_free).  Lane (tile (ty, tx) of
     an m-tile, channel kq of k-group g) reads dword kq & 1 of pair 2 g + kq // 2 at pixel (4 ty + i, 4 tx + j).  The
     hardware banks ds_read_b32 per 32-lane group on dword mod 32 (MI355X_MICROARCH.md): for every (i, j) each group
-    must hit 32 different banks; every (pixel, pair) has exactly one slot below 2880."""
+    must hit 32 different banks; every (pixel, pair) has exactly one slot below 2884."""
     def slot(p, y, x):
-        return p * 720 + (x % 4) * 180 + y * 10 + x // 4
+        return p * 721 + (x % 4) * 180 + y * 10 + x // 4
     seen = set()
     for p in range(4):
         for y in range(18):
             for x in range(34):
                 s = slot(p, y, x)
-                assert 0 <= s < 2880 and s not in seen
+                assert 0 <= s < 2884 and s not in seen
                 seen.add(s)
     for mt in range(2):
         for g in range(2):
@@ -120,18 +121,20 @@ def test_halo_slot_order_is_bank_conflict_free_for_the_transform_reads():
 
 def test_halo_slot_order_of_the_16x16_region_geometry():
     """conv_wino4b_kernel (GEO 1): 18 x 18 halo pixels x 16 channels = 8 channel-pair planes,
-    slot = p * 360 + (x % 4) * 90 + y * 5 + x // 4.  Lane (tile (ty, tx) of the 4 x 4 tiles, channel kq of k-group g) reads
+    slot = p * 394 + (x % 4) * 97 + y * 5 + x // 4 (plane / pair pitches padded for the stores' banks).  Lane (tile
+    (ty, tx) of the 4 x 4 tiles, channel kq of k-group g) reads
     dword kq & 1 of pair 2 g + kq // 2 at pixel (4 ty + i, 4 tx + j): dword = 40 ty + 2 tx + (kq & 1) + const -- ty adds
     8 banks, so every 32-lane group hits 32 different banks for every (i, j); the load lane of element
-    e = (wave + 12 k) * 64 + lane fetches pixel e // 4, channel quad e % 4 and stores pairs 2 q, 2 q + 1."""
+    e = (wave + 12 k) * 64 + lane fetches element e // 4 of the 18 x 20 (row-padded) pixel list, channel quad e % 4, and
+    stores pairs 2 q, 2 q + 1."""
     def slot(p, y, x):
-        return p * 360 + (x % 4) * 90 + y * 5 + x // 4
+        return p * 394 + (x % 4) * 97 + y * 5 + x // 4
     seen = set()
     for p in range(8):
         for y in range(18):
             for x in range(18):
                 s = slot(p, y, x)
-                assert 0 <= s < 2880 and s not in seen
+                assert 0 <= s < 3152 and s not in seen
                 seen.add(s)
     assert len(seen) == 8 * 18 * 18
     for g in range(4):
@@ -151,9 +154,76 @@ def test_halo_slot_order_of_the_16x16_region_geometry():
             for lane in range(64):
                 e = (wave + 12 * k) * 64 + lane
                 px, q = e // 4, e % 4
-                if px < 18 * 18:
-                    got.add((px, q))
+                hy, hx = divmod(px, 20)
+                if hy < 18 and hx < 18:
+                    assert (hy, hx, q) not in got
+                    got.add((hy, hx, q))
     assert len(got) == 18 * 18 * 4
+
+
+@pytest.mark.parametrize('geo', [0, 1])
+def test_halo_stores_are_bank_conflict_free(geo):
+    """The halo goes global -> registers -> LDS: lane e of a load piece holds 16 bytes (a channel quad) of one pixel and
+    stores its two channel pairs with two ds_write_b64 (pair planes 2 q and 2 q + 1).  ds_write_b64 is served in groups of
+    16 contiguous lanes, bank = dword mod 32 (MI355X_MICROARCH.md): a group = 8 aligned pixels x 2 quads (GEO 0) or 4
+    aligned pixels x 4 quads (GEO 1) -- the row pitch of the element list is padded to 40 / 20 for that -- must hit 32
+    different banks.  Round 3's pitches (pair 720 / 360, plane 180 / 90, unpadded rows) put the quads of a pixel on ONE
+    bank: 2- / 4-way conflicts on every halo store (SQ_LDS_BANK_CONFLICT 1.26 M cycles per launch)."""
+    RH, RW, RWP, XD = 18, (18 if geo else 34), (20 if geo else 40), (5 if geo else 10)
+    PLANE, PAIR, QPP = (97 if geo else 180), (394 if geo else 721), (4 if geo else 2)
+    full = 0
+    for k in range(2):
+        for wave in range(12):
+            for grp in range(4):
+                for second in (0, 1):
+                    banks, valid = [], 0
+                    for lane in range(grp * 16, grp * 16 + 16):
+                        e = (wave + 12 * k) * 64 + lane
+                        px, hq = divmod(e, QPP)
+                        hy, hx = divmod(px, RWP)
+                        if hy < RH and hx < RW:
+                            valid += 1
+                            sl = (2 * hq + second) * PAIR + (hx & 3) * PLANE + hy * XD + (hx >> 2)
+                            banks += [(2 * sl) % 32, (2 * sl + 1) % 32]
+                    if valid == 16:
+                        full += 1
+                        assert len(set(banks)) == 32, (geo, k, wave, grp)
+                    else:                       # row tails / lanes past the halo (parked): the valid lanes still never collide
+                        assert len(set(banks)) == len(banks), (geo, k, wave, grp)
+    assert full >= (136 if geo else 140)
+
+
+def test_exchange_rotation_makes_the_output_reads_bank_conflict_free():
+    """Item end: writer lane (li_w, kq_w) parks its C fragment (tiles 4 kq_w .. + 3 of channel li_w) as a float4 in slot
+    `lane` of [point][co sub-tile][64 slots]; reader lane (li, kq) of wave (ont, okq) takes tile 4 okq + kq = element kq
+    of slot 16 okq + li.  Plain float4 slots: dword 4 li + kq -> li and li + 8 share a bank (2-way on all 36 reads).
+    Writers with li_w >= 8 rotate their float4 by two dwords, the reader looks at dword (kq + 2 (li >> 3)) & 3: the 32
+    lanes of a ds_read_b32 group hit 32 banks, and every reader still gets tile 4 okq + kq."""
+    store = {}
+    for lane_w in range(64):
+        li_w, kq_w = lane_w & 15, lane_w >> 4
+        rot = 2 * (li_w >> 3)
+        for r in range(4):
+            store[(lane_w, (r + rot) & 3)] = (4 * kq_w + r, li_w)        # dword position -> (tile, channel)
+    for okq in range(4):
+        for half in (range(0, 32), range(32, 64)):
+            banks = set()
+            for lane in half:
+                li, kq = lane & 15, lane >> 4
+                pos = (kq + 2 * (li >> 3)) & 3
+                slot_ = 16 * okq + li
+                assert store[(slot_, pos)] == (4 * okq + kq, li)
+                banks.add((4 * slot_ + pos) % 32)
+            assert len(banks) == 32
+    # the writers' two ds_write_b64 (16-lane groups): elements (0, 1) at +8 * hi, (2, 3) at +8 - 8 * hi
+    for grp in range(4):
+        for first in (True, False):
+            banks = []
+            for lane in range(grp * 16, grp * 16 + 16):
+                hi = (lane & 15) >> 3
+                off = (2 * hi if first else 2 - 2 * hi)
+                banks += [(4 * lane + off) % 32, (4 * lane + off + 1) % 32]
+            assert len(set(banks)) == 32
 
 
 def test_wino4b_reads_the_same_filter_pack_in_k_group_pairs():
