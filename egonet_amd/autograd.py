@@ -130,11 +130,34 @@ class HRNetAutograd(TapeOwner):
         return views
 
 
+class _Pending(object):
+    """One train-mode forward whose backward has not run.  The bridge's in-kernel dropout needs "at most one forward
+    pending"; a forward whose graph is DROPPED without a backward (a metrics forward in train mode, an exception
+    between forward and backward, a discarded micro-batch) must release its claim too, or the bridge would fall back
+    to torch-generated masks for the rest of its life: the token lives in the autograd node's context and
+    gives the count back when that context dies, whichever way."""
+    __slots__ = ('bridge', 'live')
+
+    def __init__(self, bridge):
+        self.bridge, self.live = bridge, True
+        bridge._pending += 1
+
+    def release(self):
+        if self.live:
+            self.live = False
+            self.bridge._pending = max(0, self.bridge._pending - 1)
+
+    def __del__(self):
+        self.release()
+
+
 class _LifterFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, bridge, x, *params):
         pred, saved = bridge._fwd(x)
         ctx.bridge, ctx.saved = bridge, saved
+        ctx.token = bridge._last_token
+        bridge._last_token = None
         return pred
 
     @staticmethod
@@ -143,7 +166,10 @@ class _LifterFn(torch.autograd.Function):
         saved, ctx.saved = ctx.saved, None
         if saved is None:
             raise RuntimeError('egonet_amd lifter autograd node: backward called twice')
-        return (None, None) + tuple(ctx.bridge._bwd(saved, gout))
+        try:
+            return (None, None) + tuple(ctx.bridge._bwd(saved, gout))
+        finally:
+            ctx.token.release()
 
 
 class LifterAutograd(LifterTrainStep):
@@ -191,6 +217,7 @@ class LifterAutograd(LifterTrainStep):
         self.drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         self.drop_step = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._pending = 0
+        self._last_token = None
 
     @property
     def p(self):                      # the module's dropout probability, live (nn.Dropout.p may be edited)
@@ -221,7 +248,7 @@ class LifterAutograd(LifterTrainStep):
             self.rng_dropout = LifterTrainStep.rng_dropout and self._pending == 0
             if self.rng_dropout:
                 self.drop_step.add_(1)
-            self._pending += 1
+            self._last_token = _Pending(self)          # handed to the autograd node's context by _LifterFn.forward
             pred, saved = self._forward(x, fresh=True)
             invalidate(self.model)
         return pred, saved
@@ -239,7 +266,6 @@ class LifterAutograd(LifterTrainStep):
                 views.append(v)
                 off += sz
             self._backward(saved, gout.contiguous().float())
-            self._pending = max(0, self._pending - 1)
             self.packs.finalize()
             self._grads = None
         return views

@@ -1793,6 +1793,15 @@ static int wino9_launch_nt(ConvArgs a, size_t lds, hipStream_t stream) {
     EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino9_kernel<TH, TW, TNB, NW, NT, CLK, KQ>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
   }
+  // the kernel divides its item / tile indices by nct, tiles_x * tiles_y and tiles_x with ONE multiply-high by
+  // ceil(2^32 / d): exact while dividend * d < 2^32.  Dividends stay below (tiles + 8) * nct; shapes beyond that bound
+  // (far outside the 2 GB tensor guards for any HRNet map, but a legal call) are refused, not mis-decoded
+  {
+    const unsigned long long nct_ = (unsigned long long)(a.Cout / (16 * NT));
+    const unsigned long long ntile_ = (unsigned long long)a.tiles_x * a.tiles_y * ((a.N + TNB - 1) / TNB) + 8;
+    if (ntile_ * nct_ * nct_ >= 0x100000000ull || ntile_ * (unsigned long long)(a.tiles_x * a.tiles_y) >= 0x100000000ull)
+      return EGN_E_BADARG;
+  }
   a.mg_nct = wino_magic(a.Cout / (16 * NT));
   a.mg_txy = wino_magic(a.tiles_x * a.tiles_y);
   a.mg_tx = wino_magic(a.tiles_x);

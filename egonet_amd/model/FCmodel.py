@@ -74,8 +74,12 @@ class FCModel(nn.Module):
         # train mode under autograd (the reference's hot loop, libs/trainer/trainer.py:183-209, unchanged):
         # one autograd node on the native kernels (egonet_amd.autograd.LifterAutograd)
         import os
+        # (submodule hooks would not fire inside the single native node, DataParallel replicas would rebuild the
+        # bridge on every forward: both take the module's torch graph -- see PoseHighResolutionNet._native_autograd_ok)
+        from .heatmapModel.hrnet import _has_submodule_hooks
         return (x.is_cuda and self.training and torch.is_grad_enabled() and not x.requires_grad and x.shape[0] > 1
                 and os.environ.get('EGONET_AMD_AUTOGRAD', '1') != '0'
+                and not getattr(self, '_is_replica', False) and not _has_submodule_hooks(self)
                 and all(p.requires_grad for p in self.parameters()))
 
     def _autograd_bridge(self):

@@ -25,6 +25,17 @@ logger = logging.getLogger(__name__)
 _MOMENTUM = 0.1
 
 
+
+def _has_submodule_hooks(module):
+    """True if any SUBmodule carries a forward / backward hook (hooks on the module itself fire around its forward
+    whichever path runs inside)."""
+    for m in module.modules():
+        if m is module:
+            continue
+        if m._forward_hooks or m._forward_pre_hooks or m._backward_hooks or getattr(m, '_backward_pre_hooks', None):
+            return True
+    return False
+
 def _conv(cin, cout, k, stride=1, bias=False):
     return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=(k - 1) // 2, bias=bias)
 
@@ -268,8 +279,15 @@ class PoseHighResolutionNet(nn.Module):
     hip_eval = True          # eval-mode CUDA forwards run the HIP program (see forward)
 
     def _native_autograd_ok(self):
+        """The train-mode bridge runs ONE autograd node on the native tape: the nn.Module graph below this module is
+        not executed.  Whatever needs that graph takes the module's torch forward instead (explicit opt-outs, never a
+        silent difference): forward / backward hooks on any submodule (they would not fire), nn.DataParallel replicas
+        (a replica is re-created on every forward, so its bridge -- walker, packed filters, side stream -- would be
+        rebuilt per step; the rank-per-GPU launcher is the performance path), head variants the tape does not cover."""
         return (os.environ.get('EGONET_AMD_AUTOGRAD', '1') != '0' and not self.pixel_shuffle
                 and self.head_type in ('coordinates', 'heatmap')
+                and not getattr(self, '_is_replica', False)
+                and not _has_submodule_hooks(self)
                 and any(p.requires_grad for p in self.parameters()))
 
     def _autograd_bridge(self):

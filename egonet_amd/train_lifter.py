@@ -36,6 +36,16 @@ class _Unit(object):
         self.inf, self.outf = fc.in_features, fc.out_features
 
 
+def _rank_mixed_seed(seed):
+    """seed ^ rank * golden-ratio constant, kept inside 62 bits (rank 0 / no process group: the seed itself)."""
+    try:
+        import torch.distributed as dist
+        rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    except Exception:
+        rank = 0
+    return (seed ^ ((rank * 0x9E3779B97F4A7C15) & ((1 << 62) - 1))) & ((1 << 62) - 1)
+
+
 class LifterTrainStep(object):
     # dense layers on csrc/gemm.hip where the shape allows (EGONET_AMD_GEMM=0: the conv-kernel route everywhere);
     # tile variant per form (NT, NN, TN), the fastest of tools/gemm_probe.py on 4096 x 1024 x 1024 [MI355X r3]:
@@ -43,6 +53,7 @@ class LifterTrainStep(object):
     # dropout keep masks drawn inside the BatchNorm / ReLU kernels (EGONET_AMD_RNG_DROPOUT=0: a torch-generated mask
     # tensor per unit, the round-2 route)
     rng_dropout = os.environ.get('EGONET_AMD_RNG_DROPOUT', '1') != '0'
+    _layer_epoch = 0          # Philox 'layer' word = unit + 16 * (non-updating forwards since the last optimizer step)
     use_gemm = os.environ.get('EGONET_AMD_GEMM', '1') != '0'
     gemm_variant = [int(v) for v in os.environ.get('EGONET_AMD_GEMM_VARIANTS', '3,0,1').split(',')]
 
@@ -69,8 +80,13 @@ class LifterTrainStep(object):
         self.flat = FlatParams(model.parameters())
         # in-kernel dropout: the seed comes from torch's generator at construction (torch.manual_seed makes a run
         # reproducible), the per-iteration counter is the optimizer's device-resident step counter
-        self.drop_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        # Data-parallel ranks seeded alike (torch.manual_seed(s) on every rank) must not draw the same keep masks:
+        # the reference's DataParallel replicas use per-device generators.  The rank is mixed into the seed.
+        self.drop_seed = _rank_mixed_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
         self.drop_step = self.flat.step_dev
+        # steps that do not update (update=False) leave the optimizer's counter alone: a host-side count of such
+        # forwards since the last update goes into the Philox "layer" word, so that they do not repeat a mask
+        self._noupdate_forwards = 0
         # every Linear weight as a 1x1 conv filter [out, in, 1, 1] (views of the flat buffer): from the second
         # step on all forward / data-gradient packs of the iteration are ONE launch (train_hrnet.PackedFilters)
         from .train_hrnet import PackedFilters
@@ -254,7 +270,7 @@ class LifterTrainStep(object):
                 # regenerate it -- no mask tensor, no RNG kernel in the step
                 _lib.check(L.egn_bn_act_fwd_drop_f32(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(u.bn.weight),
                                                      _lib.ptr(u.bn.bias), self.p, self.drop_seed, _lib.ptr(self.drop_step),
-                                                     ui, self.act, None, _lib.ptr(y), B, u.outf, u.outf, st),
+                                                     ui + 16 * self._layer_epoch, self.act, None, _lib.ptr(y), B, u.outf, u.outf, st),
                            'bn_act_fwd_drop')
             else:
                 if self.p > 0:
@@ -314,12 +330,14 @@ class LifterTrainStep(object):
             dz = buf('dz%d' % ui, B, u.outf)     # per unit: the side stream reads it until the join
             if keep != 1.0 and mask is None:     # the forward drew its mask in the kernel: same (seed, unit, step) here
                 _lib.check(L.egn_bn_bwd_sums_drop_f32(_lib.ptr(d_y), _lib.ptr(z), self.p, self.drop_seed,
-                                                      _lib.ptr(self.drop_step), ui, _lib.ptr(mean), _lib.ptr(istd),
+                                                      _lib.ptr(self.drop_step), ui + 16 * self._layer_epoch, _lib.ptr(mean),
+                                                      _lib.ptr(istd),
                                                       _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), self.act, None, B,
                                                       u.outf, u.outf, _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(ws), st),
                            'bn_bwd_sums_drop')
                 _lib.check(L.egn_bn_bwd_dz_drop_f32(_lib.ptr(d_y), _lib.ptr(z), self.p, self.drop_seed,
-                                                    _lib.ptr(self.drop_step), ui, _lib.ptr(mean), _lib.ptr(istd),
+                                                    _lib.ptr(self.drop_step), ui + 16 * self._layer_epoch, _lib.ptr(mean),
+                                                      _lib.ptr(istd),
                                                     _lib.ptr(u.bn.weight), _lib.ptr(u.bn.bias), self.act, None,
                                                     _lib.ptr(dbeta), _lib.ptr(dgamma), _lib.ptr(dz), None, B, u.outf,
                                                     u.outf, st), 'bn_bwd_dz_drop')
@@ -353,6 +371,7 @@ class LifterTrainStep(object):
         target = target.contiguous().float()
         with torch.cuda.device(dev):
             st = self._st()
+            self._layer_epoch = self._noupdate_forwards        # (0 in a training loop: every step updates)
             pred, ctx = self._forward(x)
             B, no = ctx[0], self.final.out_features
             # loss + gradient of the prediction
@@ -369,6 +388,9 @@ class LifterTrainStep(object):
                 self.grad_sync(self.flat.grad)
             if update:
                 self.flat.update(self, st)
+                self._noupdate_forwards = 0
+            else:                             # the optimizer's step counter did not move: the next masks must
+                self._noupdate_forwards += 1
             self.packs.finalize()             # first step: the set of filters is known now
             # weights and BatchNorm buffers were written through raw pointers: eval-mode forwards
             # between steps (eval_during, EgoNet.L after fine-tuning) must re-fold them

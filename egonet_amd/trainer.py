@@ -67,6 +67,30 @@ def _barrier():
         dist.barrier()
 
 
+_HOST_GROUP = None
+
+
+def _wait_for_rank0():
+    """Ranks != 0 wait here while rank 0 validates.  A host-side (gloo) group with a long timeout is used where it can
+    be made: a GPU barrier kernel would sit on the device for the whole validation and is subject to the NCCL watchdog
+    timeout of the training group.  Falls back to the default group's barrier."""
+    global _HOST_GROUP
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    if _HOST_GROUP is None:
+        import datetime
+        try:
+            # collective: every rank reaches its first wait in the same place of the loop
+            _HOST_GROUP = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=12))
+        except Exception:
+            _HOST_GROUP = False
+    if _HOST_GROUP:
+        dist.barrier(group=_HOST_GROUP)
+    else:
+        dist.barrier()
+
+
 def _optim_kwargs(optim, cfgs):
     """optimizer family / momentum / weight decay of the native update, from the torch optimizer object
     ``prepare_optim`` made (or, without one, from cfgs['optimizer'])."""
@@ -287,10 +311,15 @@ def train(train_dataset, model, loss_func, optim, sche, cfgs, logger, metric_fun
                 if eval_during and epoch > eval_start and batch_idx and eval_every and batch_idx % eval_every == 0:
                     parallel.broadcast_buffers(model, src=0)    # running statistics follow rank 0 (DataParallel semantics)
                     # every rank holds the same weights and (now) buffers: rank 0 evaluates the validation set
-                    # (ts['eval_all_ranks'] restores one evaluation per rank), the others wait at the barrier
+                    # (ts['eval_all_ranks'] restores one evaluation per rank), the others wait for it.
+                    # CONTRACT: unless 'eval_all_ranks' is set, `evaluate_fn` runs on rank 0 ONLY -- it must
+                    # not contain collectives or DistributedSampler logic (they would wait for ranks that never call
+                    # them).  The waiting ranks block on a HOST-side broadcast of a done flag (gloo-style object
+                    # broadcast over the default group), not on a GPU barrier kernel, and the wait is bounded by the
+                    # process group's own timeout: choose `timeout=` in init_process_group for the longest validation.
                     if _rank() == 0 or ts.get('eval_all_ranks', False):
                         evaluate_fn(valid_dataset, model, epoch)
-                    _barrier()
+                    _wait_for_rank0()
                     model.train()
             if epoch in ts.get('snapshot_epochs', []):
                 parallel.broadcast_buffers(model, src=0)

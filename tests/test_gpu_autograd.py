@@ -205,3 +205,37 @@ def test_lifter_bridge_with_dropout_and_two_forwards_before_backward():
     torch.manual_seed(0)
     pc.sum().backward()
     assert float(dict(net.named_parameters())['w2.bias'].grad.abs().max()) > 0
+
+
+def test_lifter_bridge_releases_a_forward_whose_graph_is_dropped():
+    """a train-mode forward that never sees a backward (a metrics forward, an exception between forward and
+    backward, a discarded micro-batch) must not leave the bridge believing a forward is pending for the rest of its
+    life -- that silently switched the in-kernel dropout off.  The claim lives in the autograd node's context and is
+    returned when the context dies."""
+    import gc
+    cfg = configs.tiny_config()
+    cfg['FCModel']['dropout'] = 0.5
+    net = hip_fc.get_fc_model(1, cfg, 10, 12)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=4))
+    net = net.cuda().train()
+    x = torch.randn(16, 10, generator=torch.Generator().manual_seed(3)).cuda()
+    p = net(x)
+    br = net._autograd_bridge()
+    assert br._pending == 1 and br.rng_dropout
+    del p                                     # the graph goes away without a backward
+    gc.collect()
+    assert br._pending == 0
+    for _ in range(3):                        # dropped forwards do not accumulate
+        net(x)
+    gc.collect()
+    assert br._pending == 0
+    q = net(x)
+    assert br.rng_dropout, 'the in-kernel dropout path is back after dropped forwards'
+    q.sum().backward()
+    assert br._pending == 0
+    # a forward that IS pending still sends the next one to mask tensors (two forwards, two backwards)
+    a = net(x)
+    b = net(x)
+    assert br._pending == 2 and not br.rng_dropout
+    (a.sum() + b.sum()).backward()
+    assert br._pending == 0

@@ -112,3 +112,52 @@ def test_forward_hooks_fire_like_get_model_summary_expects():
     for h in hooks:
         h.remove()
     assert sorted(calls) == sorted(id(m) for m in leaves)
+
+
+def test_autograd_bridge_opt_outs_are_explicit():
+    """the train-mode bridge replaces the module graph by ONE native autograd node, so anything that
+    needs the graph must take the torch forward: submodule hooks (they would not fire) and nn.DataParallel replicas
+    (re-created every forward: the bridge would be rebuilt per step).  Checked on the predicate (no GPU needed)."""
+    import torch
+    from egonet_amd import configs
+    from egonet_amd.model.heatmapModel import hrnet as hip_hrnet
+    from egonet_amd.model import FCmodel as hip_fc
+    net = hip_hrnet.get_pose_net(configs.tiny_config('coordinates'), is_train=True)
+    assert net._native_autograd_ok()
+    h = net.stage2[0].branches[0][0].conv1.register_forward_hook(lambda m, i, o: None)
+    assert not net._native_autograd_ok()
+    h.remove()
+    assert net._native_autograd_ok()
+    h = net.layer1[0].register_full_backward_hook(lambda m, gi, go: None)
+    assert not net._native_autograd_ok()
+    h.remove()
+    h = net.register_forward_hook(lambda m, i, o: None)          # a hook on the module ITSELF fires either way
+    assert net._native_autograd_ok()
+    h.remove()
+    net._is_replica = True                                        # what torch.nn.parallel.replicate sets
+    assert not net._native_autograd_ok()
+    del net._is_replica
+
+    class _X(object):                                             # the lifter's predicate looks at the input too
+        is_cuda, requires_grad, shape = True, False, (8, 10)
+    lif = hip_fc.get_fc_model(1, configs.tiny_config(), 10, 12).train()
+    assert lif._native_autograd_ok(_X())
+    h = lif.res_blocks[0].w1.register_forward_pre_hook(lambda m, i: None)
+    assert not lif._native_autograd_ok(_X())
+    h.remove()
+    assert lif._native_autograd_ok(_X())
+
+
+def test_dropout_seed_is_mixed_with_the_rank(monkeypatch):
+    """Data-parallel ranks seeded alike must not draw identical keep masks (the reference's DataParallel replicas use
+    per-device generators): seed ^ rank * golden ratio, rank 0 / single process unchanged."""
+    import torch.distributed as dist
+    from egonet_amd import train_lifter
+    s = 0x1234567890ABCDEF & ((1 << 62) - 1)
+    assert train_lifter._rank_mixed_seed(s) == s
+    monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+    seeds = []
+    for r in range(4):
+        monkeypatch.setattr(dist, 'get_rank', lambda r=r: r)
+        seeds.append(train_lifter._rank_mixed_seed(s))
+    assert seeds[0] == s and len(set(seeds)) == 4 and all(0 <= v < (1 << 62) for v in seeds)
