@@ -599,11 +599,18 @@ class HRNetTrainStep(TapeOwner):
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, w_hm=1.0, w_coor=0.1, grad_sync=None,
                  sigma=1, w_cr=None, cr_type='sl1', cr_indices=None, target_cr=4.0 / 3.0, cr_loss_thres=0.15,
-                 hm_type='mse', coor_type='l1', optim_type='adam', momentum=0.0, weight_decay=0.0):
+                 hm_type='mse', coor_type='l1', optim_type='adam', momentum=0.0, weight_decay=0.0,
+                 use_target_weight=False):
         self._init_tape_owner(model)
         p0 = next(model.parameters())
         if model.head_type == 'heatmap' and w_coor:
             raise NotImplementedError("the 'heatmap' head trains with the heat-map term only (w_coor=0)")
+        # JointsMSELoss(use_target_weight) (function.py:22-46, the heat-map head's criterion): both maps are multiplied
+        # by target_weight[:, k] before the per-joint MSE.  JointsCompositeLoss (the coordinate head) stores the flag and
+        # never uses it (function.py:95-111), so there it changes nothing -- like the reference.
+        self.use_target_weight = bool(use_target_weight) and model.head_type == 'heatmap'
+        if self.use_target_weight and hm_type != 'mse':
+            raise NotImplementedError('JointsMSELoss is an MSE criterion (function.py:24-26)')
         self.lr, self.betas, self.eps = lr, betas, eps
         if optim_type not in ('adam', 'sgd'):
             raise NotImplementedError('optimizer %r (optimizer.py:8-40 knows adam and sgd)' % (optim_type,))
@@ -637,7 +644,7 @@ class HRNetTrainStep(TapeOwner):
         self.last_maps = self.last_coords = None
 
     @torch.no_grad()
-    def step(self, images, target, joints_xy=None, update=True, joints_vis=None):
+    def step(self, images, target, joints_xy=None, update=True, joints_vis=None, target_weight=None):
         """images [N,3,H,W], target [N,K,h,w] heat-maps (None: drawn on the device from
         joints_xy / joints_vis with ``self.sigma``), joints_xy [N,K,2] in input pixels
         (``meta['transformed_joints'][:, :, :2]``).  Returns the loss as a 1-element
@@ -648,9 +655,9 @@ class HRNetTrainStep(TapeOwner):
         that step's time; between steps it hides behind the queued work.  Nothing here needs it -- the
         tape's reference cycles are broken explicitly (``_Tape.release``)."""
         with _gc_paused():
-            return self._step(images, target, joints_xy, update, joints_vis)
+            return self._step(images, target, joints_xy, update, joints_vis, target_weight)
 
-    def _step(self, images, target, joints_xy, update, joints_vis):
+    def _step(self, images, target, joints_xy, update, joints_vis, target_weight=None):
         m, L = self.model, self.L
         if not m.training:
             raise RuntimeError('HRNetTrainStep.step needs model.train()')
@@ -720,10 +727,24 @@ class HRNetTrainStep(TapeOwner):
             tg = tape._empty(n * aug.h * aug.w * aug.cs)
             _lib.check(L.egn_nchw_to_nhwc_f32(_lib.ptr(target), _lib.ptr(tg), n, J, aug.h, aug.w, aug.cs, st))
             da = torch.zeros(n * aug.h * aug.w * aug.cs, dtype=torch.float32, device=self.dev)
+            pred_flat = tape.data[id(aug)]
+            wv = None
+            if self.use_target_weight:
+                # 0.5 * mean((pred * w - gt * w)^2): the same kernel on the weighted maps, gradient * w afterwards
+                # (three broadcast multiplies over [N,h,w,K]; an option no shipped configuration switches on)
+                tw = target_weight if target_weight is not None else self.last_target_weight
+                if tw is None:
+                    raise ValueError('use_target_weight needs target_weight [N,K(,1)] (or device-drawn targets)')
+                wv = torch.zeros(n, 1, 1, aug.cs, dtype=torch.float32, device=self.dev)
+                wv[:, 0, 0, :J] = torch.as_tensor(tw, dtype=torch.float32).reshape(n, J).to(self.dev)
+                pred_flat = (pred_flat.view(n, aug.h, aug.w, aug.cs) * wv).reshape(-1)
+                tg = (tg.view(n, aug.h, aug.w, aug.cs) * wv).reshape(-1)
             # (1/K) sum_k 0.5*crit_k = 0.5 * crit over all joints (equal element counts), function.py:95-111
-            _lib.check(L.egn_elem_loss_f32(_lib.ptr(tape.data[id(aug)]), _lib.ptr(tg), n * aug.h * aug.w, J, aug.cs,
+            _lib.check(L.egn_elem_loss_f32(_lib.ptr(pred_flat), _lib.ptr(tg), n * aug.h * aug.w, J, aug.cs,
                                            aug.cs, self.hm_crit, 0.5 * self.w_hm, 0, _lib.ptr(da),
                                            _lib.ptr(self.loss_dev), st), 'hm loss')
+            if wv is not None:
+                da = (da.view(n, aug.h, aug.w, aug.cs) * wv).reshape(-1)
             tape._accum(aug, da)
             # the gradient all-reduce of a slice of the flat buffer starts (on a communication
             # stream) as soon as every parameter in it has its gradient kernels issued

@@ -167,6 +167,9 @@ def make_step(model, cfgs, loss_func=None, optim=None):
         sigma = cfgs.get('heatmapModel', {}).get('sigma', 1)
         if inner.head_type == 'heatmap':
             w_coor, cr = 0.0, {k: v for k, v in cr.items() if k == 'hm_type'}
+            # JointsMSELoss(use_target_weight=...) (tools/train_IGRs.py:42, function.py:22-46)
+            cr['use_target_weight'] = bool(getattr(loss_func, 'use_target_weight',
+                                                   cfgs.get('training_settings', {}).get('use_target_weight', False)))
         cr.update(_optim_kwargs(optim, cfgs))
         step = HRNetTrainStep(inner, lr=lr, w_hm=w_hm, w_coor=w_coor, grad_sync=sync, sigma=sigma, **cr)
         step.apply_cr_loss = bool(getattr(loss_func, 'apply_cr_loss', False))
@@ -281,7 +284,8 @@ def train(train_dataset, model, loss_func, optim, sche, cfgs, logger, metric_fun
                 target = target.to(dev, non_blocking=True)
                 if is_hc:
                     joints = meta['transformed_joints'] if step.w_coor else None
-                    loss = step.step(data, target, joints)
+                    loss = step.step(data, target, joints,
+                                     target_weight=weights if step.use_target_weight else None)
                     prediction = (step.last_maps, step.last_coords) if step.last_coords is not None else step.last_maps
                 else:
                     loss = step.step(data, target)

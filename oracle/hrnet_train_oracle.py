@@ -49,6 +49,24 @@ def cross_ratio_loss(coords, cr_indices, target_cr=4.0 / 3.0, threshold=0.15, cr
     return (line * mask).sum() / mask.sum()
 
 
+def joints_mse_loss(maps, target, target_weight=None):
+    """JointsMSELoss (libs/loss/function.py:22-46), the criterion of the heat-map head: per joint
+    0.5 * mean((pred - gt)^2), with ``use_target_weight`` both maps multiplied by target_weight[:, k] first
+    (invisible joints, weight 0, drop out); mean over the joints.  Pinned on the reference's own class
+    (tests/golden/jmse_loss.npz)."""
+    n, k = maps.shape[:2]
+    pred = maps.reshape(n, k, -1)
+    gt = target.reshape(n, k, -1)
+    loss = 0
+    for j in range(k):
+        if target_weight is not None:
+            w = target_weight[:, j].reshape(n, 1)
+            loss = loss + 0.5 * F.mse_loss(pred[:, j] * w, gt[:, j] * w, reduction='mean')
+        else:
+            loss = loss + 0.5 * F.mse_loss(pred[:, j], gt[:, j], reduction='mean')
+    return loss / k
+
+
 def composite_loss(out, target, joints_xy, img_size, w_hm=1.0, w_coor=0.1, w_cr=None, cr_indices=None,
                    target_cr=4.0 / 3.0, cr_loss_thres=0.15, cr_type='sl1', hm_type='mse', coor_type='l1'):
     """out = (maps [N,K,H,W], coords [N,K,2]); target [N,K,H,W]; joints_xy [N,K,2] in
@@ -99,10 +117,14 @@ class HRNetTrainOracle(object):
         else:
             self.opt = torch.optim.Adam(params, lr=lr, weight_decay=o.get('weight_decay', 0.0))
 
-    def step(self, x, target, joints_xy, update=True):
+    def step(self, x, target, joints_xy, update=True, target_weight=None):
         self.opt.zero_grad()
         out = hrnet_oracle.hrnet_forward_train(self.sd, self.cfgs, x)
-        loss = composite_loss(out, target, joints_xy, self.cfgs['heatmapModel']['input_size'], *self.w, **self.cr)
+        if target_weight is not None:          # JointsMSELoss(use_target_weight=True): the heat-map head's criterion
+            assert not isinstance(out, tuple)
+            loss = joints_mse_loss(out, target, target_weight) * self.w[0]
+        else:
+            loss = composite_loss(out, target, joints_xy, self.cfgs['heatmapModel']['input_size'], *self.w, **self.cr)
         loss.backward()
         if update:
             self.opt.step()

@@ -19,6 +19,7 @@ seeded, construction-order independent) for the full-size W48 / lifter nets.
 Usage:  python tests/golden/make_golden.py            (from the repo root)
         --w48-pipeline only the full-size W48 end-to-end fixture (section 7b)
         --heads        only the pixel-shuffle / angle-regression head fixtures (section 3b)
+        --jmse         only the JointsMSELoss fixture (section 0f)
         --train-only   stop after the training-side fixtures (sections 0 .. 0e)
         --cr-only      stop after the cross-ratio / metric fixtures (0d, 0e)
 The generation is deterministic: re-running leaves the committed files byte-identical.
@@ -168,6 +169,29 @@ def main():
 
     if '--heads' in sys.argv:
         head_variants()
+        return
+
+    def joints_mse():
+        """---- 0f: the reference's JointsMSELoss (libs/loss/function.py:22-46) -- the heat-map head's criterion
+        (tools/train_IGRs.py builds it when the head is 'heatmap'), with and without use_target_weight: value and the
+        gradient w.r.t. the predicted maps, on random maps; weights incl. zeros (invisible joints)."""
+        import libs.loss.function as ref_loss_
+        g_ = torch.Generator().manual_seed(91)
+        n_, k_, h_, w_ = 4, 5, 8, 6
+        pred = torch.randn(n_, k_, h_, w_, generator=g_)
+        tgt = torch.rand(n_, k_, h_, w_, generator=g_)
+        tw = (torch.rand(n_, k_, 1, generator=g_) > 0.3).float() * (0.5 + torch.rand(n_, k_, 1, generator=g_))
+        arrs_ = dict(pred=pred.numpy(), target=tgt.numpy(), target_weight=tw.numpy())
+        for flag in (False, True):
+            p_ = pred.clone().requires_grad_(True)
+            loss = ref_loss_.JointsMSELoss(use_target_weight=flag)(p_, tgt, tw)
+            loss.backward()
+            arrs_['loss_%d' % int(flag)] = np.array(float(loss.detach()), dtype=np.float64)
+            arrs_['grad_%d' % int(flag)] = p_.grad.numpy()
+        save('jmse_loss.npz', **arrs_)
+
+    if '--jmse' in sys.argv:
+        joints_mse()
         return
 
     # ---- 0: two training iterations of the reference HRNet (train mode) with the
@@ -385,6 +409,7 @@ def main():
         save('hrnet_%s.npz' % tag, **arrs)
 
     head_variants()
+    joints_mse()
 
     # ---- 4: full W48, weights regenerated from synth ----------------------
     x = synth.synth_crops(4, 3, 256, 256, seed=11)

@@ -122,6 +122,31 @@ def test_heatmap_head_vs_oracle():
     assert cos > 0.9999 and gl2 < 1e-2 and med < 5e-3, (gl2, cos, med)
 
 
+def test_heatmap_head_with_target_weights_vs_oracle():
+    """JointsMSELoss(use_target_weight=True) (libs/loss/function.py:22-46, tools/train_IGRs.py:42): both maps times
+    target_weight[:, k] before the per-joint MSE -- invisible joints (weight 0) drop out of loss and gradient.  The
+    oracle's restatement is pinned on the reference's class (tests/golden/jmse_loss.npz)."""
+    cfg = configs.tiny_config('heatmap')
+    net, sd = _tiny_model(cfg, seed=5)
+    gen = torch.Generator().manual_seed(1)
+    x = synth.synth_crops(3, 3, 64, 64, seed=2)
+    tgt = torch.rand(3, 5, 16, 16, generator=gen)
+    tw = (torch.rand(3, 5, 1, generator=gen) > 0.3).float() * (0.5 + torch.rand(3, 5, 1, generator=gen))
+    assert float(tw.min()) == 0.0
+    orc = HRNetTrainOracle(sd, cfg, lr=1e-3, w_coor=0.0)
+    want_loss, want_maps, _ = orc.step(x, tgt, None, update=False, target_weight=tw)
+    plain_loss, _, _ = HRNetTrainOracle(sd, cfg, lr=1e-3, w_coor=0.0).step(x, tgt, None, update=False)
+    assert abs(want_loss - plain_loss) > 1e-3 * abs(plain_loss)
+    tr = HRNetTrainStep(net, lr=1e-3, w_coor=0.0, use_target_weight=True)
+    loss = tr.step(x.cuda(), tgt.cuda(), None, update=False, target_weight=tw.cuda())
+    assert abs(float(loss.item()) - want_loss) < 2e-5 * abs(want_loss)
+    np.testing.assert_allclose(tr.last_maps.cpu().numpy(), want_maps.numpy(), rtol=0, atol=2e-4)
+    gl2, cos, med = gradient_agreement(dict(net.named_parameters()), orc.grads())
+    assert cos > 0.9999 and gl2 < 1e-2 and med < 5e-3, (gl2, cos, med)
+    with pytest.raises(ValueError):
+        tr.step(x.cuda(), tgt.cuda(), None, update=False)            # the flag is on: the weights are required
+
+
 @pytest.mark.parametrize('hm_type,coor_type,optim', [
     ('sl1', 'mse', dict(optim_type='sgd', momentum=0.9, weight_decay=1e-3)),
     ('l1', 'sl1', dict(optim_type='adam', weight_decay=1e-2)),

@@ -266,3 +266,19 @@ def test_composite_loss_with_cross_ratio_vs_reference():
     np.testing.assert_allclose(float(loss), float(g['full/loss']), rtol=2e-6)
     np.testing.assert_allclose(c.grad.numpy(), g['full/dcoords'], rtol=0, atol=1e-6 * float(np.abs(g['full/dcoords']).max()))
     np.testing.assert_allclose(maps.grad.numpy(), g['full/dmaps'], rtol=0, atol=1e-9)
+
+
+def test_joints_mse_loss_oracle_vs_reference():
+    """oracle.hrnet_train_oracle.joints_mse_loss restates libs/loss/function.py:22-46 (JointsMSELoss, with and without
+    use_target_weight): value and gradient equal the reference's own class on tests/golden/jmse_loss.npz."""
+    import torch
+    from oracle import hrnet_train_oracle as hto
+    g = golden('jmse_loss.npz')
+    tgt, tw = torch.from_numpy(g['target']), torch.from_numpy(g['target_weight'])
+    for flag in (0, 1):
+        p = torch.from_numpy(g['pred']).clone().requires_grad_(True)
+        loss = hto.joints_mse_loss(p, tgt, tw if flag else None)
+        loss.backward()
+        assert abs(float(loss.detach()) - float(g['loss_%d' % flag])) < 1e-6 * abs(float(g['loss_%d' % flag]))
+        np.testing.assert_allclose(p.grad.numpy(), g['grad_%d' % flag], rtol=0, atol=1e-8)
+    assert float(g['loss_0']) != float(g['loss_1'])
