@@ -48,8 +48,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_HBM_GBPS = 8000.0
-# committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_r3.sh + tools/pmc_traffic.py), newest first
-TRAFFIC_JSONS = [os.path.join(ROOT, 'profiles', n) for n in ('r3_pmc_traffic.json', 'r2_pmc_traffic.json')]
+# committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_r4.sh + tools/pmc_traffic.py), newest first
+TRAFFIC_JSONS = [os.path.join(ROOT, 'profiles', n) for n in ('r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json')]
 WINO_EXECUTED = 16.0 / 36.0       # fused Winograd F(2x2,3x3): multiplies executed per direct-algorithm multiply
 WINO4_EXECUTED = 36.0 / 144.0     # F(4x4,3x3): 36 multiplies per 16 outputs instead of 144
 
@@ -67,6 +67,11 @@ def parse():
     p.add_argument('--no-train', action='store_true', help='skip the training blocks (configs 3 and 4)')
     p.add_argument('--train-batch', type=int, default=32, help='crops per GPU of the train_hc block')
     p.add_argument('--lifter-batch', type=int, default=4096)
+    p.add_argument('--live-traffic', action='store_true',
+                   help='measure roofline.traffic IN THIS RUN: two short child passes of the forward under '
+                        '`rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `WRITE_SIZE` (own runs, 120 s limit each; off by '
+                        'default: the driver\'s bench run must not depend on the profiler)')
+    p.add_argument('--traffic-child', action='store_true', help=argparse.SUPPRESS)
     p.add_argument('--dry-run', action='store_true',
                    help='launcher / rendezvous / timing-reduction plumbing only (no GPU work): what the CPU test of '
                         '`--gpus N` runs with EGONET_AMD_DIST_BACKEND=gloo')
@@ -194,6 +199,54 @@ def mfma_roofline(symbol, direct_tflops, executed_tflops):
     roof['traffic_source'] = None if traffic is None else \
         src + ' (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed; not re-measured in this run)'
     return roof
+
+
+def live_traffic(symbol, args):
+    """HBM bytes per launch of `symbol`, measured now: this script re-run as a short child (three forward passes of
+    the same program, `--traffic-child`) under rocprofv3 with ONE counter per run (FETCH_SIZE and WRITE_SIZE do not
+    fit one pass on gfx950), counters in their own runs with --kernel-trace only, FETCH_SIZE doubled
+    (MI355X_MICROARCH.md, HBM section).  Returns (bytes, description) or (None, reason)."""
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import pmc_traffic
+    exe = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not os.path.exists(exe):
+        return None, 'rocprofv3 not found'
+    vals = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        out = tempfile.mkdtemp(prefix='egn_pmc_', dir='/tmp')
+        cmd = [exe, '--kernel-trace', '--pmc', counter, '--output-format', 'csv', '-d', out, '--', sys.executable,
+               os.path.abspath(__file__), '--traffic-child', '--batch', str(args.batch), '--head', args.head]
+        try:
+            r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=120)
+            if r.returncode != 0:
+                return None, 'rocprofv3 --pmc %s exited with %d' % (counter, r.returncode)
+            per = pmc_traffic.per_kernel(out, counter)
+            if symbol not in per:
+                return None, '%s not in the %s pass' % (symbol, counter)
+            vals[counter] = sum(per[symbol]) / len(per[symbol])
+        except subprocess.TimeoutExpired:
+            return None, 'rocprofv3 --pmc %s timed out' % counter
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    return (2.0 * vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024.0, \
+        'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate child passes of the ' \
+        'same forward program, FETCH_SIZE doubled for gfx950)'
+
+
+def traffic_child(args):
+    """What live_traffic() profiles: the W48 forward + decode program of the bench, three passes."""
+    from egonet_amd import synth
+    torch.cuda.set_device(0)
+    cfg, ego, _, _ = build_model(args.head, torch.device('cuda', 0))
+    crops = synth.synth_crops(args.batch, 3, 256, 256, seed=100).cuda()
+    eng = ego.HC._hip_engine()
+    for _ in range(3):
+        eng.forward(crops, decode_mode=1 if args.head == 'heatmap' else None)
+    torch.cuda.synchronize()
 
 
 def cpu_baseline(cfg, hc_sd, l_sd, stats, head, seconds):
@@ -467,6 +520,8 @@ def main():
                          % (args.gpus, world, world))
     if args.dry_run:
         return dry_run(args, world, rank)
+    if args.traffic_child:
+        return traffic_child(args)
     dist = None
     backend = 'none'
     if world > 1:
@@ -552,6 +607,12 @@ def main():
         roof.update(launches=dom['launches'], avg_us=dom['avg_us'], time_share=dom['share'],
                     algorithmic_gflop_per_launch=dom['flops'] / dom['launches'] / 1e9,
                     algorithmic_mb_per_launch=dom['bytes'] / dom['launches'] / 1e6)
+        if args.live_traffic and world == 1:
+            lt, how = live_traffic(dom['name'], args)
+            if lt is not None:
+                roof['traffic'], roof['traffic_source'] = lt, how
+            else:
+                roof['traffic_live_error'] = how
         conv_flops = sum(a['flops'] for a in rows)
         conv_xflops = sum(a['xflops'] for a in rows)
 

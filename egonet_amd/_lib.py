@@ -115,6 +115,8 @@ SIGNATURES = {
     'egn_gemm_supported': (_i, [_i] * 7),
     'egn_gemm_ws_bytes': (C.c_long, [_i] * 4),
     'egn_gemm_f32': (_i, [_i, _p, _p, _p, _p] + [_i] * 7 + [_p, C.c_long, _p]),
+    'egn_gemm_stats_rows': (C.c_long, [_i]),
+    'egn_gemm_ex_f32': (_i, [_i, _p, _p, _p, _p, _p, _p, C.c_long] + [_i] * 7 + [_p, C.c_long, _p]),
     'egn_launch_count': (C.c_long, []),
     'egn_direct_conv_count': (C.c_long, []),
     'egn_program_op_info': (_i, [_p, _i, C.POINTER(_i), C.POINTER(_d), C.POINTER(_d), C.c_char_p, _i]),

@@ -49,6 +49,10 @@ struct GemmArgs {
   const float* B;
   float* C;           // [M][ldc], or the partial slabs [splits][M][N] when splits > 1
   const float* bias;  // [N] or null
+  // [r4] epilogue fusions of the lifter step (libs/model/FCmodel.py:33-43 under trainer.py:183-209):
+  const float* addend;  // NN form: C = A.B + addend (same ldc): the skip-path gradient of a residual block, no add pass
+  double* stats;        // NT form: partial column sums / sums of squares of the stored C, [tiles_m][2][N] doubles --
+                        // BatchNorm1d's batch statistics without a pass over z (finalised by egn_bn_stats_finalize_f32)
   int M, N, K;        // K = k range of ONE split
   int lda, ldb, ldc;
   int tiles_m, tiles_n, splits;
@@ -263,6 +267,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(GemmA
           const int col = n0 + wn * TN + q * 64 + 4 * li;
           f32x4 v = {acc[i][q * 4 + 0][r], acc[i][q * 4 + 1][r], acc[i][q * 4 + 2][r], acc[i][q * 4 + 3][r]};
           if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + col);
+          if (g.addend) v += *reinterpret_cast<const f32x4*>(g.addend + (size_t)row * g.ldc + col);
           *reinterpret_cast<f32x4*>(Cb + (size_t)row * g.ldc + col) = v;
         }
   } else {
@@ -273,6 +278,32 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(GemmA
     __builtin_amdgcn_s_barrier();                     // ... and everyone else's (the slabs alias the stage ring)
     float* sC = reinterpret_cast<float*>(smem) + wave * 16 * SLD;
     constexpr int C4 = TN / 4;                        // float4 per slab row
+    // column statistics of what is stored (z = a W^T + b): lane (li, kq) owns column 16 j + li of its wave tile for the
+    // rows 16 i + 4 kq + r -- sums in fp32 per lane (4 MT values), across kq by shuffles, across the WM waves of a
+    // column in doubles through a table behind the slabs, in a fixed order; the block writes ITS columns of row tm
+    double* sS = reinterpret_cast<double*>(reinterpret_cast<char*>(smem) + NW * 16 * SLD * 4);
+    static_assert(NW * 16 * SLD * 4 + NW * 2 * TN * 8 <= STAGES * ST_BYTES, "slabs + statistics table fit in the stage ring");
+    if (g.stats != nullptr) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float bj = g.bias ? g.bias[n0 + wn * TN + j * 16 + li] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = acc[i][j][r] + bj;
+            s1 += v;
+            s2 += v * v;
+          }
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+        if (kq == 0) {
+          sS[(wave * 2 + 0) * TN + j * 16 + li] = (double)s1;
+          sS[(wave * 2 + 1) * TN + j * 16 + li] = (double)s2;
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -289,6 +320,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(GemmA
         *reinterpret_cast<f32x4*>(Cb + (size_t)row * g.ldc + col) = v;
       }
       __builtin_amdgcn_s_waitcnt(0xC07F);             // reads done before the next tile row overwrites the slab
+    }
+    if (g.stats != nullptr) {
+      __syncthreads();
+      for (int e = tid; e < 2 * BN; e += NTH) {
+        const int which = e / BN, c = e - which * BN;
+        const int cwn = c / TN, cl = c - cwn * TN;
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < WM; ++k) v += sS[((k * WN + cwn) * 2 + which) * TN + cl];
+        g.stats[((size_t)tm * 2 + which) * g.N + n0 + c] = v;
+      }
     }
   }
 }
@@ -340,12 +382,23 @@ extern "C" long egn_gemm_ws_bytes(int form, int M, int N, int K) {
   return splits > 1 ? (long)splits * M * N * 4 : 0;
 }
 
+// rows of the partial statistics table of egn_gemm_ex_f32(form 0, stats): one per 128-row block tile
+extern "C" long egn_gemm_stats_rows(int M) { return M > 0 && M % 128 == 0 ? M / 128 : 0; }
+
 extern "C" int egn_gemm_f32(int form, const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                             int lda, int ldb, int ldc, int variant, void* ws, long ws_bytes, void* stream) {
+  return egn_gemm_ex_f32(form, A, B, C, bias, nullptr, nullptr, 0, M, N, K, lda, ldb, ldc, variant, ws, ws_bytes, stream);
+}
+
+extern "C" int egn_gemm_ex_f32(int form, const float* A, const float* B, float* C, const float* bias, const float* addend,
+                               double* stats, long stats_rows, int M, int N, int K, int lda, int ldb, int ldc, int variant,
+                               void* ws, long ws_bytes, void* stream) {
   if (!A || !B || !C || !egn_gemm_supported(form, M, N, K, lda, ldb, ldc)) return EGN_E_BADARG;
+  if (addend && form != 1) return EGN_E_BADARG;                                  // C = A.B + addend: the NN form only
+  if (stats && (form != 0 || stats_rows < egn_gemm_stats_rows(M))) return EGN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   GemmArgs g = {};
-  g.A = A; g.B = B; g.C = C; g.bias = bias;
+  g.A = A; g.B = B; g.C = C; g.bias = bias; g.addend = addend; g.stats = stats;
   g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.splits = 1;
   g.a_bytes = (size_t)(form == 2 ? K : M) * lda * 4;
   g.b_bytes = (size_t)(form == 0 ? N : K) * ldb * 4;

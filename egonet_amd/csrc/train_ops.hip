@@ -386,6 +386,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   }
   const bool rng = !mask && drop.thresh != 0;
   const unsigned dstep = rng ? (unsigned)*drop.step : 0u;
+  // `relu`: 0 none, 1 ReLU, 2 LeakyReLU; | 0x10: `res` is added AFTER activation and dropout (the residual block's
+  // output, so that the lifter step needs no add pass) instead of in front of the activation (HRNet's BasicBlock)
+  const int act = relu & 0xf;
+  const bool res_after = (relu & 0x10) != 0;
   for (int r = blockIdx.x * rpi + r_local; r < rows; r += gridDim.x * rpi) {
     const size_t e = (size_t)r * ld4 + c4;
     const float4 v = reinterpret_cast<const float4*>(z)[e];
@@ -402,10 +406,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     for (int k = 0; k < 4; ++k) {
       float o = 0.f;
       if (ok[k]) {
-        o = pg[k] * ((in[k] - pm[k]) * pi[k]) + pb[k] + ra[k];
-        if (relu == 2) o = o > 0.f ? o : 0.01f * o;   // nn.LeakyReLU() default slope (FCmodel.py:19-22)
-        else if (relu) o = fmaxf(o, 0.f);
+        o = pg[k] * ((in[k] - pm[k]) * pi[k]) + pb[k] + (res_after ? 0.f : ra[k]);
+        if (act == 2) o = o > 0.f ? o : 0.01f * o;   // nn.LeakyReLU() default slope (FCmodel.py:19-22)
+        else if (act) o = fmaxf(o, 0.f);
         if (mask || rng) o *= mka[k] * keep_scale;
+        if (res_after) o = ra[k] + o;                // FCmodel.py:49-51: out = x + dropout(relu(bn(z)))
       }
       out[k] = o;
     }

@@ -55,6 +55,10 @@ class LifterTrainStep(object):
     rng_dropout = os.environ.get('EGONET_AMD_RNG_DROPOUT', '1') != '0'
     _layer_epoch = 0          # Philox 'layer' word = unit + 16 * (non-updating forwards since the last optimizer step)
     use_gemm = os.environ.get('EGONET_AMD_GEMM', '1') != '0'
+    # [r4] BatchNorm statistics from the forward GEMM's epilogue, skip-path gradient added in the data-gradient GEMM's
+    # epilogue (EGONET_AMD_GEMM_FUSE=0: the separate column-reduction / add passes of round 3)
+    fuse_gemm_epilogue = os.environ.get('EGONET_AMD_GEMM_FUSE', '1') != '0'
+    _gemm_fused = False
     gemm_variant = [int(v) for v in os.environ.get('EGONET_AMD_GEMM_VARIANTS', '3,0,1').split(',')]
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, dropout=None, grad_sync=None,
@@ -124,9 +128,23 @@ class LifterTrainStep(object):
     def _st(self):
         return _lib.current_stream(self.dev)
 
-    def _gemm(self, a, rows, k, ld_a, w_src, ld_w, cout, transpose_w, out, shift=None, tagk=''):
+    def _stats_table(self, ui, nrow, cols):
+        """float64 [nrow][2][cols] partial-statistics table of unit ``ui`` (written whole by the GEMM's epilogue)."""
+        key = ('stats', ui, nrow, cols)
+        t = self._ws.get(key)
+        if t is None:
+            t = torch.zeros(nrow * 2 * cols, dtype=torch.float64, device=self.dev)
+            self._ws[key] = t
+        return t
+
+    def _gemm(self, a, rows, k, ld_a, w_src, ld_w, cout, transpose_w, out, shift=None, tagk='', addend=None, stats=None):
         """out[rows, cout] (contiguous) = a[rows, :k] @ W^T + shift, W[co][ci] taken from
-        w_src (row-major, ld_w) directly (transpose_w=0) or transposed (1)."""
+        w_src (row-major, ld_w) directly (transpose_w=0) or transposed (1).  On the dense-GEMM route two epilogue
+        fusions [r4]: ``addend`` ([rows, cout], data-gradient form: out = a W + addend -- the skip-path gradient of a
+        residual block, no add pass) and ``stats`` (forward form: a [rows / 128][2][cout] float64 table the epilogue
+        fills with partial column sums / sums of squares of ``out`` -- BatchNorm1d's batch statistics without a pass
+        over z).  Returns (out, fused): ``fused`` says whether the requested fusion happened (else the caller runs
+        the separate pass)."""
         L = self.L
         form = 1 if transpose_w else 0
         if self.use_gemm and L.egn_gemm_supported(form, rows, cout, k, ld_a, ld_w, cout):
@@ -135,13 +153,20 @@ class LifterTrainStep(object):
             if tm is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(torch.cuda.current_stream(self.dev))
-            _lib.check(L.egn_gemm_f32(form, _lib.ptr(a), _lib.ptr(w_src), _lib.ptr(out),
-                                      _lib.ptr(shift.detach()) if shift is not None else None, rows, cout, k, ld_a, ld_w,
-                                      cout, self.gemm_variant[form], None, 0, self._st()), 'gemm')
+            fuse = self.fuse_gemm_epilogue
+            _lib.check(L.egn_gemm_ex_f32(form, _lib.ptr(a), _lib.ptr(w_src), _lib.ptr(out),
+                                         _lib.ptr(shift.detach()) if shift is not None else None,
+                                         _lib.ptr(addend) if fuse and form == 1 else None,
+                                         _lib.ptr(stats) if fuse and form == 0 else None,
+                                         stats.numel() // (2 * cout) if fuse and form == 0 and stats is not None else 0,
+                                         rows, cout, k, ld_a, ld_w, cout, self.gemm_variant[form], None, 0, self._st()),
+                       'gemm')
             if tm is not None:
                 e1.record(torch.cuda.current_stream(self.dev))
                 tm.append((-(form + 1), 2.0 * rows * k * cout, e0, e1))
+            self._gemm_fused = fuse and (addend is not None or stats is not None)
             return out
+        self._gemm_fused = False
         coutp = _round_up(cout, 16)
         w4 = self.w4.get(id(w_src))
         if w4 is not None and ld_w == w4.shape[1]:
@@ -255,35 +280,50 @@ class LifterTrainStep(object):
         block_in = None
         for ui, u in enumerate(self.units):
             z = buf('z%d' % ui, B, u.outf)
-            self._gemm(a, B, u.inf, ld_a, u.fc.weight, u.inf, u.outf, 0, z, shift=u.fc.bias, tagk='f%d' % ui)
+            nrow = L.egn_gemm_stats_rows(B)
+            part = self._stats_table(ui, nrow, u.outf) if nrow else None
+            self._gemm(a, B, u.inf, ld_a, u.fc.weight, u.inf, u.outf, 0, z, shift=u.fc.bias, tagk='f%d' % ui, stats=part)
             mean = buf('mean%d' % ui, u.outf)
             istd = buf('istd%d' % ui, u.outf)
             varu = buf('varu%d' % ui, u.outf)
             mom = u.bn.momentum if u.bn.momentum is not None else 0.1
-            _lib.check(L.egn_bn_stats_f32(_lib.ptr(z), B, u.outf, u.outf, u.bn.eps, _lib.ptr(mean), _lib.ptr(istd),
-                                          _lib.ptr(varu), _lib.ptr(u.bn.running_mean),
-                                          _lib.ptr(u.bn.running_var), mom, _lib.ptr(ws), st), 'bn_stats')
+            if part is not None and self._gemm_fused:
+                # the GEMM's epilogue left partial column sums: only the finalise launch remains
+                _lib.check(L.egn_bn_stats_finalize_f32(_lib.ptr(part), nrow, B, u.outf, u.bn.eps, _lib.ptr(mean),
+                                                       _lib.ptr(istd), _lib.ptr(varu), _lib.ptr(u.bn.running_mean),
+                                                       _lib.ptr(u.bn.running_var), mom, st), 'bn_stats_finalize')
+            else:
+                _lib.check(L.egn_bn_stats_f32(_lib.ptr(z), B, u.outf, u.outf, u.bn.eps, _lib.ptr(mean), _lib.ptr(istd),
+                                              _lib.ptr(varu), _lib.ptr(u.bn.running_mean),
+                                              _lib.ptr(u.bn.running_var), mom, _lib.ptr(ws), st), 'bn_stats')
             mask = None
-            y = buf('y%d' % ui, B, u.outf)
+            # second unit of a residual block: out = block_in + y (FCmodel.py:33-43) is written by the BatchNorm pass
+            # itself (activation flag | 0x10: `res` added after activation and dropout) -- no add pass [r4]
+            tail = ui > 0 and ui % 2 == 0 and self.fuse_gemm_epilogue
+            y = buf(('blk%d' if tail else 'y%d') % ui, B, u.outf)
+            act_flag, res_ptr = (self.act | 0x10, _lib.ptr(block_in)) if tail else (self.act, None)
             if self.p > 0 and self.rng_dropout:
                 # keep mask drawn inside the kernel (Philox on (seed; element, unit, step)): the backward kernels
                 # regenerate it -- no mask tensor, no RNG kernel in the step
                 _lib.check(L.egn_bn_act_fwd_drop_f32(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(u.bn.weight),
                                                      _lib.ptr(u.bn.bias), self.p, self.drop_seed, _lib.ptr(self.drop_step),
-                                                     ui + 16 * self._layer_epoch, self.act, None, _lib.ptr(y), B, u.outf, u.outf, st),
-                           'bn_act_fwd_drop')
+                                                     ui + 16 * self._layer_epoch, act_flag, res_ptr, _lib.ptr(y), B, u.outf,
+                                                     u.outf, st), 'bn_act_fwd_drop')
             else:
                 if self.p > 0:
                     mask = buf('mask%d' % ui, B, u.outf)
                     mask.bernoulli_(1.0 - self.p)          # keep mask (0/1), one launch, capture-aware RNG
                 _lib.check(L.egn_bn_act_fwd_f32(_lib.ptr(z), _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(u.bn.weight),
-                                                _lib.ptr(u.bn.bias), _lib.ptr(mask), keep, self.act, None, _lib.ptr(y), B,
+                                                _lib.ptr(u.bn.bias), _lib.ptr(mask), keep, act_flag, res_ptr, _lib.ptr(y), B,
                                                 u.outf, u.outf, st), 'bn_act_fwd')
             saved.append((a, ld_a, z, mean, istd, mask))
             if ui == 0:
                 block_in = y
                 a = y
             elif ui % 2 == 1:          # first unit of a residual block
+                a = y
+            elif tail:                 # second unit, sum already written by the BatchNorm pass
+                block_in = y
                 a = y
             else:                      # second unit: out = block_in + y   (FCmodel.py:33-43)
                 out = buf('blk%d' % ui, B, u.outf)
@@ -356,13 +396,17 @@ class LifterTrainStep(object):
                 sess.done([u.fc.weight, u.fc.bias, u.bn.weight, u.bn.bias])
             if ui == 0:
                 break
-            da = buf('da%d' % (ui % 2), B, u.inf)
-            self._gemm(dz, B, u.outf, u.outf, u.fc.weight, u.inf, u.inf, 1, da, tagk='d')
             if ui % 2 == 0:            # second unit of a block: continue into the first unit
+                da = buf('da%d' % (ui % 2), B, u.inf)
+                self._gemm(dz, B, u.outf, u.outf, u.fc.weight, u.inf, u.inf, 1, da, tagk='d')
                 d_y = da
             else:                      # first unit: block input gradient = skip path + branch path
                 nxt = buf('dblk%d' % ((ui // 2) % 2), B, u.inf)
-                _lib.check(L.egn_add_f32(_lib.ptr(d_block_out), _lib.ptr(da), _lib.ptr(nxt), B * u.inf, st))
+                self._gemm(dz, B, u.outf, u.outf, u.fc.weight, u.inf, u.inf, 1, nxt, tagk='d', addend=d_block_out)
+                if not self._gemm_fused:        # conv-kernel route / fusion off: nxt holds dz W, add the skip path
+                    da = buf('da%d' % (ui % 2), B, u.inf)
+                    da.copy_(nxt)
+                    _lib.check(L.egn_add_f32(_lib.ptr(d_block_out), _lib.ptr(da), _lib.ptr(nxt), B * u.inf, st))
                 d_block_out = nxt
         self._join_side()
 

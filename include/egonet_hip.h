@@ -268,6 +268,16 @@ int egn_gemm_supported(int form, int M, int N, int K, int lda, int ldb, int ldc)
 long egn_gemm_ws_bytes(int form, int M, int N, int K);
 int egn_gemm_f32(int form, const float* A, const float* B, float* C, const float* bias, int M, int N, int K,
                  int lda, int ldb, int ldc, int variant, void* ws, long ws_bytes, void* stream);
+/* The same with the epilogue fusions of the lifter's training step (FCmodel.py:33-43 under trainer.py:183-209):
+ *   addend (form 1 only, [M][ldc]): C = A.B + addend -- the skip-path gradient of a residual block (FCmodel.py:49-51,
+ *           `out = x + y`) joins the branch gradient without an add pass;
+ *   stats  (form 0 only): partial column sums and sums of squares of the stored C, [stats_rows][2][N]
+ *           doubles with stats_rows >= egn_gemm_stats_rows(M) (one row per 128-row block tile, fixed summation order)
+ *           -- nn.BatchNorm1d's batch statistics without a pass over z; egn_bn_stats_finalize_f32 adds the rows. */
+long egn_gemm_stats_rows(int M);
+int egn_gemm_ex_f32(int form, const float* A, const float* B, float* C, const float* bias, const float* addend,
+                    double* stats, long stats_rows, int M, int N, int K, int lda, int ldb, int ldc, int variant,
+                    void* ws, long ws_bytes, void* stream);
 /* dst[c][r] = src[r][c]; dst columns R..ld_dst-1 are zeroed */
 int egn_transpose_f32(const float* src, int R, int C, int ld_src, float* dst,
                       int ld_dst, void* stream);
