@@ -121,3 +121,68 @@ def test_in_kernel_dropout_is_philox_and_forward_backward_agree():
     m2 = torch.empty_like(mask)
     _lib.check(L.egn_dropout_mask_f32(_lib.ptr(m2), rows * cols, p, seed, _lib.ptr(step), layer, st))
     assert not torch.equal(mask, m2)
+
+
+@pytest.mark.parametrize('M,N,K,variant', [(256, 128, 64, 0), (4096, 1024, 1024, 3), (512, 256, 96, 1), (384, 128, 32, 2)])
+def test_gemm_forward_epilogue_leaves_batchnorm_partial_sums(M, N, K, variant):
+    """egn_gemm_ex_f32(form 0, stats): z = a W^T + b AND, from the same epilogue, partial column sums / sums of squares
+    of z per 128-row block tile ([M / 128][2][N] doubles) -- nn.BatchNorm1d's batch statistics (FCmodel.py:33-43 in
+    train mode) without a pass over z.  z is bit-identical to the plain call; the finalised mean / 1/sigma equal
+    egn_bn_stats_f32's on the same z."""
+    L = _lib.lib()
+    st = _lib.current_stream()
+    g = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    z0 = torch.empty(M, N, device='cuda')
+    _lib.check(L.egn_gemm_f32(0, _lib.ptr(A), _lib.ptr(B), _lib.ptr(z0), _lib.ptr(bias), M, N, K, K, K, N, variant, None, 0, st))
+    nrow = L.egn_gemm_stats_rows(M)
+    assert nrow == M // 128
+    part = torch.full((nrow, 2, N), float('nan'), dtype=torch.float64, device='cuda')
+    z1 = torch.empty(M, N, device='cuda')
+    _lib.check(L.egn_gemm_ex_f32(0, _lib.ptr(A), _lib.ptr(B), _lib.ptr(z1), _lib.ptr(bias), None, _lib.ptr(part), nrow,
+                                 M, N, K, K, K, N, variant, None, 0, st), 'gemm + stats')
+    torch.cuda.synchronize()
+    assert torch.equal(z0, z1)
+    zd = z1.double().view(nrow, 128, N)
+    np.testing.assert_allclose(part[:, 0].cpu().numpy(), zd.sum(1).cpu().numpy(), rtol=2e-6, atol=1e-4)
+    np.testing.assert_allclose(part[:, 1].cpu().numpy(), (zd * zd).sum(1).cpu().numpy(), rtol=2e-6, atol=1e-4)
+    # finalise == the two-pass statistics of the same z
+    mean, istd, varu = (torch.empty(N, device='cuda') for _ in range(3))
+    _lib.check(L.egn_bn_stats_finalize_f32(_lib.ptr(part), nrow, M, N, 1e-5, _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(varu),
+                                           None, None, 0.1, st))
+    m2, i2, v2 = (torch.empty(N, device='cuda') for _ in range(3))
+    ws = torch.empty(L.egn_colreduce_ws_bytes(N) // 4, device='cuda')
+    _lib.check(L.egn_bn_stats_f32(_lib.ptr(z1), M, N, N, 1e-5, _lib.ptr(m2), _lib.ptr(i2), _lib.ptr(v2), None, None, 0.1,
+                                  _lib.ptr(ws), st))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(mean.cpu().numpy(), m2.cpu().numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(istd.cpu().numpy(), i2.cpu().numpy(), rtol=2e-5, atol=0)
+    # deterministic, and refused where it does not apply
+    part2 = torch.empty_like(part)
+    _lib.check(L.egn_gemm_ex_f32(0, _lib.ptr(A), _lib.ptr(B), _lib.ptr(z1), _lib.ptr(bias), None, _lib.ptr(part2), nrow,
+                                 M, N, K, K, K, N, variant, None, 0, st))
+    assert torch.equal(part, part2)
+    assert L.egn_gemm_ex_f32(0, _lib.ptr(A), _lib.ptr(B), _lib.ptr(z1), None, None, _lib.ptr(part), nrow - 1, M, N, K, K, K,
+                             N, variant, None, 0, st) != 0
+
+
+def test_gemm_data_gradient_epilogue_adds_the_skip_path():
+    """egn_gemm_ex_f32(form 1, addend): da = dz W + d_skip in one launch (the residual block's `out = x + y`,
+    FCmodel.py:49-51, in the backward); equal to the plain product plus the addend, refused for the other forms."""
+    L = _lib.lib()
+    st = _lib.current_stream()
+    M, N, K = 512, 256, 128
+    g = torch.Generator().manual_seed(3)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = torch.randn(K, N, generator=g).cuda()
+    add = torch.randn(M, N, generator=g).cuda()
+    c0, c1 = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda')
+    _lib.check(L.egn_gemm_f32(1, _lib.ptr(A), _lib.ptr(B), _lib.ptr(c0), None, M, N, K, K, N, N, 0, None, 0, st))
+    _lib.check(L.egn_gemm_ex_f32(1, _lib.ptr(A), _lib.ptr(B), _lib.ptr(c1), None, _lib.ptr(add), None, 0, M, N, K, K, N, N, 0,
+                                 None, 0, st))
+    torch.cuda.synchronize()
+    assert torch.equal(c1, c0 + add)
+    assert L.egn_gemm_ex_f32(0, _lib.ptr(A), _lib.ptr(B), _lib.ptr(c1), None, _lib.ptr(add), None, 0, M, N, K, K, K, N, 0,
+                             None, 0, st) != 0
