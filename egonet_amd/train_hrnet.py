@@ -568,7 +568,10 @@ class TapeOwner(object):
         self.col_ws = torch.zeros(self.L.egn_colreduce_ws_bytes(widest) // 4, dtype=torch.float32, device=self.dev)
         self._wgrad_ws = None
         # weight gradients on a second stream (EGONET_AMD_WGRAD_STREAM=0: everything on one stream)
-        self.wgrad_stream = torch.cuda.Stream(device=self.dev) \
+        # EGONET_AMD_WGRAD_PRIORITY: HIP stream priority of that stream (0 normal, positive = lower where the runtime
+        # has a low level): the chain's latency-bound BatchNorm / reduction kernels should not queue behind the
+        # weight gradients' grids
+        self.wgrad_stream = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get('EGONET_AMD_WGRAD_PRIORITY', '0'))) \
             if os.environ.get('EGONET_AMD_WGRAD_STREAM', '1') != '0' else None
         self.walker = HRNetEngine(model)
         self.packs = PackedFilters(self.dev)

@@ -34,6 +34,8 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--graph', action='store_true', help='replay the iteration as one hipGraph (single GPU)')
+    ap.add_argument('--main-priority', type=int, default=None,
+                    help='run the step on a stream of this HIP priority (-1 = high) instead of the default stream')
     a = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -51,6 +53,11 @@ def main():
     x = synth.synth_crops(a.batch, 3, 256, 256, seed=50 + rank).cuda()
     tgt = torch.rand(a.batch, 33, 64, 64, generator=g).cuda()
     jt = (torch.rand(a.batch, 33, 2, generator=g) * 256).cuda()
+    if a.main_priority is not None:
+        print('stream priority range (least, greatest):', torch.cuda.Stream.priority_range(), file=sys.stderr)
+        main_stream = torch.cuda.Stream(priority=a.main_priority)
+        main_stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(main_stream)
     for _ in range(a.warmup):
         tr.step(x, tgt, jt)
     step = lambda: tr.step(x, tgt, jt)                     # noqa: E731
