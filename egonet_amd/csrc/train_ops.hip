@@ -267,9 +267,27 @@ __global__ __launch_bounds__(256) void colreduce_final_kernel(ColArgs p, const d
   const int c = blockIdx.x * 8 + cl;
   double a0 = 0.0, a1 = 0.0;
   if (c < p.cols) {
-    for (int k = sl; k < p.nsplit; k += 32) {
+    // nsplit <= 256: at most 8 rows per lane.  All 16 loads are issued before the first add (the rolled loop made 8
+    // dependent L2 round trips: 5.1 us per launch for a kernel the training step runs 610 times, profiles/
+    // r3_train_hc_kernel_stats_single_stream.csv); the sums are taken in the same order as before.
+    static_assert(EGN_COL_MAX_SPLITS <= 8 * 32, "eight rows per split lane");
+    for (int k = sl + 256; k < p.nsplit; k += 32) {      // (tables with more than 256 rows: a large-M GEMM epilogue)
       a0 += ws[((size_t)k * 2 + 0) * p.cols + c];
       a1 += ws[((size_t)k * 2 + 1) * p.cols + c];
+    }
+    double v0[8], v1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = sl + 32 * u;
+      const bool in = k < p.nsplit;
+      const size_t kk = in ? (size_t)k : 0;
+      v0[u] = ws[(kk * 2 + 0) * p.cols + c];
+      v1[u] = ws[(kk * 2 + 1) * p.cols + c];
+      if (!in) { v0[u] = 0.0; v1[u] = 0.0; }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (sl + 32 * u < p.nsplit) { a0 += v0[u]; a1 += v1[u]; }
     }
   }
   r0[sl][cl] = a0;
