@@ -302,7 +302,9 @@ static int launch_one(const ConvArgs& a, size_t lds, hipStream_t stream) {
 
 // dma family: local ids 1..10 = config ids 11..20 (table in conv_plan.hip)
 int egn_conv_launch_dma(const ConvArgs& a, int local_id, size_t lds, hipStream_t stream) {
-  // timing ablations of the 128x48 / 128x96 tiles (tools/conv_probe.py); never set in production
+#ifdef EGN_PROBES
+  // timing ablations of the 128x48 / 128x96 tiles (tools/conv_probe.py): probe builds only (-DEGN_PROBES) -- the product
+  // library neither contains these kernels nor reads the variable
   static const int abl = getenv("EGN_CONV_ABLATE") ? atoi(getenv("EGN_CONV_ABLATE")) : 0;
   if (abl && (local_id == 2 || local_id == 6)) {
     if (local_id == 2) {
@@ -315,6 +317,7 @@ int egn_conv_launch_dma(const ConvArgs& a, int local_id, size_t lds, hipStream_t
       if (abl == 3) return launch_abl<4, 1, 2, 3, 3>(a, lds, stream);
     }
   }
+#endif
   switch (local_id) {
     case 1: return launch_one<4, 1, 4, 3>(a, lds, stream);
     case 2: return launch_one<2, 2, 4, 3>(a, lds, stream);

@@ -413,6 +413,7 @@ static int wgw_launch(const WgradArgs& a, hipStream_t stream) {
 }
 
 int egn_wgrad_wino_launch(const WgradArgs& a, int variant, hipStream_t stream) {
+#ifdef EGN_PROBES      // timing-ablation / stamp builds (WRONG RESULTS): probe builds only, tools/wgrad_probe.py / wgw_clk.py
   static const int abl = getenv("EGN_WGW_ABL") ? atoi(getenv("EGN_WGW_ABL")) : 0;
   if (abl && variant != 2) {
     switch (abl) {
@@ -425,5 +426,6 @@ int egn_wgrad_wino_launch(const WgradArgs& a, int variant, hipStream_t stream) {
       default: break;
     }
   }
+#endif
   return variant == 2 ? wgw_launch<8, 2>(a, stream) : wgw_launch<16, 1>(a, stream);
 }
