@@ -720,11 +720,14 @@ class HRNetEngine(object):
             nslots += 3
         return r, nslots, out_shapes
 
-    def program(self, x, decode_mode=None):
+    def program(self, x, decode_mode=None, slot=0):
+        """``slot``: independent copies of the program (own arena, own launch lanes) for batches IN FLIGHT together: a
+        serving loop that alternates two streams runs slot 0 on one and slot 1 on the other, and the low-occupancy head
+        and tail of one batch overlap the other batch's kernels."""
         if self._stamp.changed():
             self.programs.clear()
         n, c, h, w = x.shape
-        key = (x.device, n, c, h, w, decode_mode)
+        key = (x.device, n, c, h, w, decode_mode) if not slot else (x.device, n, c, h, w, decode_mode, slot)
         prog = self.programs.get(key)
         if prog is None:
             if h % 32 or w % 32:
@@ -736,14 +739,14 @@ class HRNetEngine(object):
         return prog
 
     # -- execution ---------------------------------------------------------
-    def forward(self, x, decode_mode=None, timed=False):
+    def forward(self, x, decode_mode=None, timed=False, slot=0):
         """x [N,C,H,W] fp32 CUDA.  Returns what the module's forward returns;
         with decode_mode 0/1 additionally (xy[N,K,2], maxvals[N,K,1], idx[N,K])."""
         if x.dtype != torch.float32:
             raise TypeError('egonet_amd HRNet engine computes in fp32, got %s' % x.dtype)
         x = x.contiguous()
         with torch.cuda.device(x.device):
-            prog = self.program(x, decode_mode)
+            prog = self.program(x, decode_mode, slot)
             shp = prog.out_shapes
             maps = torch.empty(shp['maps'], dtype=torch.float32, device=x.device)
             prog.bind(SLOT_USER0, x)
@@ -806,17 +809,17 @@ class LifterEngine(object):
         lin(y, m.w2, None, ACT_NONE, None, 'w2', dst=out, nchw=True)
         return r
 
-    def program(self, device, n, ld_in=None):
+    def program(self, device, n, ld_in=None, slot=0):
         if self._stamp.changed():
             self.programs.clear()
-        key = (device, n, ld_in)
+        key = (device, n, ld_in) if not slot else (device, n, ld_in, slot)
         prog = self.programs.get(key)
         if prog is None:
             prog = Program(self._record(n, ld_in), device, 2)
             self.programs[key] = prog
         return prog
 
-    def forward(self, x, ld_in=None):
+    def forward(self, x, ld_in=None, slot=0):
         """x [N,in] fp32 CUDA (or [N,ld_in] zero-padded rows) -> [N,out]."""
         if x.dtype != torch.float32:
             raise TypeError('egonet_amd lifter engine computes in fp32, got %s' % x.dtype)
@@ -826,7 +829,7 @@ class LifterEngine(object):
         if n == 0:
             return out
         with torch.cuda.device(x.device):
-            prog = self.program(x.device, n, ld_in)
+            prog = self.program(x.device, n, ld_in, slot)
             prog.bind(SLOT_USER0, x)
             prog.bind(SLOT_USER0 + 1, out)
             prog.run()

@@ -64,7 +64,7 @@ class EgoNet(nn.Module):
     # ------------------------------------------------------------------
     @torch.no_grad()
     def infer_crops(self, instances, centers, scales, K=None, kpts_x_for_alpha=None,
-                    alpha_mode='proj', decode='auto', to_host=True):
+                    alpha_mode='proj', decode='auto', to_host=True, slot=0):
         """instances [n,C,H,W] fp32 CUDA crops; centers/scales [n,2] float64
         (``modify_bbox`` outputs).  Returns a dict with
           kpts_2d [n,2J] f64 (screen), kpts_3d [n,J-1,3] f64, euler [n,3],
@@ -72,6 +72,8 @@ class EgoNet(nn.Module):
         as numpy arrays (``to_host``) or device tensors.
         decode: 'coords' (coordinate head, the shipped configs), 'soft' /
         'hard' (heat-map arg-max), 'auto' = by ``HC.head_type``.
+        slot: which copy of the launch programs to use -- a serving loop that keeps two batches in flight on two
+        streams alternates slot 0 / 1 (engine.HRNetEngine.program).
         """
         if not instances.is_cuda:
             raise ValueError('infer_crops is the GPU pipeline; pass CUDA crops')
@@ -88,11 +90,11 @@ class EgoNet(nn.Module):
         with torch.cuda.device(dev):
             stream = _lib.current_stream(dev)
             if decode == 'coords':
-                _, local = HC._hip_engine().forward(instances.float())
+                _, local = HC._hip_engine().forward(instances.float(), slot=slot)
                 mul = (float(width), float(height))
             else:
                 mode = 1 if decode == 'soft' else 0
-                out, (local, _, _) = HC._hip_engine().forward(instances.float(), decode_mode=mode)
+                out, (local, _, _) = HC._hip_engine().forward(instances.float(), decode_mode=mode, slot=slot)
                 maps = out[0] if isinstance(out, tuple) else out
                 mul = (float(width) / maps.shape[3], float(height) / maps.shape[2])
             key = ('ls', dev)
@@ -109,7 +111,7 @@ class EgoNet(nn.Module):
                 _lib.ptr(local), n, J, mul[0], mul[1], _lib.ptr(c_d), _lib.ptr(s_d), int(width),
                 int(height), _lib.ptr(screen), _lib.ptr(ls['mean_in']), _lib.ptr(ls['std_in']),
                 _lib.ptr(lin), ld_in, stream), 'keypoints_to_screen')
-            y = self.L._hip_engine().forward(lin, ld_in=ld_in)
+            y = self.L._hip_engine().forward(lin, ld_in=ld_in, slot=slot)
             D = y.shape[1]
             pred3d = torch.empty(n, D, dtype=torch.float64, device=dev)
             _lib.check(L.egn_unnormalize_f64(_lib.ptr(y), n, D, D, _lib.ptr(ls['mean_out']),
