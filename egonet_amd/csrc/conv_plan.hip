@@ -25,7 +25,8 @@ bool egn_conv_stem_applies(const ConvArgs& a);
 size_t egn_conv_stem_lds_bytes();
 int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, int geo, hipStream_t stream);          // conv_wino4.hip
 bool egn_conv_wino4_applies(const ConvArgs& a, int geo);
-size_t egn_conv_wino4_lds_bytes();
+size_t egn_conv_wino4_lds_bytes(int geo);
+int egn_conv_wino4_tickets(const ConvArgs& a, int geo);
 int egn_conv_launch_fc(const ConvArgs& a, hipStream_t stream);                          // conv_fc.hip
 bool egn_conv_fc_applies(const ConvArgs& a);
 size_t egn_conv_wino_lds_bytes(int variant, int cout);
@@ -116,6 +117,8 @@ static const ConvConfig kConfigs[] = {
     {79, 4, 1, 1, 1, 0, 0, 8},     // 1x1 conv on 1 x 1 maps (the lifter's Linear layers): one 16 x 16 tile per block, K split over the waves (conv_fc.hip)
     {80, 12, 1, 1, 3, 1, 0, 7},    // conv_wino4b_kernel: F(4x4,3x3) on 16 x 16 pixel regions, 16-channel stages (ai = geometry 1); filter kind 3
     {81, 12, 1, 1, 3, 1, 64, 7},   // 80 with s_memtime stamps (tools/wino4_clk.py)
+    {82, 12, 1, 1, 3, 2, 0, 7},    // conv_wino4c_kernel<0, 1>: F(4x4,3x3) on 8 x 8 maps, four images per region (ai = geometry 2); filter kind 3
+    {83, 12, 1, 1, 3, 6, 0, 7},    // conv_wino4c_kernel<0, 2>: 82 with the input channels of an item split over two blocks (ai bit 2): memset, atomic adds, conv_wino4_finish_kernel
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -169,6 +172,7 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (cfg < 1 || cfg > kNumConfigs || !buf || len < 8) return EGN_E_BADARG;
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 6) { snprintf(buf, len, "conv_stem_kernel(ConvArgs)"); return 0; }
+  if (c.dma == 7 && (c.ai & 3) == 2) { snprintf(buf, len, "void conv_wino4c_kernel<%d, %d>(ConvArgs)", c.bi, (c.ai & 4) ? 2 : 1); return 0; }
   if (c.dma == 7) { snprintf(buf, len, "void conv_wino4%s_kernel<%d>(ConvArgs)", c.ai ? "b" : "", c.bi); return 0; }
   if (c.dma == 8) { snprintf(buf, len, "conv_fc_kernel(ConvArgs)"); return 0; }
   if (c.dma == 5 && (c.bi & 15) == 10) { snprintf(buf, len, "void conv_wino43_kernel<0>(ConvArgs)"); return 0; }
@@ -216,7 +220,7 @@ static size_t lds_stage_bytes(const ConvArgs& a, const ConvConfig& cf) {
 }
 static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
   if (cf.dma == 6) return egn_conv_stem_lds_bytes();
-  if (cf.dma == 7) return egn_conv_wino4_lds_bytes();
+  if (cf.dma == 7) return egn_conv_wino4_lds_bytes(cf.ai);
   if (cf.dma == 8) return 0;
   if (cf.dma == 5) return egn_conv_wino_lds_bytes(cf.bi, a.Cout);
   if (cf.dma == 4 && cf.bi == 2) return (size_t)(3 * 336 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // chunk ring + filter
@@ -251,12 +255,14 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
     return true;
   }
   if (cf.dma == 7) {
-    // conv_wino4.hip: 16 x 32 (ai = 0) / 16 x 16 (ai = 1) pixel regions of whole-region maps, 48-channel co-tiles
+    // conv_wino4.hip: 16 x 32 (ai = 0) / 16 x 16 (ai = 1) pixel regions of whole-region maps, or four whole 8 x 8
+    // images per region (ai & 3 = 2; ai bit 2: K split), 48-channel co-tiles
     if (!egn_conv_wino4_applies(a, cf.ai)) return false;
-    a.TH = 16; a.TW = cf.ai ? 16 : 32; a.TNB = 1; a.HH = 18; a.HW = a.TW + 2;
-    a.npix = 18 * a.HW; a.npixp = (a.npix + 15) & ~15; a.tps = 36;
+    const int g7 = cf.ai & 3;
+    a.TH = g7 == 2 ? 8 : 16; a.TW = g7 == 2 ? 8 : (g7 ? 16 : 32); a.TNB = g7 == 2 ? 4 : 1; a.HH = a.TH + 2; a.HW = a.TW + 2;
+    a.npix = a.TNB * a.HH * a.HW; a.npixp = (a.npix + 15) & ~15; a.tps = 36;
     a.tiles_x = a.Wo / a.TW;
-    a.tiles_y = a.Ho / 16;
+    a.tiles_y = a.Ho / a.TH;
     if (cost_out) *cost_out = 0.0;
     return true;
   }
@@ -405,6 +411,13 @@ int egn_conv_stats_rows(const ConvArgs& a, int cfg_id) {
   if (cfg_id < 1 || cfg_id > kNumConfigs) return 0;
   const ConvConfig& cf = kConfigs[cfg_id - 1];
   return cf.dma == 5 ? egn_conv_wino_stats_rows(a, cf.bi) : 0;
+}
+
+// ticket words (zeroed unsigned) a launch of cfg_id wants in a.tickets to run as ONE kernel; 0 = the config uses none
+int egn_conv_ticket_count(const ConvArgs& a, int cfg_id) {
+  if (cfg_id < 1 || cfg_id > kNumConfigs) return 0;
+  const ConvConfig& cf = kConfigs[cfg_id - 1];
+  return cf.dma == 7 ? egn_conv_wino4_tickets(a, cf.ai) : 0;
 }
 
 int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {

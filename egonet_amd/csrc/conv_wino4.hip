@@ -38,6 +38,12 @@
 //          192-channel branch are 256 items at 64 crops (two-image regions would be 128: half the chip), and small
 //          batches (BASELINE configs[4]'s 16-crop shard) fill the CUs.  A "k-group pair" (8 channels x 1 m-tile) takes
 //          the place of GEO 0's k-group (4 channels x 2 m-tiles) in the stage schedule.
+//   GEO 2  conv_wino4c_kernel  FOUR IMAGES of an 8 x 8 map per region (the 384-channel branch: 2 x 2 tiles per image,
+//          one m-tile = 4 images), 16-channel stages as GEO 1; 3 halo pieces per wave and stage (4 x 10 x 10 pixels).
+//          Template parameter KS = 2 splits the input channels of an item over two blocks (64 crops x 384 -> 384
+//          channels are 16 regions x 8 co-tiles = 128 items: half the chip; 256 with the split): both add their
+//          raw Y = A^T M A into a zeroed y (buffer_atomic_add_f32 -- two addends onto 0: the sum does not depend on
+//          the order), and conv_wino4_finish_kernel applies scale / shift / residual / ReLU in place.
 // Reference: the 3x3 stride-1 convolutions of libs/model/heatmapModel/hrnet.py (BasicBlock :49-76 and the
 // branches built from it); tolerance as for the F(2x2,3x3) kernels, see tools/wino43_network_study.py.
 #include <stdlib.h>
@@ -59,35 +65,54 @@ constexpr int W4_CO = 48;
 // The loads fetch pixel-major (32 contiguous bytes per pixel) and each lane stores its two channel pairs.
 template <int GEO>
 struct W4G {
-  static constexpr int RH = 18, RW = GEO ? 18 : 34;     // halo pixels of a region
-  static constexpr int RWP = GEO ? 20 : 40;             // load-element row pitch: a 16-lane store group = 4 / 8 ALIGNED pixels
-  static constexpr int XD = GEO ? 5 : 10;               // slots per row and plane (x div 4: 0..4 / 0..8)
+  static constexpr int NIMG = GEO == 2 ? 4 : 1;         // images of a region (GEO 2: whole 8 x 8 maps)
+  static constexpr int RH = GEO == 2 ? 10 : 18, RW = GEO == 0 ? 34 : (GEO == 1 ? 18 : 10);     // halo pixels of an image
+  // load-element row pitch: a 16-lane store group = 8 (GEO 0) / 4 ALIGNED pixels of one row
+  static constexpr int RWP = GEO == 0 ? 40 : (GEO == 1 ? 20 : 12);
+  static constexpr int XD = GEO == 0 ? 10 : (GEO == 1 ? 5 : 3);      // slots per row and plane (x div 4: 0..8 / 0..4 / 0..2)
   // plane / pair pitches carry a bank skew for the halo STORES (ds_write_b64 is served in groups of 16 lanes: 8 pixels x
-  // 2 quads, GEO 1: 4 pixels x 4 quads; without the skew the quads of a pixel fell on one bank: 2- / 4-way conflicts).
-  // GEO 0: pixel x -> 8 (x & 3) + 2 (x >> 2) dwords, quad -> + 4: 32 banks.  GEO 1: pixel -> 2 (x & 3), quad -> 8 q.
-  // The transform's READS are per (i, j) and per pair plane: they only see XD (bank-free as before).
-  static constexpr int PLANE = GEO ? 97 : RH * XD;      // >= RH * XD = 90 / 180; 2 PLANE mod 32 = 2 / 8 dwords
-  static constexpr int PAIR = GEO ? 394 : 4 * PLANE + 1;  // 8-byte slots per channel pair; 4 PAIR mod 32 = 8 / 4 dwords
+  // 2 quads, GEO 1 / 2: 4 pixels x 4 quads; without the skew the quads of a pixel fell on one bank: 2- / 4-way conflicts).
+  // GEO 0: pixel x -> 8 (x & 3) + 2 (x >> 2) dwords, quad -> + 4: 32 banks.  GEO 1 / 2: pixel -> 2 (x & 3), quad -> 8 q.
+  // The transform's READS are per (i, j) and per pair plane: they only see XD and the image bases (bank-free as before).
+  static constexpr int PLANE = GEO == 0 ? RH * XD : (GEO == 1 ? 97 : 145);     // 2 PLANE mod 32 = 8 / 2 / 2 dwords
+  static constexpr int PAIR = GEO == 0 ? 4 * PLANE + 1 : (GEO == 1 ? 394 : 586);   // 8-byte slots per channel pair; 4 PAIR mod 32 = 4 / 8 / 8 dwords
   static constexpr int QPP = GEO ? 4 : 2;               // channel quads per pixel and stage (16 / 8 channels)
-  static constexpr int HSLOT = 2 * QPP * PAIR;          // 2884 / 3152 slots of the 26 KB buffer
+  static constexpr int NP = GEO == 2 ? 3 : 2;           // halo load pieces per wave and stage
+  static constexpr int HSLOT = 2 * QPP * PAIR;          // 2884 / 3152 / 4688 slots
+  static constexpr int HBYTES = (GEO == 2 ? 38 : 26) * 1024;   // halo slots + 1 KB parking for the idle load lanes
   static constexpr int SBYTES = 16 * QPP;               // bytes of a pixel's channels of one stage
   static constexpr int NMT = GEO ? 1 : 2;               // m-tiles of a region
   static constexpr int NKK = GEO ? 2 : 1;               // k-groups multiplied per filter wait ("k-group pair")
-  static constexpr int TWX = GEO ? 4 : 8;               // tiles per region row
-  static constexpr int RGW = GEO ? 16 : 32;             // region width in pixels
+  static constexpr int TWX = GEO == 0 ? 8 : (GEO == 1 ? 4 : 2);      // tiles per image row
+  static constexpr int RGW = GEO == 0 ? 32 : (GEO == 1 ? 16 : 8);    // region width in pixels
+  static constexpr int RGH = GEO == 2 ? 8 : 16;                      // region height
+  // slot of image `img` inside a plane (GEO 2): 30 slots per image + a skew of 4 per image and 4 more per image PAIR, so
+  // that the 16 tiles of a read group (img 0..3 x ty 0..1 (12 slots) x tx 0..1) fall on 16 different even dwords mod 32
+  __host__ __device__ static constexpr int imgbase(int img) { return GEO == 2 ? 34 * img + 4 * (img >> 1) : 0; }
+  // halo slot of lane tile `li` (pixel (0, 0) of the tile, x & 3 == 0 plane)
+  __host__ __device__ static constexpr int tileslot(int li, int tw) {
+    return GEO == 0 ? 4 * XD * (2 * (tw >> 1) + (li >> 3)) + (li & 7)
+                    : (GEO == 1 ? 4 * XD * (li >> 2) + (li & 3) : imgbase(li >> 2) + 4 * XD * ((li >> 1) & 1) + (li & 1));
+  }
 };
 // GEO 1 (tests/test_wino4_design_cpu.py): slot (4 XD ty + tx) -> dword 40 ty + 2 tx + (kq & 1): ty 0..3 -> banks
-// +0, +8, +16, +24 -- 32 different banks per 32-lane group again.
-constexpr int W4_HBYTES = 26 * 1024;                  // halo slots (<= 25 216 B) + 1 KB parking for the idle load lanes
-constexpr int W4_VBYTES = 36 * 1024;                  // [pt][mt][g][lane] floats (GEO 1: [pt][g 0..3][lane])
-constexpr int W4_V0 = 0, W4_V1 = W4_VBYTES, W4_H0 = 2 * W4_VBYTES, W4_H1 = W4_H0 + W4_HBYTES;
-constexpr int W4_LDS = W4_H1 + W4_HBYTES;             // 126 976 B
+// +0, +8, +16, +24 -- 32 different banks per 32-lane group again.  GEO 2: slot imgbase(img) + 12 ty + tx -> dwords
+// {0, 2, 24, 26} + {0, 68, 144, 212} mod 32 = {0, 4, 16, 20}: 16 different even banks.
+constexpr int W4_VBYTES = 36 * 1024;                  // [pt][mt][g][lane] floats (GEO 1 / 2: [pt][g 0..3][lane])
+constexpr int W4_V0 = 0, W4_V1 = W4_VBYTES, W4_H0 = 2 * W4_VBYTES;
+template <int GEO>
+constexpr int w4_lds_bytes() { return W4_H0 + 2 * W4G<GEO>::HBYTES; }      // 126 976 B (GEO 0 / 1), 151 552 B (GEO 2)
 constexpr int W4_XBYTES = 36 * 3 * 1024;              // exchange [pt][nt][lane] float4: 110 592 B
-static_assert(W4_XBYTES <= W4_LDS, "the exchange reuses the stage buffers");
-static_assert(W4G<0>::HSLOT * 8 + 1024 <= W4_HBYTES && W4G<1>::HSLOT * 8 + 1024 <= W4_HBYTES,
+static_assert(W4_XBYTES <= w4_lds_bytes<0>(), "the exchange reuses the stage buffers");
+static_assert(W4G<0>::HSLOT * 8 + 1024 <= W4G<0>::HBYTES && W4G<1>::HSLOT * 8 + 1024 <= W4G<1>::HBYTES &&
+                  W4G<2>::HSLOT * 8 + 1024 <= W4G<2>::HBYTES,
               "the halo and the parking slots of the idle load lanes fit the buffer");
-static_assert(W4G<0>::QPP * W4G<0>::RH * W4G<0>::RWP <= 2 * W4_NW * 64 && W4G<1>::QPP * W4G<1>::RH * W4G<1>::RWP <= 2 * W4_NW * 64,
-              "two load pieces per wave cover the halo");
+static_assert(W4G<0>::QPP * W4G<0>::RH * W4G<0>::RWP <= W4G<0>::NP * W4_NW * 64 &&
+                  W4G<1>::QPP * W4G<1>::RH * W4G<1>::RWP <= W4G<1>::NP * W4_NW * 64 &&
+                  W4G<2>::QPP * W4G<2>::NIMG * W4G<2>::RH * W4G<2>::RWP <= W4G<2>::NP * W4_NW * 64,
+              "the load pieces of the waves cover the halo");
+static_assert(W4G<2>::imgbase(3) + W4G<2>::RH * W4G<2>::XD <= W4G<2>::PLANE && w4_lds_bytes<2>() + 12 * 96 * 8 <= 160 * 1024 - 512,
+              "GEO 2: four images fit a plane, the buffers fit the CU");
 constexpr int W4_UKG = W4_NW * 3 * 64 * 4;            // filter floats of one (co-tile, stage, k-group): 9216 (9 of 12 used)
 constexpr unsigned W4_PAST = 0x80000000u;             // scalar byte offset past every buffer (tensors stay below 2 GB)
 }  // namespace
@@ -125,6 +150,10 @@ template <int N>
 __device__ __forceinline__ void w4_vm_landed2(f32x4 (&h)[2]) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(h[0]), "+v"(h[1]) : "n"(N));
 }
+__device__ __forceinline__ void w4_vm_landedH(f32x4 (&h)[2]) { w4_vm_landed2<0>(h); }
+__device__ __forceinline__ void w4_vm_landedH(f32x4 (&h)[3]) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(h[0]), "+v"(h[1]), "+v"(h[2]));
+}
 // the filter registers of a wait group (one k-group: 3 dwordx4; GEO 1's k-group pair: 6), tied to the s_waitcnt
 __device__ __forceinline__ void w4_vm_landedB(f32x4 (&b)[1][3]) {
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]));
@@ -149,6 +178,32 @@ __device__ __forceinline__ float w4_xrd(unsigned xr0, unsigned xr1) {
   else return w4_lds<(PT - 18) * 3072>(xr1);
 }
 __device__ __forceinline__ unsigned w4_udiv(unsigned x, unsigned magic) { return magic ? __umulhi(x, magic) : x; }
+
+// Item order: what the XCD of a block (block index mod 8 -- blocks w, w + 8, ... stay on one XCD; a matter of speed only)
+// owns.  The transformed filter is 36 x 4 bytes per (ci, co): 21 MB at 384 -> 384 channels, 5.3 MB at 192 -> 192 -- more
+// than an XCD's 4 MB of L2, and a layer's filter arrives cold from HBM.
+//   0  regions: 8 consecutive regions on the 8 XCDs, every XCD streams the WHOLE filter (small filters: 48 / 96 channels);
+//   1  nct in {2, 4} (from W4_COX_MIN_NCT up): co-tile = xcd % nct, the XCD takes every (8 / nct)-th (region, half);
+//   2  nct a multiple of 8: co-tile = 8 j + xcd -- each XCD reads its share of the filter once and keeps it, and reads
+//      the halos of all regions instead (6 MB per 64 images at 384 channels).
+// Measured on the 64-crop network (profiles/r4_wino4c.txt): 384 -> 384 @ 8 x 8 with regions on the XCDs 13.60 ms per
+// batch, with co-tiles on them 13.17 ms.
+#ifndef W4_COX_MIN_NCT
+#define W4_COX_MIN_NCT 4
+#endif
+__host__ __device__ inline int w4_item_mode(int nct) {
+#ifdef W4_NO_COTILE_XCD
+  return 0;
+#else
+  if ((nct & 7) == 0) return 2;
+  return nct >= W4_COX_MIN_NCT && (nct == 2 || nct == 4) ? 1 : 0;
+#endif
+}
+__host__ __device__ inline int w4_item_count(int mode, int nreg, int nct, int ks) {
+  if (mode == 2) return nreg * nct * ks;
+  if (mode == 1) return 8 * ((nreg * ks + 8 / nct - 1) / (8 / nct));
+  return ((nreg + 7) >> 3) * nct * ks * 8;
+}
 
 // 1-D input transform of six values (12 instructions)
 __device__ __forceinline__ void w4_bt(const float (&t)[6], float (&o)[6]) {
@@ -176,8 +231,8 @@ __device__ __forceinline__ void w4_at(const float (&m)[6], float (&y)[4]) {
 template <int P, int PART, int GEO>
 __device__ __forceinline__ void w4_transform(unsigned hb0, unsigned vw0) {
   typedef W4G<GEO> Q;
-  static_assert(W4_H1 - W4_H0 + (3 * Q::PLANE + 5 * Q::XD + 1) * 8 < 65536, "halo immediates");
-  constexpr int HO = P ? W4_H1 - W4_H0 : 0;
+  static_assert(Q::HBYTES + (3 * Q::PLANE + 5 * Q::XD + 1) * 8 < 65536, "halo immediates");
+  constexpr int HO = P ? Q::HBYTES : 0;
 #define W4_D(I, J) w4_lds<HO + (((J) & 3) * Q::PLANE + (I)*Q::XD + ((J) >> 2)) * 8>(hb0)
 #define W4_WR(PT, VAL) asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(vw0), "v"(VAL), "n"((PT)*1024) : "memory")
 #define W4_ROW(FI, O)                                                                                   \
@@ -241,7 +296,7 @@ __device__ __forceinline__ void w4_transform(unsigned hb0, unsigned vw0) {
 // bit 5 bank-conflict-free halo reads, bit 6 s_memtime stamps (tools/wino4_clk.py).
 // (Round 4 also measured two other stage schedules -- the last transform third moved to mid-stage: no change; every
 // wave weaving its third between its own MFMA groups: 20-35 % slower -- profiles/r4_wino4_experiments.txt.)
-template <int ABL, int GEO>
+template <int ABL, int GEO, int KS = 1>
 __device__ __forceinline__ void w4_body(const ConvArgs& a) {
   typedef W4G<GEO> Q;
   extern __shared__ float4 w4_smem[];
@@ -257,7 +312,7 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
 
   const int C = a.Cin, Co = a.Cout;
   const int nct = Co / W4_CO;
-  const int S = C / (4 * Q::QPP);          // stages of 8 (GEO 0) / 16 (GEO 1) channels
+  const int S = C / (4 * Q::QPP * KS);     // stages of 8 (GEO 0) / 16 (GEO 1, 2) channels of an item (KS: its half of Cin)
 
   const unsigned long long xaddr = reinterpret_cast<unsigned long long>(a.x);
   const unsigned long long uaddr = reinterpret_cast<unsigned long long>(a.w);
@@ -270,23 +325,24 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
   const __amdgpu_buffer_rsrc_t rr =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res ? a.res : a.y), 0, out_bytes, 0x00020000);
 
-  // ---- halo loads: this wave's pieces wave and wave + 12; element e -> (pixel = e / QPP, channel quad e % QPP)
-  int hyx[2];
-  unsigned hrel[2], hws[2], hws2[2];
+  // ---- halo loads: this wave's pieces wave, wave + 12 (, wave + 24); element e -> (pixel = e / QPP, channel quad e % QPP)
+  int hyx[Q::NP];
+  unsigned hrel[Q::NP], hws[Q::NP], hws2[Q::NP];
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < Q::NP; ++k) {
     // LOAD order pixel-major, the channel quads of a pixel in neighbouring lanes (32 / 64 contiguous bytes: 32 or
     // 16 cache lines per instruction instead of 64); the lane stores its 16 bytes to the pixel's slots of the
     // bank-conflict-free order above
     const int e = (wave + W4_NW * k) * 64 + lane;
     const int px = e / Q::QPP, hq = e % Q::QPP;
-    const int hy = px / Q::RWP, hx = px - hy * Q::RWP;          // (rows padded to whole store groups)
-    const bool ok = hy < Q::RH && hx < Q::RW;
-    hyx[k] = ok ? ((hy << 16) | hx) : -1;
-    hrel[k] = ok ? (unsigned)(((hy * a.W + hx) * C + 4 * hq) * 4) : 0u;
+    const int hya = px / Q::RWP, hx = px - hya * Q::RWP;        // (rows padded to whole store groups)
+    const int img = hya / Q::RH, hy = hya - img * Q::RH;        // (GEO 2: the rows of the region's images follow each other)
+    const bool ok = img < Q::NIMG && hx < Q::RW;
+    hyx[k] = ok ? ((img << 24) | (hy << 16) | hx) : -1;
+    hrel[k] = ok ? (unsigned)((((img * a.H + hy) * a.W + hx) * C + 4 * hq) * 4) : 0u;
     // (lanes past the last pixel park their zeros in the unused tail of the buffer)
     // channels 4 hq, 4 hq + 1 -> pair plane 2 hq, channels 4 hq + 2, + 3 -> pair plane 2 hq + 1
-    const int slot = 2 * hq * Q::PAIR + (hx & 3) * Q::PLANE + hy * Q::XD + (hx >> 2);
+    const int slot = 2 * hq * Q::PAIR + (hx & 3) * Q::PLANE + Q::imgbase(img) + hy * Q::XD + (hx >> 2);
     hws[k] = lds0 + (unsigned)(W4_H0 + (ok ? slot * 8 : Q::HSLOT * 8 + lane * 8));
     hws2[k] = lds0 + (unsigned)(W4_H0 + (ok ? (slot + Q::PAIR) * 8 : Q::HSLOT * 8 + 512 + lane * 8));
   }
@@ -294,8 +350,7 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
   unsigned hb0, vw0;
   {
     const int g = GEO ? tw : (tw & 1);
-    const int ty = GEO ? (li >> 2) : (2 * (tw >> 1) + (li >> 3)), tx = GEO ? (li & 3) : (li & 7);
-    hb0 = lds0 + (unsigned)(W4_H0 + ((2 * g + (kq >> 1)) * Q::PAIR + 4 * Q::XD * ty + tx) * 8 + (kq & 1) * 4);
+    hb0 = lds0 + (unsigned)(W4_H0 + ((2 * g + (kq >> 1)) * Q::PAIR + Q::tileslot(li, tw)) * 8 + (kq & 1) * 4);
     vw0 = lds0 + (unsigned)(W4_V0 + tw * 256 + lane * 4);        // V[pt][mt * 2 + g | g][lane]
     if constexpr ((ABL & 32) != 0) hb0 = lds0 + (unsigned)(W4_H0 + lane * 4);     // conflict-free reads (wrong data)
   }
@@ -314,17 +369,21 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
   const unsigned xr0 = lds0 + (unsigned)((ont * 64 + okq * 16 + li) * 16) + (((unsigned)kq + 2u * xhi) & 3u) * 4u;
 
   const int regs_x = a.tiles_x, regs_xy = a.tiles_x * a.tiles_y;
-  const int nreg = regs_xy * a.N;
-  const int nwork = ((nreg + 7) >> 3) * nct * 8;
+  const int nreg = regs_xy * ((a.N + Q::NIMG - 1) / Q::NIMG);
+  const int imode = w4_item_mode(nct);     // what the XCD owns: regions / co-tiles (w4_item_mode)
+  const int nwork = w4_item_count(imode, nreg, nct, KS);
   const int gsz = __builtin_amdgcn_readfirstlane((int)gridDim.x);
   const float act_lo = (a.act & EGN_ACT_MASK) == EGN_ACT_RELU ? 0.f : -__builtin_inff();
-  const bool has_res = (ABL & 64) ? false : a.res != nullptr;
+  // K split: with a ticket word per item pair (ConvArgs::tickets, programs) the second half to finish does the
+  // epilogue; without one both halves add into a zeroed y (see the launcher)
+  const bool tk = KS > 1 && a.tickets != nullptr;
+  const bool has_res = (ABL & 64) || (KS > 1 && !tk) ? false : a.res != nullptr;
   const unsigned rowpitch = (unsigned)(a.Wo * Co) * 4u, colpitch = (unsigned)Co * 4u;
 
   // ABL & 64 (tools/wino4_clk.py): s_memtime stamps of every wave into the LDS above the stage buffers, dumped into
   // `res` at the end ([block][1 + 12 x 96] u64)
   constexpr int W4_NTK = 96;
-  unsigned long long* sT = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(w4_smem) + W4_LDS);
+  unsigned long long* sT = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(w4_smem) + w4_lds_bytes<GEO>());
   int ntk = 0;
 #define W4_CLK()                                                                        \
   {                                                                                     \
@@ -338,23 +397,35 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
     // item -> (region, co-tile): blocks w, w + 8, ... stay on one XCD (conv_wino.hip: wino8_grid)
     const unsigned wi = (unsigned)__builtin_amdgcn_readfirstlane(w);
     const unsigned xq = wi & 7u, q_ = wi >> 3;
+    // (mg_nct: the multiplier of nct * KS (mode 0) or of nct / 8 (mode 2); KS is a power of two)
     const unsigned qq = w4_udiv(q_, a.mg_nct);
-    const int reg = (int)(qq * 8u + xq);
-    const int ct = (int)(q_ - qq * (unsigned)nct);
-    if (reg >= nreg) continue;                         // (uniform) padding of the last group of 8
+    int reg, ct, ks;
+    if (imode == 0) {
+      const int cs_ = (int)(q_ - qq * (unsigned)(nct * KS));
+      reg = (int)(qq * 8u + xq); ct = cs_ / KS; ks = cs_ % KS;
+    } else if (imode == 1) {
+      const unsigned lg = (unsigned)nct >> 1;          // log2 of 2 / 4
+      const int cs_ = (int)(q_ * (8u >> lg) + (xq >> lg));
+      reg = cs_ / KS; ct = (int)(xq & ((unsigned)nct - 1u)); ks = cs_ % KS;
+    } else {
+      reg = (int)qq / KS; ct = (int)((q_ - qq * ((unsigned)nct >> 3)) * 8u + xq); ks = (int)qq % KS;
+    }
+    if (reg >= nreg) continue;                         // (uniform) padding of the last round of the XCDs
     const unsigned n_ = w4_udiv((unsigned)reg, a.mg_txy);
     const unsigned r_ = (unsigned)reg - n_ * (unsigned)regs_xy;
     const unsigned ry_ = w4_udiv(r_, a.mg_tx);
-    const int n = (int)n_, y0 = (int)ry_ * 16, x0 = (int)(r_ - ry_ * (unsigned)regs_x) * Q::RGW;
+    // (GEO 2: the region is the four images n .. n + 3; images past N load zeros and store nothing)
+    const int n = (int)n_ * Q::NIMG, y0 = (int)ry_ * Q::RGH, x0 = (int)(r_ - ry_ * (unsigned)regs_x) * Q::RGW;
 
     // halo offsets of the item (stage 0): uniform base + per-lane relative offset, zero padding by OOB offsets
-    unsigned doff[2];
+    unsigned doff[Q::NP];
     {
-      const int base = ((n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * C * 4;
+      // (KS: the item's half of the input channels starts ks * S stages into the pixel)
+      const int base = ((n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * C * 4 + ks * S * Q::SBYTES;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const unsigned iy = (unsigned)(y0 - 1 + (hyx[k] >> 16)), ix = (unsigned)(x0 - 1 + (hyx[k] & 0xffff));
-        const bool in = hyx[k] >= 0 && iy < (unsigned)a.H && ix < (unsigned)a.W;
+      for (int k = 0; k < Q::NP; ++k) {
+        const unsigned iy = (unsigned)(y0 - 1 + ((hyx[k] >> 16) & 0xff)), ix = (unsigned)(x0 - 1 + (hyx[k] & 0xffff));
+        const bool in = hyx[k] >= 0 && iy < (unsigned)a.H && ix < (unsigned)a.W && n + (hyx[k] >> 24) < a.N;
         doff[k] = in ? (unsigned)base + hrel[k] : EGN_OOB;
       }
     }
@@ -363,17 +434,18 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
 #define W4_HLOAD(K, STAGE) /* piece K of this wave; STAGE: byte offset of the stage's channels, W4_PAST = none */ \
   if constexpr ((ABL & 16) == 0) hreg[K] = w4_gld4<0>(rxv, doff[K], (unsigned)(STAGE));                        \
   else hreg[K] = f32x4{1.f, 2.f, 3.f, (float)lane};
+#define W4_HLOADS(STAGE) W4_HLOAD(0, STAGE) W4_HLOAD(1, STAGE) if constexpr (Q::NP == 3) { W4_HLOAD(Q::NP - 1, STAGE) }
 #define W4_HSTORE(P)                                                                                           \
   {                                                                                                            \
-    w4_xwr2<(P)*W4_HBYTES>(hws[0], hreg[0][0], hreg[0][1]);                                                    \
-    w4_xwr2<(P)*W4_HBYTES>(hws2[0], hreg[0][2], hreg[0][3]);                                                   \
-    w4_xwr2<(P)*W4_HBYTES>(hws[1], hreg[1][0], hreg[1][1]);                                                    \
-    w4_xwr2<(P)*W4_HBYTES>(hws2[1], hreg[1][2], hreg[1][3]);                                                   \
+    _Pragma("unroll") for (int k_ = 0; k_ < Q::NP; ++k_) {                                                     \
+      w4_xwr2<(P)*Q::HBYTES>(hws[k_], hreg[k_][0], hreg[k_][1]);                                               \
+      w4_xwr2<(P)*Q::HBYTES>(hws2[k_], hreg[k_][2], hreg[k_][3]);                                              \
+    }                                                                                                          \
   }
     // filter of this wave: k-group h (4 channels) = [co-tile][h][wave][3 x dwordx4 per lane] (engine.pack_wino4_weight);
     // a wait group is one k-group (GEO 0: x 2 m-tiles) or two consecutive ones (GEO 1).  Raw ISA -- the waits are
     // mine (tools/check_wino4_isa.py checks that no load's destination is touched before its wait)
-    const unsigned ubase = (unsigned)(ct * (C >> 2)) * (W4_UKG * 4u) + (unsigned)wave * (3u * 64u * 16u);
+    const unsigned ubase = (unsigned)(ct * (C >> 2) + ks * (C >> 2) / KS) * (W4_UKG * 4u) + (unsigned)wave * (3u * 64u * 16u);
 #define W4_LOADB(DST, HS)                                                                                      \
   if constexpr ((ABL & 8) != 0) {                                                                              \
     _Pragma("unroll") for (int k_ = 0; k_ < Q::NKK; ++k_)                                                      \
@@ -389,15 +461,13 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
   }
     constexpr unsigned WGB = (unsigned)Q::NKK * W4_UKG * 4u;       // filter bytes between consecutive wait groups
     f32x4 b0[Q::NKK][3], b1[Q::NKK][3];       // value p = 3 pl + nt of a k-group = b[kk][p >> 2][p & 3]
-    f32x4 hreg[2];
-    W4_HLOAD(0, 0u)
-    W4_HLOAD(1, 0u)
+    f32x4 hreg[Q::NP];
+    W4_HLOADS(0u)
     W4_LOADB(b0, ubase)
     W4_CLK()      /* item top: halo + filter loads issued */
-    w4_vm_landed2<0>(hreg);                             // stage 0's pieces (and the first filter wait group)
+    w4_vm_landedH(hreg);                                // stage 0's pieces (and the first filter wait group)
     W4_HSTORE(0)
-    W4_HLOAD(0, (unsigned)Q::SBYTES)                    // stage 1's pieces fly during the first transform
-    W4_HLOAD(1, (unsigned)Q::SBYTES)
+    W4_HLOADS((unsigned)Q::SBYTES)                      // stage 1's pieces fly during the first transform
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     W4_CLK()      /* own pieces of stage 0 in LDS */
     __builtin_amdgcn_s_barrier();
@@ -411,7 +481,7 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
     asm volatile("" ::: "memory");
     // this wave's pieces of stage 1 (and the filter loads before them) have landed: into LDS with them -- the
     // first third transforms stage 1 right behind the barrier
-    w4_vm_landed2<0>(hreg);
+    w4_vm_landedH(hreg);
     W4_HSTORE(1)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     W4_CLK()      /* stage 0 transformed */
@@ -493,10 +563,10 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
     W4_CLK() /* 3: filter wait group 2s+1 landed */                                                            \
     W4_LOADB(b0, bn_)       /* (its registers are free: G = 0 is issued) a whole half stage of flight */       \
     W4_TRANS(P, 1)                                                                                             \
-    W4_MUL(P, 1, b1, W4_HLOAD(0, dst_), W4_HLOAD(1, dst_), )                                                   \
+    W4_MUL(P, 1, b1, W4_HLOAD(0, dst_), W4_HLOAD(1, dst_), if constexpr (Q::NP == 3) { W4_HLOAD(Q::NP - 1, dst_) })   \
     W4_TRANS(P, 2)                                                                                             \
     W4_CLK() /* 4: G = 1 multiplies and wait group 2s+2 issued (+ transforms) */                               \
-    w4_vm_landed2<0>(hreg);          /* the pieces of stage s + 2 and wait group 2s+2 */                       \
+    w4_vm_landedH(hreg);             /* the pieces of stage s + 2 and wait group 2s+2 */                       \
     W4_HSTORE(P)                                                                                               \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
     W4_CLK() /* 5: own pieces of stage s + 2 in LDS, V writes done */                                          \
@@ -508,7 +578,7 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
       W4_STAGE(0, s)
       W4_STAGE(1, s + 1)
     }
-    if constexpr (GEO == 1) {
+    if constexpr (GEO != 0) {
       if (S & 1) W4_STAGE(0, S - 1)          // 48 / 16 = 3 stages: the odd one (every item starts at parity 0)
     }
     // the loads past the end: tied to the wait -- for the compiler their registers are dead at the loop exit, and it
@@ -516,13 +586,14 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
     // the item end, caught by tools/check_wino4_isa.py)
     w4_vm_landedB(b0);
     w4_vm_landedB(b1);
-    w4_vm_landed2<0>(hreg);
+    w4_vm_landedH(hreg);
     W4_CLK()      /* K loop done */
 #undef W4_STAGE
 #undef W4_TRANS
 #undef W4_MUL
 #undef W4_MUL6
 #undef W4_HLOAD
+#undef W4_HLOADS
 #undef W4_HSTORE
 #undef W4_LOADB
 
@@ -544,8 +615,12 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
     for (int mt = 0; mt < Q::NMT; ++mt) {
       // this lane's output tile of the round: tile 4 okq + kq of m-tile mt, channel 16 ont + li
       const int tile = 4 * okq + kq;
-      const int ty = GEO ? (tile >> 2) : (2 * mt + (tile >> 3)), tx = GEO ? (tile & 3) : (tile & 7);
-      const unsigned vo = (unsigned)((((n * a.Ho + y0 + 4 * ty) * a.Wo + x0 + 4 * tx) * Co + ct * W4_CO + ont * 16 + li) * 4);
+      const int oimg = GEO == 2 ? (tile >> 2) : 0;
+      const int ty = GEO == 0 ? (2 * mt + (tile >> 3)) : (GEO == 1 ? (tile >> 2) : ((tile >> 1) & 1));
+      const int tx = GEO == 0 ? (tile & 7) : (GEO == 1 ? (tile & 3) : (tile & 1));
+      const unsigned vo = n + oimg < a.N ? (unsigned)(((((n + oimg) * a.Ho + y0 + 4 * ty) * a.Wo + x0 + 4 * tx) * Co +
+                                                       ct * W4_CO + ont * 16 + li) * 4)
+                                         : EGN_OOB;
       float rv[4][4];
 #pragma unroll
       for (int oa = 0; oa < 4; ++oa)
@@ -589,10 +664,68 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
       for (int oa = 0; oa < 4; ++oa) {
         float yo[4];
         w4_at(yc[oa], yo);
+        if constexpr (KS > 1) {
 #pragma unroll
-        for (int ob = 0; ob < 4; ++ob) {
-          const float v = fmaxf(__builtin_fmaf(yo[ob], sc, sh) + rv[oa][ob], act_lo);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, vo, oa * rowpitch + ob * colpitch, 0);
+          for (int ob = 0; ob < 4; ++ob) yc[oa][ob] = yo[ob];      // (the column values of this row are spent)
+        } else {
+#pragma unroll
+          for (int ob = 0; ob < 4; ++ob) {
+            const float v = fmaxf(__builtin_fmaf(yo[ob], sc, sh) + rv[oa][ob], act_lo);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, vo, oa * rowpitch + ob * colpitch, 0);
+          }
+        }
+      }
+      if constexpr (KS > 1) {
+        // yc[oa][ob]: this item's share of the output sum (its half of the input channels)
+        if (!tk) {      // no ticket word: add into the zeroed y; conv_wino4_finish_kernel does the rest
+#pragma unroll
+          for (int oa = 0; oa < 4; ++oa)
+#pragma unroll
+            for (int ob = 0; ob < 4; ++ob)
+              __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(yc[oa][ob], ry, vo, oa * rowpitch + ob * colpitch, 0);
+        } else {
+          // The two halves of an item pair meet through a ticket word (zero between launches).  Whoever finishes its
+          // K loop first writes its raw share THROUGH to memory (sc1 stores into y: no release fence -- a buffer_wbl2
+          // per block costs microseconds and all 768 lanes fencing 4x that), drains its stores and bumps the word to
+          // 3; the other half polls for that with relaxed loads (its partner is already in its item end: no dependence
+          // on dispatch order or placement), reads the share back with sc1 loads (past the CU's L1: no acquire fence,
+          // MI355X_MICROARCH.md "inter-workgroup visibility": sc1 stores AND sc1 loads), adds its own and applies the
+          // epilogue.  Two addends: the sum does not depend on who came first.
+          constexpr int SC1 = 16;            // aux bit of the raw buffer builtins
+          unsigned* tkw = a.tickets + (reg * nct + ct);
+          unsigned* tks = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(w4_smem) + W4_XBYTES);   // (past the exchange)
+          if (tid == 0) *tks = __hip_atomic_fetch_add(tkw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __syncthreads();
+          const bool first = __builtin_amdgcn_readfirstlane(*tks) == 0u;
+          if (first) {
+#pragma unroll
+            for (int oa = 0; oa < 4; ++oa)
+#pragma unroll
+              for (int ob = 0; ob < 4; ++ob)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yc[oa][ob]), ry, vo,
+                                                      oa * rowpitch + ob * colpitch, SC1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its stores have left the CU
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(tkw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            if (tid == 0)
+              while (__hip_atomic_load(tkw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 3u) __builtin_amdgcn_s_sleep(2);
+            __syncthreads();
+            float pv[4][4];
+#pragma unroll
+            for (int oa = 0; oa < 4; ++oa)
+#pragma unroll
+              for (int ob = 0; ob < 4; ++ob)
+                pv[oa][ob] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ry, vo, oa * rowpitch + ob * colpitch, SC1));
+#pragma unroll
+            for (int oa = 0; oa < 4; ++oa)
+#pragma unroll
+              for (int ob = 0; ob < 4; ++ob) {
+                const float v = fmaxf(__builtin_fmaf(yc[oa][ob] + pv[oa][ob], sc, sh) + rv[oa][ob], act_lo);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, vo, oa * rowpitch + ob * colpitch, 0);
+              }
+            if (tid == 0) __hip_atomic_store(tkw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       }
       asm volatile("" ::: "memory");
@@ -616,14 +749,47 @@ template <int ABL>
 __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) { w4_body<ABL, 0>(a); }
 template <int ABL>
 __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4b_kernel(ConvArgs a) { w4_body<ABL, 1>(a); }
+template <int ABL, int KS>
+__global__ __launch_bounds__(W4_NTH, 1) void conv_wino4c_kernel(ConvArgs a) { w4_body<ABL, 2, KS>(a); }
 
+// second pass of the K-split form: y holds the sum of the items' raw outputs; y = act(y * scale + shift + res) in place
+__global__ __launch_bounds__(256) void conv_wino4_finish_kernel(float* __restrict__ y, const float* __restrict__ res,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, unsigned n4, unsigned co4,
+                                                                float act_lo) {
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n4) return;
+  const unsigned c = i % co4;
+  const float4 sc = reinterpret_cast<const float4*>(scale)[c], sh = reinterpret_cast<const float4*>(shift)[c];
+  float4 v = reinterpret_cast<float4*>(y)[i];
+  const float4 r = res ? reinterpret_cast<const float4*>(res)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  v.x = fmaxf(__builtin_fmaf(v.x, sc.x, sh.x) + r.x, act_lo);
+  v.y = fmaxf(__builtin_fmaf(v.y, sc.y, sh.y) + r.y, act_lo);
+  v.z = fmaxf(__builtin_fmaf(v.z, sc.z, sh.z) + r.z, act_lo);
+  v.w = fmaxf(__builtin_fmaf(v.w, sc.w, sh.w) + r.w, act_lo);
+  reinterpret_cast<float4*>(y)[i] = v;
+}
+
+// geo: bits 0-1 the geometry (0: 16 x 32 regions, 1: 16 x 16 regions, 2: four 8 x 8 images), bit 2: input channels split
+// over two items (geometry 2 only)
 bool egn_conv_wino4_applies(const ConvArgs& a, int geo) {
+  const int g = geo & 3, ks = (geo & 4) ? 2 : 1;
+  if (g > 2 || (ks > 1 && g != 2)) return false;
+  const bool map_ok = g == 2 ? (a.Ho == 8 && a.Wo == 8) : (a.Ho % 16 == 0 && a.Wo % (g ? 16 : 32) == 0);
+  // (K split: whole 16-channel stages per half; the residual is read after y was zeroed -- it must be another buffer)
+  if (ks > 1 && (a.Cin % 32 || (a.res && a.res == a.y))) return false;
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Cin % 16 == 0 && a.cs_in == a.Cin &&
-         a.Cout % W4_CO == 0 && a.cs_out == a.Cout && !a.out_nchw && a.Ho % 16 == 0 && a.Wo % (geo ? 16 : 32) == 0 &&
-         !(a.act & EGN_ACT_RES_AFTER) &&
+         a.Cout % W4_CO == 0 && a.cs_out == a.Cout && !a.out_nchw && map_ok && !(a.act & EGN_ACT_RES_AFTER) &&
          ((a.act & EGN_ACT_MASK) == EGN_ACT_NONE || (a.act & EGN_ACT_MASK) == EGN_ACT_RELU);
 }
-size_t egn_conv_wino4_lds_bytes() { return W4_LDS + 12 * 96 * 8; }      // (+ the stamp area of the ABL & 64 build)
+// ticket words a K-split launch wants (zeroed once; every launch leaves them zero): one per (region, co-tile); 0 = none
+int egn_conv_wino4_tickets(const ConvArgs& a, int geo) {
+  if ((geo & 7) != 6 || !egn_conv_wino4_applies(a, geo)) return 0;
+  return ((a.N + 3) / 4) * (a.Cout / W4_CO);
+}
+size_t egn_conv_wino4_lds_bytes(int geo) {      // (+ the stamp area of the ABL & 64 build)
+  return ((geo & 3) == 2 ? w4_lds_bytes<2>() : w4_lds_bytes<0>()) + 12 * 96 * 8;
+}
 // floats of the packed filter (engine.pack_wino4_weight): [co-tile][k-group = Cin / 4][wave][9 of 12][64]
 extern "C" long long egn_wino4_weight_floats(int cout, int cin) {
   if (cout % W4_CO || cin % 8 || cin < 16) return 0;
@@ -632,11 +798,11 @@ extern "C" long long egn_wino4_weight_floats(int cout, int cin) {
 
 static unsigned w4_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
-template <int ABL, int GEO>
+template <int ABL, int GEO, int KS>
 static int wino4_launch(ConvArgs a, size_t lds, hipStream_t stream) {
   static bool raised[EGN_MAX_DEVICES];
   static int cus = 0;
-  auto kern = GEO ? &conv_wino4b_kernel<ABL> : &conv_wino4_kernel<ABL>;
+  auto kern = GEO == 2 ? &conv_wino4c_kernel<ABL, KS> : (GEO ? &conv_wino4b_kernel<ABL> : &conv_wino4_kernel<ABL>);
   if (egn_first_use_on_device(raised)) {
     EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024 - 512));
@@ -647,44 +813,58 @@ static int wino4_launch(ConvArgs a, size_t lds, hipStream_t stream) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
-  const int nct = a.Cout / W4_CO;
-  const int nreg = a.tiles_x * a.tiles_y * a.N;
-  const int nwork = ((nreg + 7) / 8) * 8 * nct;
+  const int nct = a.Cout / W4_CO, nck = nct * KS;
+  const int nreg = a.tiles_x * a.tiles_y * ((a.N + W4G<GEO>::NIMG - 1) / W4G<GEO>::NIMG);
+  const int imode = w4_item_mode(nct);
+  const int nwork = w4_item_count(imode, nreg, nct, KS);
   // the item index divisions run as one multiply-high each: exact while x * d < 2^32 (x = the dividend's range)
-  if ((unsigned long long)nwork * (unsigned)(8 * nct) >= 0x100000000ull ||
+  if ((unsigned long long)nwork * (unsigned)(8 * nck) >= 0x100000000ull ||
       (unsigned long long)(nreg + 8) * (unsigned)(a.tiles_x * a.tiles_y) >= 0x100000000ull)
     return EGN_E_BADARG;
-  a.mg_nct = w4_magic(nct);
+  a.mg_nct = imode == 1 ? 0u : w4_magic(imode == 2 ? nct / 8 : nck);
   a.mg_txy = w4_magic(a.tiles_x * a.tiles_y);
   a.mg_tx = w4_magic(a.tiles_x);
-  int cap = cus / (8 * nct) * (8 * nct);              // one 120 KB block per CU, whole XCD rounds
-  if (cap <= 0) cap = 8 * nct;
+  int cap = cus / (8 * nck) * (8 * nck);              // one block per CU, whole XCD rounds
+  if (cap <= 0) cap = 8 * nck;
   const int grid = nwork < cap ? nwork : cap;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(W4_NTH), lds, stream, a);
+  if (KS > 1 && !a.tickets) {
+    const size_t n = (size_t)a.N * a.Ho * a.Wo * a.Cout;
+    EGN_CHECK_HIP(hipMemsetAsync(a.y, 0, n * sizeof(float), stream));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(W4_NTH), lds, stream, a);
+    const float act_lo = (a.act & EGN_ACT_MASK) == EGN_ACT_RELU ? 0.f : -__builtin_inff();
+    hipLaunchKernelGGL(conv_wino4_finish_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, a.y, a.res,
+                       a.scale, a.shift, (unsigned)(n / 4), (unsigned)(a.Cout / 4), act_lo);
+  } else {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(W4_NTH), lds, stream, a);
+  }
   return (int)hipGetLastError();
 }
 int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, int geo, hipStream_t stream) {
   if (!egn_conv_wino4_applies(a, geo) || a.stats) return EGN_E_BADARG;
+  if ((geo & 3) == 2) {
+    if (abl) return EGN_E_BADARG;
+    return (geo & 4) ? wino4_launch<0, 2, 2>(a, lds, stream) : wino4_launch<0, 2, 1>(a, lds, stream);
+  }
   if (geo) {
     switch (abl) {
-      case 0: return wino4_launch<0, 1>(a, lds, stream);
+      case 0: return wino4_launch<0, 1, 1>(a, lds, stream);
 #ifdef EGN_PROBES
-      case 64: return wino4_launch<64, 1>(a, lds, stream);
+      case 64: return wino4_launch<64, 1, 1>(a, lds, stream);
 #endif
       default: return EGN_E_BADARG;
     }
   }
   switch (abl) {
-    case 0: return wino4_launch<0, 0>(a, lds, stream);
+    case 0: return wino4_launch<0, 0, 1>(a, lds, stream);
 #ifdef EGN_PROBES       // timing ablations / stamp builds: tools/ only (python -m egonet_amd.build --probes)
-    case 1: return wino4_launch<1, 0>(a, lds, stream);
-    case 2: return wino4_launch<2, 0>(a, lds, stream);
-    case 4: return wino4_launch<4, 0>(a, lds, stream);
-    case 8: return wino4_launch<8, 0>(a, lds, stream);
-    case 16: return wino4_launch<16, 0>(a, lds, stream);
-    case 7: return wino4_launch<7, 0>(a, lds, stream);
-    case 32: return wino4_launch<32, 0>(a, lds, stream);
-    case 64: return wino4_launch<64, 0>(a, lds, stream);
+    case 1: return wino4_launch<1, 0, 1>(a, lds, stream);
+    case 2: return wino4_launch<2, 0, 1>(a, lds, stream);
+    case 4: return wino4_launch<4, 0, 1>(a, lds, stream);
+    case 8: return wino4_launch<8, 0, 1>(a, lds, stream);
+    case 16: return wino4_launch<16, 0, 1>(a, lds, stream);
+    case 7: return wino4_launch<7, 0, 1>(a, lds, stream);
+    case 32: return wino4_launch<32, 0, 1>(a, lds, stream);
+    case 64: return wino4_launch<64, 0, 1>(a, lds, stream);
 #endif
     default: return EGN_E_BADARG;
   }

@@ -48,6 +48,10 @@ struct ConvArgs {
   // conv_wino9_kernel: multipliers ceil(2^32 / d) for the item index divisions by nct, tiles_x * tiles_y and
   // tiles_x (0 = the divisor is 1), set by its launcher -- the divisions run on the scalar unit
   unsigned mg_nct, mg_txy, mg_tx;
+  // conv_wino4c_kernel<., 2> (input channels of an item split over two blocks): one zeroed word per item pair,
+  // egn_conv_ticket_count() of them -- the second block to finish applies the epilogue.  NULL: the launcher zeroes y,
+  // both blocks add into it and conv_wino4_finish_kernel applies the epilogue (three launches instead of one).
+  unsigned* tickets;
 };
 
 struct ConvConfig {
@@ -67,3 +71,4 @@ int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream);
 int egn_conv_plan(ConvArgs& a, int& cfg_id, size_t& lds_bytes);
 const ConvConfig* egn_conv_config(int cfg);
 int egn_conv_stats_rows(const ConvArgs& a, int cfg_id);
+int egn_conv_ticket_count(const ConvArgs& a, int cfg_id);   // a planned for cfg_id; 0 = the config uses none

@@ -135,6 +135,7 @@ struct Op {
 struct egn_program {
   std::vector<void*> slots;
   std::vector<Op> ops;
+  std::vector<void*> owned;   // device words of the program's own (ConvArgs::tickets of K-split convs): freed with it
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
   int cur_lane = 0;
@@ -163,6 +164,7 @@ extern "C" void egn_program_destroy(egn_program* p) {
   if (!p) return;
   if (p->exec) hipGraphExecDestroy(p->exec);
   if (p->graph) hipGraphDestroy(p->graph);
+  for (void* d : p->owned) hipFree(d);
   for (int k = 1; k < kMaxLanes; ++k) {
     if (p->side[k]) hipStreamDestroy(p->side[k]);
     if (p->ev_join[k]) hipEventDestroy(p->ev_join[k]);
@@ -204,6 +206,16 @@ extern "C" int egn_program_add_conv2d(egn_program* p, egn_ref x, egn_ref wpack, 
     if (!ref_ok(p, op.r[k])) return EGN_E_BADARG;
   op.flops = 2.0 * N * op.conv.Ho * op.conv.Wo * (double)Cout * Cin * KH * KW;
   op.lane = p->cur_lane;
+  // K-split configurations (conv_wino4.hip) run as one kernel when the op brings a ticket word per item pair: they
+  // belong to the op (a program never runs beside itself), are zeroed here and left zero by every launch
+  const int ntk = egn_conv_ticket_count(op.conv, cfg);
+  if (ntk > 0) {
+    void* d = nullptr;
+    EGN_CHECK_HIP(hipMalloc(&d, (size_t)ntk * sizeof(unsigned)));
+    p->owned.push_back(d);
+    EGN_CHECK_HIP(hipMemset(d, 0, (size_t)ntk * sizeof(unsigned)));
+    op.conv.tickets = static_cast<unsigned*>(d);
+  }
   p->ops.push_back(op);
   return 0;
 }

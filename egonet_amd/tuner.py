@@ -49,29 +49,49 @@ def autotune_enabled():
 
 
 def _time_cfg(L, args, cfg, stream, x, w, sc, sh, res, y):
+    """One conv of shape ``args`` under configuration ``cfg`` as a ONE-OP PROGRAM -- the way the engine launches it
+    (configurations that split a layer over several kernels when called through egn_conv2d_f32 run as one launch inside
+    a program: conv_wino4c_kernel's ticket words belong to the program's op).  Min of 5 after 2 warm-ups, ms."""
     n, h, wd, cin, cs_in, cout, cs_out, kh, kw, stride, pad, has_res, out_nchw = args
-
-    def launch():
-        return L.egn_conv2d_f32(_lib.ptr(x), _lib.ptr(w), _lib.ptr(sc), _lib.ptr(sh),
-                                _lib.ptr(res) if has_res else None, _lib.ptr(y), n, h, wd, cin, cs_in,
-                                cout, cs_out, kh, kw, stride, pad, 1, int(out_nchw), cfg, stream)
-    if launch() != 0:
+    prog = C.c_void_p(L.egn_program_create(8))
+    if not prog:
         return None
-    launch()
-    best = None
-    for _ in range(5):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+    try:
+        refs = []
+        for slot, t in enumerate((x, w, sc, sh, res if has_res else None, y)):
+            if t is None:
+                refs.append(_lib.NULL_REF)
+                continue
+            if L.egn_program_bind(prog, slot, _lib.ptr(t)) != 0:
+                return None
+            refs.append(_lib.Ref(slot, 0))
+        if L.egn_program_add_conv2d(prog, *refs, n, h, wd, cin, cs_in, cout, cs_out, kh, kw, stride, pad, 1,
+                                    int(out_nchw), cfg) != 0:
+            return None
+
+        def launch():
+            return L.egn_program_run(prog, stream)
+        if launch() != 0:
+            return None
         launch()
-        e1.record()
-        e1.synchronize()
-        t = e0.elapsed_time(e1)
-        best = t if best is None or t < best else best
-    return best
+        best = None
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch()
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            best = t if best is None or t < best else best
+        return best
+    finally:
+        torch.cuda.synchronize()
+        L.egn_program_destroy(prog)
 
 
-def tune(device, args, skip=()):
-    """Time every tile configuration on the real shape (except ``skip``); returns (cfg, {cfg: ms})."""
+def tune(device, args, skip=(), only=None):
+    """Time every tile configuration on the real shape (except ``skip``; ``only``: just these ids); returns
+    (cfg, {cfg: ms})."""
     L = _lib.lib()
     n, h, wd, cin, cs_in, cout, cs_out, kh, kw, stride, pad, has_res, out_nchw = args
     ho = (h + 2 * pad - kh) // stride + 1
@@ -92,8 +112,8 @@ def tune(device, args, skip=()):
         stream = _lib.current_stream(device)
         times = {}
         for cfg in range(1, L.egn_conv_num_configs() + 1):
-            if L.egn_conv_config_kind(cfg) < 0 or cfg in skip:      # timing-ablation builds
-                continue
+            if L.egn_conv_config_kind(cfg) < 0 or cfg in skip or (only is not None and cfg not in only):
+                continue                                              # (kind < 0: timing-ablation builds)
             out = (C.c_int * 12)()
             if L.egn_conv_plan_query(n, h, wd, cin, cs_in, cout, cs_out, kh, kw, stride, pad,
                                      int(out_nchw), cfg, out) != 0:

@@ -278,6 +278,95 @@ def test_conv_wino4b_kernel(n, h, w, cin, cout, res, act):
     assert L.egn_conv_plan_query(2, 16, 24, 48, 48, 48, 48, 3, 3, 1, 1, 0, 80, out) != 0
 
 
+@pytest.mark.parametrize('cfg', [82, 83])
+@pytest.mark.parametrize('n,cin,cout,res,act', [
+    (4, 32, 48, True, 1),       # one region, one stage per half (83) / two stages (82)
+    (8, 384, 384, True, 1),     # the 8 x 8 maps of the 384-channel branch (hrnet.py stage 4): 8 co-tiles, 24 stages
+    (6, 96, 96, False, 0),      # ragged last region (images 4, 5 + two absent ones), no activation, no residual
+    (1, 64, 144, True, 1),      # a single image: three absent images in the region
+    (37, 96, 48, True, 0),      # odd batch: 10 regions, the last one with a single image
+    (64, 384, 384, True, 1),    # BASELINE configs[1]'s batch: 16 regions x 8 co-tiles (x 2 halves = one item per CU)
+])
+def test_conv_wino4c_kernel(cfg, n, cin, cout, res, act):
+    """Configs 82 / 83, conv_wino4c_kernel<0, 1 | 2>: the F(4x4,3x3) body of csrc/conv_wino4.hip on regions of FOUR
+    8 x 8 images (hrnet.py's 384-channel branch), 83 with the input channels of an item split over two blocks that add
+    their raw outputs into a zeroed y (conv_wino4_finish_kernel applies scale / shift / residual / ReLU).  Same filter
+    pack, oracle and tolerance as config 70; two addends onto zero: 83 is run twice and must be bit-identical."""
+    import ctypes as C
+    from egonet_amd import _lib, ops
+    L = _lib.lib()
+    assert L.egn_conv_config_kind(cfg) == 3
+    out = (C.c_int * 12)()
+    assert L.egn_conv_plan_query(n, 8, 8, cin, cin, cout, cout, 3, 3, 1, 1, 0, cfg, out) == 0
+    assert list(out)[5:8] == [8, 8, 4]
+    err = _conv_case(n, 8, 8, cin, cout, 3, 1, 1, act=act, use_res=res, cfg=cfg, seed=n + cin + cfg)
+    assert err < 5e-4, err
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(n, 8, 8, cin, generator=g).cuda()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    pc = ops.PackedConv(wt, None, None, kind=3)
+    r = torch.randn(n, 8, 8, cout, generator=g).cuda() if res else None
+    ya = ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=cfg)
+    yb = ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=cfg)
+    yc = ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=82)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+    # the split changes the summation order of the two channel halves only (same tolerance as against the oracle)
+    assert (ya - yc).abs().max().item() < 5e-4
+    for hh, ww, ci in ((16, 16, 48), (8, 16, 48), (4, 4, 48)):
+        assert L.egn_conv_plan_query(2, hh, ww, ci, ci, 48, 48, 3, 3, 1, 1, 0, cfg, out) != 0
+    if cfg == 83:       # whole 16-channel stages per half
+        assert L.egn_conv_plan_query(2, 8, 8, 48, 48, 48, 48, 3, 3, 1, 1, 0, 83, out) != 0
+
+
+@pytest.mark.parametrize('n,cin,cout,res,act', [(64, 384, 384, True, 1), (10, 96, 96, True, 1), (5, 64, 48, False, 0)])
+def test_conv_wino4c_ticket_path_of_programs(n, cin, cout, res, act):
+    """Config 83 inside a program (egn_program_add_conv2d): the op owns one zeroed ticket word per item pair and the layer
+    is ONE launch -- the half of a pair that finishes second adds the first one's raw share (read back from y) and applies
+    the epilogue -- instead of memset + atomic adds + conv_wino4_finish_kernel (egn_conv2d_f32, no ticket words).  Same
+    arithmetic per output: bit-identical to that path; launched many times (every launch must leave the words zero), run
+    eagerly and as a captured graph."""
+    from egonet_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(n + cin)
+    x = torch.randn(n, 8, 8, cin, generator=g).cuda()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    bn = _bn(cout, g)
+    pc = ops.PackedConv(wt, None, bn, kind=3)
+    r = torch.randn(n, 8, 8, cout, generator=g).cuda() if res else None
+    want = ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=83)
+    y = torch.full((n, 8, 8, cout), float('nan'), device='cuda')
+    h = L.egn_program_create(8)
+    assert h
+    try:
+        tensors = [x, pc.w, pc.scale, pc.shift, r, y]
+        refs = []
+        for slot, t in enumerate(tensors):
+            if t is None:
+                refs.append(_lib.NULL_REF)
+                continue
+            assert L.egn_program_bind(h, slot, _lib.ptr(t)) == 0
+            refs.append(_lib.Ref(slot, 0))
+        assert L.egn_program_add_conv2d(h, *refs, n, 8, 8, cin, cin, cout, cout, 3, 3, 1, 1, act, 0, 83) == 0
+        side = torch.cuda.Stream()          # (a capture needs a stream of its own)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            st = _lib.current_stream()
+            for _ in range(20):
+                y.fill_(float('nan'))
+                assert L.egn_program_run(h, st) == 0
+                torch.cuda.synchronize()
+                assert torch.equal(y, want)
+            assert L.egn_program_capture(h, st) == 0
+            for _ in range(5):
+                y.fill_(float('nan'))
+                assert L.egn_program_replay(h, st) == 0
+                torch.cuda.synchronize()
+                assert torch.equal(y, want)
+    finally:
+        L.egn_program_destroy(h)
+
+
 @pytest.mark.parametrize('h,c,cfg', [(64, 48, 51), (32, 96, 51), (16, 192, 51), (8, 384, 56), (16, 192, 57)])
 def test_winograd_at_the_bench_batch_size_agrees_with_direct_and_is_linear(h, c, cfg):
     """BASELINE configs[1] size (64 crops): the Winograd kernel of each shape class against the direct

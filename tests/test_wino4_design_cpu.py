@@ -161,6 +161,120 @@ def test_halo_slot_order_of_the_16x16_region_geometry():
     assert len(got) == 18 * 18 * 4
 
 
+def test_halo_slot_order_of_the_four_image_geometry():
+    """conv_wino4c_kernel (GEO 2): four 8 x 8 images per region, 10 x 10 halo pixels each x 16 channels = 8 channel-pair
+    planes, slot = p * 586 + (x % 4) * 145 + imgbase(img) + y * 3 + x // 4 with imgbase = 34 img + 4 (img // 2).  Lane
+    (tile li: image li // 4, tile (ty, tx) = ((li // 2) % 2, li % 2) of its 2 x 2 tiles; channel kq of k-group g) reads
+    dword kq & 1 of pair 2 g + kq // 2 at pixel (4 ty + i, 4 tx + j): the 16 tiles fall on 16 different even dwords mod
+    32, so every 32-lane group hits 32 banks.  Three load pieces per wave cover the 4 x 10 x 12 (row-padded) pixel list x
+    4 channel quads; their ds_write_b64 (groups of 16 lanes = 4 aligned pixels x 4 quads) hit 32 banks too.  The K split
+    (KS = 2) hands stages [ks S, (ks + 1) S) of the pixel's channels and k-groups [48 ks, 48 ks + 48) of the filter to
+    item half ks."""
+    XD, PLANE, PAIR, QPP, RWP = 3, 145, 586, 4, 12
+    def imgbase(img):
+        return 34 * img + 4 * (img >> 1)
+    def slot(p, img, y, x):
+        return p * PAIR + (x & 3) * PLANE + imgbase(img) + y * XD + (x >> 2)
+    seen = set()
+    for p in range(8):
+        for img in range(4):
+            for y in range(10):
+                for x in range(10):
+                    s = slot(p, img, y, x)
+                    assert 0 <= s < 8 * PAIR and s not in seen
+                    seen.add(s)
+    assert 8 * PAIR * 8 + 1024 <= 38 * 1024 and 2 * 36 * 1024 + 2 * 38 * 1024 + 12 * 96 * 8 <= 160 * 1024 - 512
+    for g in range(4):
+        for i in range(6):
+            for j in range(6):
+                for half in (range(0, 32), range(32, 64)):
+                    banks = set()
+                    for lane in half:
+                        li, kq = lane & 15, lane >> 4
+                        img, ty, tx = li >> 2, (li >> 1) & 1, li & 1
+                        banks.add((slot(2 * g + kq // 2, img, 4 * ty + i, 4 * tx + j) * 2 + (kq & 1)) % 32)
+                    assert len(banks) == 32, (g, i, j, len(banks))
+    got, full = set(), 0
+    for k in range(3):
+        for wave in range(12):
+            for grp in range(4):
+                for second in (0, 1):
+                    banks, valid = [], 0
+                    for lane in range(grp * 16, grp * 16 + 16):
+                        e = (wave + 12 * k) * 64 + lane
+                        px, hq = divmod(e, QPP)
+                        hya, hx = divmod(px, RWP)
+                        img, hy = divmod(hya, 10)
+                        if img < 4 and hx < 10:
+                            valid += 1
+                            if second == 0:
+                                assert (img, hy, hx, hq) not in got
+                                got.add((img, hy, hx, hq))
+                            sl = slot(2 * hq + second, img, hy, hx)
+                            banks += [(2 * sl) % 32, (2 * sl + 1) % 32]
+                    if valid == 16:
+                        full += 1
+                        assert len(set(banks)) == 32, (k, wave, grp)
+                    else:
+                        assert len(set(banks)) == len(banks), (k, wave, grp)
+    assert len(got) == 4 * 10 * 10 * 4 and full >= 160
+    # output tile of lane (wave, lane) in the exchange round: tile = 4 (wave & 3) + (lane >> 4) -> (image, ty, tx)
+    tiles = {(t >> 2, (t >> 1) & 1, t & 1) for t in range(16)}
+    assert len(tiles) == 16
+    # K split of 384 input channels: 24 stages of 16 channels -> 12 per half; k-groups of 4 channels -> 48 per half
+    cin, ks_n = 384, 2
+    s_half = cin // (16 * ks_n)
+    for ks in range(ks_n):
+        chans = [ks * s_half * 16 + s * 16 + c for s in range(s_half) for c in range(16)]
+        groups = [ks * (cin // 4) // ks_n + 4 * s + h for s in range(s_half) for h in range(4)]
+        assert chans == list(range(ks * cin // 2, (ks + 1) * cin // 2))
+        assert [4 * h_ + q for h_ in groups for q in range(4)] == chans
+
+
+def test_item_orders_visit_every_region_cotile_and_half_once():
+    """w4_item_mode / w4_item_count and the item decode of w4_body, restated: block w -> (xcd = w & 7, q = w >> 3) ->
+    (region, co-tile, K half).  Mode 0 (1 - 3, 6 co-tiles) puts 8 consecutive regions on the 8 XCDs; mode 1 (4
+    co-tiles: the 192-channel branch) co-tile xcd % nct with every (8 / nct)-th (region, half) per XCD; mode 2 (multiples
+    of 8: the 384-channel branch) co-tile 8 j + xcd.  Every (region, co-tile, half) exactly once, padding items are
+    skipped; in modes 0 and 2 both halves of a pair land on the same XCD (a matter of speed, never of correctness)."""
+    def mode(nct):
+        if nct % 8 == 0:
+            return 2
+        return 1 if nct == 4 else 0          # (W4_COX_MIN_NCT = 4)
+    def count(m, nreg, nct, ks):
+        if m == 2:
+            return nreg * nct * ks
+        if m == 1:
+            return 8 * ((nreg * ks + 8 // nct - 1) // (8 // nct))
+        return ((nreg + 7) >> 3) * nct * ks * 8
+    for nct in (1, 2, 3, 4, 6, 8, 16):
+        for KS in (1, 2):
+            for nreg in (1, 3, 4, 16, 17, 64):
+                m = mode(nct)
+                seen = {}
+                for w in range(count(m, nreg, nct, KS)):
+                    xq, q = w & 7, w >> 3
+                    if m == 0:
+                        qq = q // (nct * KS)
+                        cs = q - qq * nct * KS
+                        reg, ct, ks = qq * 8 + xq, cs // KS, cs % KS
+                    elif m == 1:
+                        lg = nct >> 1
+                        cs = q * (8 >> lg) + (xq >> lg)
+                        reg, ct, ks = cs // KS, xq & (nct - 1), cs % KS
+                    else:
+                        c8 = nct >> 3
+                        qq = q // c8
+                        reg, ct, ks = qq // KS, (q - qq * c8) * 8 + xq, qq % KS
+                    if reg >= nreg:
+                        continue
+                    assert 0 <= ct < nct and (reg, ct, ks) not in seen
+                    seen[(reg, ct, ks)] = xq
+                assert len(seen) == nreg * nct * KS, (nct, KS, nreg, m)
+                if KS == 2 and m != 1:      # (mode 1 spreads a pair over two XCDs: the hand-off is placement-independent)
+                    assert all(seen[(r, c, 0)] == seen[(r, c, 1)] for r in range(nreg) for c in range(nct))
+
+
 @pytest.mark.parametrize('geo', [0, 1])
 def test_halo_stores_are_bank_conflict_free(geo):
     """The halo goes global -> registers -> LDS: lane e of a load piece holds 16 bytes (a channel quad) of one pixel and

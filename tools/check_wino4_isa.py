@@ -48,12 +48,13 @@ def inflight(queue):
     return out
 
 
-KERNELS = ('conv_wino4_kernel', 'conv_wino4b_kernel')       # the two geometries of the body (GEO 0 / 1), product builds
+# the geometries of the body (GEO 0 / 1 / 2, the last one without and with the K split), product builds
+KERNELS = ('conv_wino4_kernelILi0E', 'conv_wino4b_kernelILi0E', 'conv_wino4c_kernelILi0ELi1E', 'conv_wino4c_kernelILi0ELi2E')
 
 
-def check(path, kernel='conv_wino4_kernel'):
+def check(path, kernel='conv_wino4_kernelILi0E'):
     text = open(path).read()
-    m = re.search(r'^(_Z\d+%sILi0E\w*):' % kernel, text, re.M)
+    m = re.search(r'^(_Z\d+%s\w*):' % kernel, text, re.M)
     assert m, 'kernel symbol not found: ' + kernel
     body = text[m.end():text.index('s_endpgm', m.end())]
     queue = []          # outstanding vector-memory operations, oldest first: destination VGPRs or None
@@ -64,7 +65,7 @@ def check(path, kernel='conv_wino4_kernel'):
         if not t or t.endswith(':') or t.startswith('.'):
             continue
         op, _, rest = t.partition(' ')
-        if op.startswith('buffer_load') or op.startswith('buffer_store'):
+        if op.startswith('buffer_load') or op.startswith('buffer_store') or op.startswith('buffer_atomic'):
             dst = None
             if op.startswith('buffer_load') and ' lds' not in t:
                 dst = frozenset(regs_of(rest.split(',', 1)[0]))
