@@ -319,7 +319,8 @@ def test_conv_wino4c_kernel(cfg, n, cin, cout, res, act):
         assert L.egn_conv_plan_query(2, 8, 8, 48, 48, 48, 48, 3, 3, 1, 1, 0, 83, out) != 0
 
 
-@pytest.mark.parametrize('n,cin,cout,res,act', [(64, 384, 384, True, 1), (10, 96, 96, True, 1), (5, 64, 48, False, 0)])
+@pytest.mark.parametrize('n,cin,cout,res,act', [(64, 384, 384, True, 1), (10, 96, 96, True, 1), (5, 64, 48, False, 0),
+                                                (16, 64, 192, True, 1)])     # (4 co-tiles: the halves of a pair on two XCDs)
 def test_conv_wino4c_ticket_path_of_programs(n, cin, cout, res, act):
     """Config 83 inside a program (egn_program_add_conv2d): the op owns one zeroed ticket word per item pair and the layer
     is ONE launch -- the half of a pair that finishes second adds the first one's raw share (read back from y) and applies
