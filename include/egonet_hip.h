@@ -85,10 +85,13 @@ int egn_conv_config_name(int cfg, char* buf, int len);
  *      strides, act none/ReLU): the TRANSFORMED filter from egn_wino_pack_weight_f32
  *   2  fused Winograd F(4x4,3x3), conv_wino43_kernel: U = G g G^T for points 0, +-1, +-2,
  *      inf packed [Cout/48][Cin/4][f = 6i+j][ci % 4][48] (host: engine.pack_wino43_weight)
- *   3  fused Winograd F(4x4,3x3), conv_wino4_kernel / conv_wino4b_kernel (3x3, stride 1, pad 1,
- *      Cin % 16 == 0, Cout % 48 == 0, maps of whole 16 x 32 / 16 x 16 pixel regions): the same U
- *      packed for register feeding, [Cout/48][k-group Cin/4][wave 12][3][64 lanes][4] floats (9 of
- *      12 used) (egn_wino4_weight_floats; host: engine.pack_wino4_weight)
+ *   3  fused Winograd F(4x4,3x3), conv_wino4_kernel / conv_wino4b_kernel / conv_wino4c_kernel (3x3,
+ *      stride 1, pad 1, Cin % 16 == 0, Cout % 48 == 0, maps of whole 16 x 32 / 16 x 16 pixel regions
+ *      or 8 x 8 maps): the same U packed for register feeding, [Cout/48][k-group Cin/4][wave 12][3]
+ *      [64 lanes][4] floats (9 of 12 used) (egn_wino4_weight_floats; host: engine.pack_wino4_weight).
+ *      Config 83 (8 x 8 maps, input channels of a work item split over two blocks; Cin % 32 == 0):
+ *      called through egn_conv2d_f32 it is THREE launches on `stream` (y zeroed, atomic adds, in-place
+ *      epilogue; res must not alias y); as an op of a program it is one launch.
  *  -1  not selectable: invalid id, retired family, timing-ablation / stamp build.  The product
  *      library neither plans nor launches such an id (egn_conv2d_f32 returns EGN_E_BADARG);
  *      a probe build (-DEGN_PROBES, tools/ only) compiles them. */
