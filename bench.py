@@ -68,7 +68,7 @@ def parse():
     p.add_argument('--train-batch', type=int, default=32, help='crops per GPU of the train_hc block')
     p.add_argument('--lifter-batch', type=int, default=4096)
     p.add_argument('--pipelined', action='store_true',
-                   help='also time the K steps with TWO batches in flight on two streams (measured r4: +0.8 %: the step is '
+                   help='also time the K steps with TWO batches in flight on two streams (measured r4: +0.8 %%: the step is '
                         'its kernel time -- off by default)')
     p.add_argument('--live-traffic', action='store_true',
                    help='measure roofline.traffic IN THIS RUN: two short child passes of the forward under '

@@ -41,3 +41,11 @@ def test_more_gpus_than_visible_fails_loudly():
     r = _run(['--gpus', '8', '--steps', '1'])
     assert r.returncode == 2 and 'only %d GPU(s) are visible' % torch.cuda.device_count() in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{')]       # no bench line under a false n_gpus
+
+
+def test_help_prints_every_option():
+    """argparse expands `%` in help strings: a literal per-cent sign there made `--help` raise (found in round 4)."""
+    r = _run(['--help'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    for opt in ('--gpus', '--steps', '--warmup', '--batch', '--pipelined', '--live-traffic', '--profile-json'):
+        assert opt in r.stdout
