@@ -119,6 +119,7 @@ static const ConvConfig kConfigs[] = {
     {81, 12, 1, 1, 3, 1, 64, 7},   // 80 with s_memtime stamps (tools/wino4_clk.py)
     {82, 12, 1, 1, 3, 2, 0, 7},    // conv_wino4c_kernel<0, 1>: F(4x4,3x3) on 8 x 8 maps, four images per region (ai = geometry 2); filter kind 3
     {83, 12, 1, 1, 3, 6, 0, 7},    // conv_wino4c_kernel<0, 2>: 82 with the input channels of an item split over two blocks (ai bit 2): memset, atomic adds, conv_wino4_finish_kernel
+    {84, 12, 1, 1, 3, 5, 0, 7},    // conv_wino4bk_kernel: 80 with the input channels of an item split over two blocks (ai bit 2), as 83
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -173,7 +174,7 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 6) { snprintf(buf, len, "conv_stem_kernel(ConvArgs)"); return 0; }
   if (c.dma == 7 && (c.ai & 3) == 2) { snprintf(buf, len, "void conv_wino4c_kernel<%d, %d>(ConvArgs)", c.bi, (c.ai & 4) ? 2 : 1); return 0; }
-  if (c.dma == 7) { snprintf(buf, len, "void conv_wino4%s_kernel<%d>(ConvArgs)", c.ai ? "b" : "", c.bi); return 0; }
+  if (c.dma == 7) { snprintf(buf, len, "void conv_wino4%s_kernel<%d>(ConvArgs)", c.ai == 5 ? "bk" : (c.ai ? "b" : ""), c.bi); return 0; }
   if (c.dma == 8) { snprintf(buf, len, "conv_fc_kernel(ConvArgs)"); return 0; }
   if (c.dma == 5 && (c.bi & 15) == 10) { snprintf(buf, len, "void conv_wino43_kernel<0>(ConvArgs)"); return 0; }
   if (c.dma == 5 && ((c.bi & 15) == 11 || (c.bi & 15) == 12)) {
@@ -259,7 +260,7 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
     // images per region (ai & 3 = 2; ai bit 2: K split), 48-channel co-tiles
     if (!egn_conv_wino4_applies(a, cf.ai)) return false;
     const int g7 = cf.ai & 3;
-    a.TH = g7 == 2 ? 8 : 16; a.TW = g7 == 2 ? 8 : (g7 ? 16 : 32); a.TNB = g7 == 2 ? 4 : 1; a.HH = a.TH + 2; a.HW = a.TW + 2;
+    a.TH = g7 == 2 ? 8 : 16; a.TW = g7 == 2 ? 8 : (g7 == 1 ? 16 : 32); a.TNB = g7 == 2 ? 4 : 1; a.HH = a.TH + 2; a.HW = a.TW + 2;
     a.npix = a.TNB * a.HH * a.HW; a.npixp = (a.npix + 15) & ~15; a.tps = 36;
     a.tiles_x = a.Wo / a.TW;
     a.tiles_y = a.Ho / a.TH;

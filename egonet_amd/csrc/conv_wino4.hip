@@ -40,6 +40,7 @@
 //          the place of GEO 0's k-group (4 channels x 2 m-tiles) in the stage schedule.
 //   GEO 2  conv_wino4c_kernel  FOUR IMAGES of an 8 x 8 map per region (the 384-channel branch: 2 x 2 tiles per image,
 //          one m-tile = 4 images), 16-channel stages as GEO 1; 3 halo pieces per wave and stage (4 x 10 x 10 pixels).
+//          (conv_wino4bk_kernel: GEO 1 with the same K split -- small batches: 16 crops x 192 channels are 64 items.)
 //          Template parameter KS = 2 splits the input channels of an item over two blocks (64 crops x 384 -> 384
 //          channels are 16 regions x 8 co-tiles = 128 items: half the chip; 256 with the split): both add their
 //          raw Y = A^T M A into a zeroed y (buffer_atomic_add_f32 -- two addends onto 0: the sum does not depend on
@@ -749,6 +750,8 @@ template <int ABL>
 __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4_kernel(ConvArgs a) { w4_body<ABL, 0>(a); }
 template <int ABL>
 __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4b_kernel(ConvArgs a) { w4_body<ABL, 1>(a); }
+template <int ABL>      // conv_wino4b_kernel with the input channels of an item split over two blocks (as conv_wino4c_kernel<., 2>)
+__global__ __launch_bounds__(W4_NTH, 1) void conv_wino4bk_kernel(ConvArgs a) { w4_body<ABL, 1, 2>(a); }
 template <int ABL, int KS>
 __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4c_kernel(ConvArgs a) { w4_body<ABL, 2, KS>(a); }
 
@@ -771,10 +774,10 @@ __global__ __launch_bounds__(256) void conv_wino4_finish_kernel(float* __restric
 }
 
 // geo: bits 0-1 the geometry (0: 16 x 32 regions, 1: 16 x 16 regions, 2: four 8 x 8 images), bit 2: input channels split
-// over two items (geometry 2 only)
+// over two items (geometries 1 and 2: one exchange round per item)
 bool egn_conv_wino4_applies(const ConvArgs& a, int geo) {
   const int g = geo & 3, ks = (geo & 4) ? 2 : 1;
-  if (g > 2 || (ks > 1 && g != 2)) return false;
+  if (g > 2 || (ks > 1 && g == 0)) return false;
   const bool map_ok = g == 2 ? (a.Ho == 8 && a.Wo == 8) : (a.Ho % 16 == 0 && a.Wo % (g ? 16 : 32) == 0);
   // (K split: whole 16-channel stages per half; the residual is read after y was zeroed -- it must be another buffer)
   if (ks > 1 && (a.Cin % 32 || (a.res && a.res == a.y))) return false;
@@ -783,9 +786,11 @@ bool egn_conv_wino4_applies(const ConvArgs& a, int geo) {
          ((a.act & EGN_ACT_MASK) == EGN_ACT_NONE || (a.act & EGN_ACT_MASK) == EGN_ACT_RELU);
 }
 // ticket words a K-split launch wants (zeroed once; every launch leaves them zero): one per (region, co-tile); 0 = none
+// (a: planned -- tiles_x / tiles_y are the regions of an image)
 int egn_conv_wino4_tickets(const ConvArgs& a, int geo) {
-  if ((geo & 7) != 6 || !egn_conv_wino4_applies(a, geo)) return 0;
-  return ((a.N + 3) / 4) * (a.Cout / W4_CO);
+  if (!(geo & 4) || !egn_conv_wino4_applies(a, geo)) return 0;
+  const int nimg = (geo & 3) == 2 ? 4 : 1;
+  return a.tiles_x * a.tiles_y * ((a.N + nimg - 1) / nimg) * (a.Cout / W4_CO);
 }
 size_t egn_conv_wino4_lds_bytes(int geo) {      // (+ the stamp area of the ABL & 64 build)
   return ((geo & 3) == 2 ? w4_lds_bytes<2>() : w4_lds_bytes<0>()) + 12 * 96 * 8;
@@ -802,7 +807,7 @@ template <int ABL, int GEO, int KS>
 static int wino4_launch(ConvArgs a, size_t lds, hipStream_t stream) {
   static bool raised[EGN_MAX_DEVICES];
   static int cus = 0;
-  auto kern = GEO == 2 ? &conv_wino4c_kernel<ABL, KS> : (GEO ? &conv_wino4b_kernel<ABL> : &conv_wino4_kernel<ABL>);
+  auto kern = GEO == 2 ? &conv_wino4c_kernel<ABL, KS> : (GEO == 0 ? &conv_wino4_kernel<ABL> : (KS > 1 ? &conv_wino4bk_kernel<ABL> : &conv_wino4b_kernel<ABL>));
   if (egn_first_use_on_device(raised)) {
     EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024 - 512));
@@ -845,6 +850,7 @@ int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, int geo, hipStream_t 
     if (abl) return EGN_E_BADARG;
     return (geo & 4) ? wino4_launch<0, 2, 2>(a, lds, stream) : wino4_launch<0, 2, 1>(a, lds, stream);
   }
+  if (geo == 5) return abl ? EGN_E_BADARG : wino4_launch<0, 1, 2>(a, lds, stream);
   if (geo) {
     switch (abl) {
       case 0: return wino4_launch<0, 1, 1>(a, lds, stream);

@@ -89,7 +89,8 @@ int egn_conv_config_name(int cfg, char* buf, int len);
  *      stride 1, pad 1, Cin % 16 == 0, Cout % 48 == 0, maps of whole 16 x 32 / 16 x 16 pixel regions
  *      or 8 x 8 maps): the same U packed for register feeding, [Cout/48][k-group Cin/4][wave 12][3]
  *      [64 lanes][4] floats (9 of 12 used) (egn_wino4_weight_floats; host: engine.pack_wino4_weight).
- *      Config 83 (8 x 8 maps, input channels of a work item split over two blocks; Cin % 32 == 0):
+ *      Configs 83 / 84 (8 x 8 maps / 16 x 16 regions, input channels of a work item split over two
+ *      blocks; Cin % 32 == 0):
  *      called through egn_conv2d_f32 it is THREE launches on `stream` (y zeroed, atomic adds, in-place
  *      epilogue; res must not alias y); as an op of a program it is one launch.
  *  -1  not selectable: invalid id, retired family, timing-ablation / stamp build.  The product

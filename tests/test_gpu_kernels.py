@@ -278,6 +278,61 @@ def test_conv_wino4b_kernel(n, h, w, cin, cout, res, act):
     assert L.egn_conv_plan_query(2, 16, 24, 48, 48, 48, 48, 3, 3, 1, 1, 0, 80, out) != 0
 
 
+@pytest.mark.parametrize('n,h,w,cin,cout,res,act', [
+    (2, 16, 16, 32, 48, True, 1),       # one stage per half
+    (3, 16, 16, 192, 192, True, 1),     # the 16 x 16 maps of the 192-channel branch at a small batch: 6 stages per half
+    (16, 16, 16, 192, 192, True, 1),    # BASELINE configs[4]'s per-GPU shard: 64 regions x 4 co-tiles x 2 halves
+    (2, 32, 48, 96, 96, False, 0),      # 2 x 3 regions, 3 stages per half (odd), no activation, no residual
+    (70, 16, 16, 64, 96, True, 1),      # more item pairs than blocks (persistent rounds), 2 stages per half
+])
+def test_conv_wino4bk_kernel(n, h, w, cin, cout, res, act):
+    """Config 84, conv_wino4bk_kernel: conv_wino4b_kernel (16 x 16 regions) with the input channels of an item split over
+    two blocks, the hand-off of conv_wino4c_kernel<., 2> (csrc/conv_wino4.hip) -- small batches of the 96- / 192-channel
+    branches have fewer regions than the chip has CUs.  Through egn_conv2d_f32 (zeroed y, atomic adds, finish pass) and as
+    a program's op (ticket words, one launch): same bits, twice; against cfg 80 only the order of the two halves' sum."""
+    import ctypes as C
+    from egonet_amd import _lib, ops
+    L = _lib.lib()
+    assert L.egn_conv_config_kind(84) == 3
+    out = (C.c_int * 12)()
+    assert L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, 84, out) == 0
+    assert list(out)[5:8] == [16, 16, 1]
+    err = _conv_case(n, h, w, cin, cout, 3, 1, 1, act=act, use_res=res, cfg=84, seed=n + h + cin)
+    assert err < 5e-4, err
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    pc = ops.PackedConv(wt, None, _bn(cout, g), kind=3)
+    r = torch.randn(n, h, w, cout, generator=g).cuda() if res else None
+    ya = ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=84)
+    yb = ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=84)
+    yc = ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=80)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+    assert (ya - yc).abs().max().item() < 5e-4
+    y = torch.full((n, h, w, cout), float('nan'), device='cuda')
+    prog = L.egn_program_create(8)
+    assert prog
+    try:
+        refs = []
+        for slot, t in enumerate([x, pc.w, pc.scale, pc.shift, r, y]):
+            if t is None:
+                refs.append(_lib.NULL_REF)
+                continue
+            assert L.egn_program_bind(prog, slot, _lib.ptr(t)) == 0
+            refs.append(_lib.Ref(slot, 0))
+        assert L.egn_program_add_conv2d(prog, *refs, n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, act, 0, 84) == 0
+        for _ in range(10):
+            y.fill_(float('nan'))
+            assert L.egn_program_run(prog, _lib.current_stream()) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(y, ya)
+    finally:
+        L.egn_program_destroy(prog)
+    assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 48, 48, 3, 3, 1, 1, 0, 84, out) != 0     # whole 16-channel stages per half
+    assert L.egn_conv_plan_query(2, 8, 8, 64, 64, 48, 48, 3, 3, 1, 1, 0, 84, out) != 0
+
+
 @pytest.mark.parametrize('cfg', [82, 83])
 @pytest.mark.parametrize('n,cin,cout,res,act', [
     (4, 32, 48, True, 1),       # one region, one stage per half (83) / two stages (82)

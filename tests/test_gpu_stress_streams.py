@@ -99,6 +99,7 @@ CONV_CASES = [
     (80, (64, 16, 16, 192, 192, 3, 1, 1), True),     # conv_wino4b_kernel
     (82, (64, 8, 8, 384, 384, 3, 1, 1), True),       # conv_wino4c_kernel<0, 1>: four 8 x 8 images per region
     (83, (64, 8, 8, 384, 384, 3, 1, 1), True),       # conv_wino4c_kernel<0, 2> without ticket words: memset, atomic adds, finish
+    (84, (16, 16, 16, 192, 192, 3, 1, 1), True),     # conv_wino4bk_kernel (16 crops: configs[4]'s shard), the same three-launch form
     (59, (64, 16, 16, 192, 192, 3, 1, 1), True),     # conv_wino9_kernel, 16 x 16 tile, 8 waves
     (61, (64, 8, 8, 384, 384, 3, 1, 1), True),       # conv_wino9_kernel, two 8 x 8 images, 4 waves
     (62, (32, 16, 16, 192, 192, 3, 1, 1), True),     # conv_wino9_kernel, 8 x 16 tile, 4 waves
@@ -147,25 +148,25 @@ def test_conv_kernels_are_bit_identical_beside_two_busy_streams(cfg, shape, use_
     assert bad == 0, (cfg, bad)
 
 
-@pytest.mark.parametrize('n,cin,cout', [(64, 384, 384), (64, 64, 192), (7, 96, 96)])
-def test_k_split_ticket_hand_off_is_bit_identical_beside_two_busy_streams(n, cin, cout):
-    """Config 83 the way programs launch it (one kernel; the halves of an item pair hand their share over through a
+@pytest.mark.parametrize('cfg,n,hw,cin,cout', [(83, 64, 8, 384, 384), (83, 64, 8, 64, 192), (83, 7, 8, 96, 96), (84, 16, 16, 192, 192)])
+def test_k_split_ticket_hand_off_is_bit_identical_beside_two_busy_streams(cfg, n, hw, cin, cout):
+    """Configs 83 / 84 the way programs launch them (one kernel; the halves of an item pair hand their share over through a
     ticket word, csrc/conv_wino4.hip): beside two busy streams the two blocks of a pair start far apart in time -- the
     late one takes the waiting path.  4 co-tiles (192 output channels) put the halves of a pair on DIFFERENT XCDs (item
     order 1): the hand-off must not depend on placement.  Every repetition bit-identical to the solo run, which in turn
     equals the three-launch form."""
     L = _lib.lib()
     g = torch.Generator().manual_seed(n + cout)
-    x = torch.randn(n, 8, 8, cin, generator=g).cuda()
+    x = torch.randn(n, hw, hw, cin, generator=g).cuda()
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
     wp = engine.pack_for_kind(wt, 3).cuda()
     sc = (torch.rand(cout, generator=g) + 0.5).cuda()
     sh = torch.randn(cout, generator=g).cuda()
-    res = torch.randn(n, 8, 8, cout, generator=g).cuda()
-    y = torch.empty(n, 8, 8, cout, device='cuda')
+    res = torch.randn(n, hw, hw, cout, generator=g).cuda()
+    y = torch.empty(n, hw, hw, cout, device='cuda')
     want = torch.empty_like(y)
     _lib.check(L.egn_conv2d_f32(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(sc), _lib.ptr(sh), _lib.ptr(res), _lib.ptr(want),
-                                n, 8, 8, cin, cin, cout, cout, 3, 3, 1, 1, 1, 0, 83, _lib.current_stream()), 'conv cfg 83')
+                                n, hw, hw, cin, cin, cout, cout, 3, 3, 1, 1, 1, 0, cfg, _lib.current_stream()), 'conv cfg %d' % cfg)
     prog = L.egn_program_create(8)
     assert prog
     try:
@@ -173,14 +174,14 @@ def test_k_split_ticket_hand_off_is_bit_identical_beside_two_busy_streams(n, cin
         for slot, t in enumerate((x, wp, sc, sh, res, y)):
             _lib.check(L.egn_program_bind(prog, slot, _lib.ptr(t)))
             refs.append(_lib.Ref(slot, 0))
-        _lib.check(L.egn_program_add_conv2d(prog, *refs, n, 8, 8, cin, cin, cout, cout, 3, 3, 1, 1, 1, 0, 83))
+        _lib.check(L.egn_program_add_conv2d(prog, *refs, n, hw, hw, cin, cin, cout, cout, 3, 3, 1, 1, 1, 0, cfg))
         st = _lib.current_stream()
 
         def launch():
-            _lib.check(L.egn_program_run(prog, st), 'program cfg 83')
+            _lib.check(L.egn_program_run(prog, st), 'program cfg %d' % cfg)
         bad, overlapped, checks = _stress(launch, y, _Hogs('conv'))
-        print('cfg 83 as a program, %d x %d -> %d: %d of %d repetitions differ; side streams busy at %d of %d checkpoints'
-              % (n, cin, cout, bad, REPS, overlapped, checks))
+        print('cfg %d as a program, %d x %d -> %d @ %d x %d: %d of %d repetitions differ; side streams busy at %d of %d checkpoints'
+              % (cfg, n, cin, cout, hw, hw, bad, REPS, overlapped, checks))
         assert overlapped >= checks // 2
         assert bad == 0, bad
         assert torch.equal(y, want)

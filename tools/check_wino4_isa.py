@@ -49,7 +49,8 @@ def inflight(queue):
 
 
 # the geometries of the body (GEO 0 / 1 / 2, the last one without and with the K split), product builds
-KERNELS = ('conv_wino4_kernelILi0E', 'conv_wino4b_kernelILi0E', 'conv_wino4c_kernelILi0ELi1E', 'conv_wino4c_kernelILi0ELi2E')
+KERNELS = ('conv_wino4_kernelILi0E', 'conv_wino4b_kernelILi0E', 'conv_wino4bk_kernelILi0E', 'conv_wino4c_kernelILi0ELi1E',
+           'conv_wino4c_kernelILi0ELi2E')
 
 
 def check(path, kernel='conv_wino4_kernelILi0E'):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Re-measure the F(4x4,3x3) configurations of conv_wino4.hip (cfg 70 / 80 / 82 / 83) against each table entry's best
+"""Re-measure the F(4x4,3x3) configurations of conv_wino4.hip (cfg 70 / 80 / 82 / 83 / 84) against each table entry's best
 other configuration, for every shape of `tuned/gfx950.json` one of them plans for, and rewrite the entries.
 
 Round 4 changed what these kernels cost after the table was measured: conv_wino4c_kernel (cfg 82 / 83: four 8 x 8
@@ -21,7 +21,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from egonet_amd import _lib, tuner  # noqa: E402
 
-F43 = (70, 80, 82, 83)
+F43 = (70, 80, 82, 83, 84)
 KEY = re.compile(r'n(\d+)_h(\d+)_w(\d+)_ci(\d+)\.(\d+)_co(\d+)\.(\d+)_k(\d+)x(\d+)_s(\d+)_p(\d+)_r(\d+)_o(\d+)$')
 
 
