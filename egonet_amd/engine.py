@@ -368,8 +368,10 @@ class Program(object):
         self.meta = []
         _lib.check(L.egn_program_bind(self.handle, SLOT_ARENA, _lib.ptr(self.arena)))
         _lib.check(L.egn_program_bind(self.handle, SLOT_WEIGHTS, _lib.ptr(self.weights)))
-        for kind, op in rec.ops:
-            self._emit(kind, op)
+        # (ops may own device memory -- the ticket words of K-split convolutions: allocate it on the program's device)
+        with torch.cuda.device(device):
+            for kind, op in rec.ops:
+                self._emit(kind, op)
 
     @staticmethod
     def _conv_key(op):
