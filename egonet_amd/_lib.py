@@ -40,6 +40,8 @@ SIGNATURES = {
     'egn_probe_build': (_i, []),
     'egn_wino_weight_floats': (C.c_long, [_i, _i, _i]),
     'egn_wino4_weight_floats': (C.c_longlong, [_i, _i]),
+    'egn_wino4_pack_weight_floats': (C.c_longlong, [_i, _i, _i]),
+    'egn_wino4_pack_weight_f32': (_i, [_p, _i, _i, _i, _p, _p]),
     'egn_wino_pack_weight_f32': (_i, [_p, _i, _i, _i, _p, _p]),
     'egn_fuse_sum_relu_f32': (_i, [_p, _i, _i, _i, _i, _i, _i, C.POINTER(_p), C.POINTER(_i), _i, _p]),
     'egn_nchw_to_nhwc_f32': (_i, [_p, _p, _i, _i, _i, _i, _i, _p]),

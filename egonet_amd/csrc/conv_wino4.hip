@@ -801,6 +801,69 @@ extern "C" long long egn_wino4_weight_floats(int cout, int cin) {
   return (long long)(cout / W4_CO) * (cin / 8) * 2 * W4_UKG;
 }
 
+// Filter transform on the device: torch weight [Cout][Cin][3][3] -> U = G g G^T (float64 arithmetic, one rounding to fp32)
+// in the register-feed layout above -- what engine.pack_wino4_weight computes on the host.  dgrad = 1: the data-gradient
+// filter (in / out channels swapped, taps rotated by 180 degrees), as egn_wino_pack_weight_f32 does for F(2x2,3x3).  One
+// thread per (co, ci): 9 loads, 36 stores; the thread of a co-tile's first 16 channels also zeroes the three padding
+// values per (wave, lane).  (Training weights change every step: the host transform cannot feed the tape.)
+__global__ __launch_bounds__(256) void wino4_pack_weight_kernel(const float* __restrict__ w, int Cout, int Cin, int dgrad,
+                                                                float* __restrict__ dst) {
+  const int n_out = dgrad ? Cin : Cout, n_in = dgrad ? Cout : Cin;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_out * n_in; e += gridDim.x * blockDim.x) {
+    const int o = e / n_in, i = e - o * n_in;
+    double g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+        g[a][b] = dgrad ? (double)w[((size_t)i * Cin + o) * 9 + (2 - a) * 3 + (2 - b)]
+                        : (double)w[((size_t)o * Cin + i) * 9 + a * 3 + b];
+    // rows of G (points 0, +-1, +-2, inf): [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+    double t[6][3];   // G g
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const double g0 = g[0][b], g1 = g[1][b], g2 = g[2][b];
+      t[0][b] = g0 / 4.0;
+      t[1][b] = -(g0 + g1 + g2) / 6.0;
+      t[2][b] = -(g0 - g1 + g2) / 6.0;
+      t[3][b] = g0 / 24.0 + g1 / 12.0 + g2 / 6.0;
+      t[4][b] = g0 / 24.0 - g1 / 12.0 + g2 / 6.0;
+      t[5][b] = g2;
+    }
+    const int ct = o / W4_CO, nt = (o % W4_CO) >> 4, li = o & 15;
+    const int h = i >> 2, kq = i & 3;
+    float* base = dst + ((size_t)ct * (n_in >> 2) + h) * W4_UKG + (16 * kq + li) * 4;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      const double t0 = t[a][0], t1 = t[a][1], t2 = t[a][2];
+      const double u[6] = {t0 / 4.0, -(t0 + t1 + t2) / 6.0, -(t0 - t1 + t2) / 6.0, t0 / 24.0 + t1 / 12.0 + t2 / 6.0,
+                           t0 / 24.0 - t1 / 12.0 + t2 / 6.0, t2};
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const int pt = a * 6 + b, wave = pt / 3, p = 3 * (pt % 3) + nt;       // value p = 4 q + r of (wave, lane)
+        base[(size_t)wave * 768 + (p >> 2) * 256 + (p & 3)] = (float)u[b];
+      }
+    }
+    if (nt == 0) {
+#pragma unroll
+      for (int wave = 0; wave < W4_NW; ++wave) {
+        float* pad = base + (size_t)wave * 768 + 2 * 256;
+        pad[1] = 0.f; pad[2] = 0.f; pad[3] = 0.f;
+      }
+    }
+  }
+}
+extern "C" long long egn_wino4_pack_weight_floats(int Cout, int Cin, int dgrad) {
+  return dgrad ? egn_wino4_weight_floats(Cin, Cout) : egn_wino4_weight_floats(Cout, Cin);
+}
+extern "C" int egn_wino4_pack_weight_f32(const float* w, int Cout, int Cin, int dgrad, float* dst, void* stream) {
+  if (!w || !dst || egn_wino4_pack_weight_floats(Cout, Cin, dgrad) == 0) return EGN_E_BADARG;
+  const long total = (long)Cout * Cin;
+  const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(wino4_pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, dgrad, dst);
+  return (int)hipGetLastError();
+}
+
 static unsigned w4_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
 template <int ABL, int GEO, int KS>

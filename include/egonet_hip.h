@@ -101,6 +101,15 @@ int egn_conv_config_kind(int cfg);
 int egn_probe_build(void);
 /* floats of the kind-3 filter of a [Cout][Cin][3][3] weight (0 = shape not supported) */
 long long egn_wino4_weight_floats(int Cout, int Cin);
+/* The kind-3 filter transform on the device: torch weight [Cout][Cin][3][3] -> U = G g G^T (float64
+ * arithmetic, rounded once to fp32) in the register-feed layout of kind 3 -- the device form of
+ * engine.pack_wino4_weight; dgrad 1 = the data-gradient filter (channels swapped, taps rotated by
+ * 180 degrees).  egn_wino4_pack_weight_floats = floats dst must hold (0 = shape not supported:
+ * output channels % 48, input channels % 8, >= 16).  Replaces nothing in the reference (cuDNN
+ * transforms filters internally for the Conv2d calls of hrnet.py:24-27); it is what lets weights
+ * that change every step (libs/trainer/trainer.py:183-209) feed the F(4x4,3x3) kernels. */
+long long egn_wino4_pack_weight_floats(int Cout, int Cin, int dgrad);
+int egn_wino4_pack_weight_f32(const float* w, int Cout, int Cin, int dgrad, float* dst, void* stream);
 /* Winograd filter transform on the device: torch weight [Cout][Cin][3][3] ->
  * U = G g G^T (float64 arithmetic, rounded once to fp32) packed as
  * [Cout/T][Cin/16][f = 4i+j][quad][T][4] floats (ci = chunk*16 + quad*4 + r),

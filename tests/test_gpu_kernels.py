@@ -333,6 +333,46 @@ def test_conv_wino4bk_kernel(n, h, w, cin, cout, res, act):
     assert L.egn_conv_plan_query(2, 8, 8, 64, 64, 48, 48, 3, 3, 1, 1, 0, 84, out) != 0
 
 
+@pytest.mark.parametrize('cout,cin', [(48, 16), (96, 48), (192, 192), (384, 384), (48, 256)])
+def test_wino4_filter_transform_on_the_device(cout, cin):
+    """egn_wino4_pack_weight_f32: U = G g G^T of a torch weight in the register-feed layout of the F(4x4,3x3) kernels,
+    computed on the device (float64 arithmetic, one rounding) -- against engine.pack_wino4_weight (host, float64 einsum):
+    equal up to the association order (<= 1 ulp of the largest term), padding values exactly zero; dgrad = 1 against the
+    host pack of the channel-swapped, tap-rotated weight; and a convolution fed with the device-packed filter against one
+    fed with the host pack."""
+    from egonet_amd import _lib, engine, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(cout + cin)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    wd = wt.cuda()
+    st = _lib.current_stream()
+    for dgrad in (0, 1):
+        n_out, n_in = (cin, cout) if dgrad else (cout, cin)
+        nfl = L.egn_wino4_pack_weight_floats(cout, cin, dgrad)
+        if n_out % 48 or n_in % 8:
+            assert nfl == 0
+            continue
+        ref = engine.pack_wino4_weight(wt.permute(1, 0, 2, 3).flip(2, 3).contiguous() if dgrad else wt)
+        assert nfl == ref.numel() == L.egn_wino4_weight_floats(n_out, n_in)
+        dst = torch.full((nfl,), float('nan'), device='cuda')
+        _lib.check(L.egn_wino4_pack_weight_f32(_lib.ptr(wd), cout, cin, dgrad, _lib.ptr(dst), st), 'wino4 pack')
+        torch.cuda.synchronize()
+        got = dst.cpu()
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() <= 2e-7 * max(1.0, ref.abs().max().item())
+        assert torch.equal(got == 0, ref == 0) or (got[ref == 0] == 0).all()
+    if cout % 48 == 0 and cin % 16 == 0:
+        pc = ops.PackedConv(wt, None, None, kind=3)
+        x = torch.randn(2, 32, 32, cin, generator=g).cuda()
+        y_host = ops.conv2d_nhwc(x, pc, cin, 1, 1, 0, None, cfg=80)
+        pc.w = torch.empty_like(pc.w)
+        _lib.check(L.egn_wino4_pack_weight_f32(_lib.ptr(wd), cout, cin, 0, _lib.ptr(pc.w), st), 'wino4 pack')
+        y_dev = ops.conv2d_nhwc(x, pc, cin, 1, 1, 0, None, cfg=80)
+        torch.cuda.synchronize()
+        # (filters that differ in the last bit of a few U values; the output transform amplifies by up to ~100)
+        assert (y_dev - y_host).abs().max().item() < 2e-4
+
+
 @pytest.mark.parametrize('cfg', [82, 83])
 @pytest.mark.parametrize('n,cin,cout,res,act', [
     (4, 32, 48, True, 1),       # one region, one stage per half (83) / two stages (82)

@@ -367,6 +367,37 @@ def test_wino4b_reads_the_same_filter_pack_in_k_group_pairs():
                         assert abs(got - U[16 * nt + li, 4 * h + kq, pt // 6, pt % 6]) < 1e-6
 
 
+def test_device_filter_transform_addresses_the_register_feed_layout():
+    """wino4_pack_weight_kernel (egn_wino4_pack_weight_f32) restated: thread (o, i) writes U[pt] = (G g G^T)[pt // 6][pt % 6]
+    to ((ct * (n_in / 4) + i / 4) * 9216 + wave * 768 + (p / 4) * 256 + (16 (i % 4) + o % 16) * 4 + p % 4 with wave = pt / 3,
+    p = 3 (pt % 3) + nt, nt = (o % 48) / 16; the thread with nt = 0 zeroes values 9..11.  dgrad swaps the channels and
+    rotates the taps.  Must equal engine.pack_wino4_weight (the layout the kernels are tested with) element for element."""
+    from egonet_amd import engine
+    rng = np.random.default_rng(0)
+    for dgrad in (0, 1):
+        cout, cin = (96, 48) if not dgrad else (48, 96)
+        w = rng.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+        n_out, n_in = (cin, cout) if dgrad else (cout, cin)
+        dst = np.full((n_out // 48) * (n_in // 4) * 9216, np.nan, np.float32)
+        for o in range(n_out):
+            for i in range(n_in):
+                g = (w[i, o, ::-1, ::-1] if dgrad else w[o, i]).astype(np.float64)
+                U = G @ g @ G.T
+                ct, nt, li = o // 48, (o % 48) >> 4, o & 15
+                base = (ct * (n_in >> 2) + (i >> 2)) * 9216 + (16 * (i & 3) + li) * 4
+                for pt in range(36):
+                    p = 3 * (pt % 3) + nt
+                    dst[base + (pt // 3) * 768 + (p >> 2) * 256 + (p & 3)] = U[pt // 6, pt % 6]
+                if nt == 0:
+                    for wave in range(12):
+                        dst[base + wave * 768 + 513: base + wave * 768 + 516] = 0
+        wt = torch.from_numpy(w)
+        if dgrad:
+            wt = wt.permute(1, 0, 2, 3).flip(2, 3).contiguous()
+        ref = engine.pack_wino4_weight(wt).numpy()
+        assert not np.isnan(dst).any() and np.abs(dst - ref).max() < 1e-6
+
+
 @pytest.mark.skipif(shutil.which(os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')) is None, reason='hipcc not installed')
 def test_filter_load_registers_reach_their_waitcnt_untouched():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_wino4_isa.py')], capture_output=True, text=True,
