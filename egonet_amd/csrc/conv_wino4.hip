@@ -18,7 +18,7 @@
 //     18 MFMAs per 4-channel k-group, 72 accumulator registers.
 //
 // Block = 16 x 32 output pixels of one image = 4 x 8 tiles of 4 x 4 pixels = 2 m-tiles (tile rows {0,1} / {2,3})
-// x 48 output channels; K stages of 8 channels (two k-groups of 4).  LDS (120 KB): two halo buffers
+// x 48 output channels; K stages of 8 channels (two k-groups of 4).  LDS (124 KB): two halo buffers
 // [18 x 34 pixels][8 ch] (through registers: buffer_load_dwordx4 -> ds_write_b128, two stages ahead), two V buffers
 // [36 points][m-tile][k-group][64] floats.  Stage s: every wave loads its 2 halo pieces of stage s + 2 and its
 // 2 x 3 filter dwordx4 of the next k-groups, turns its third of halo s + 1 into V s + 1 and multiplies V s; one
