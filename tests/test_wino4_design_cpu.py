@@ -275,6 +275,60 @@ def test_item_orders_visit_every_region_cotile_and_half_once():
                     assert all(seen[(r, c, 0)] == seen[(r, c, 1)] for r in range(nreg) for c in range(nct))
 
 
+def test_ticket_hand_off_of_the_k_split_in_every_interleaving():
+    """The protocol of w4_body's K-split item end as a state machine over its atomic steps, run under every schedule of
+    the two blocks of a pair: block = draw a ticket (fetch_add on the pair's word); ticket 0 -> store the share, bump the
+    word; any other ticket (1 if the partner has not bumped yet, 2 if it has) -> poll until the word is 3, read the share,
+    write the result, reset the word to 0.  Claims: the waiting block only ever waits for a partner that HAS drawn its
+    ticket (no dependence on dispatch order), the share is read only after it was stored, exactly one block writes the
+    result, and the word is 0 again at the end (the next launch starts from zero)."""
+    import itertools
+
+    def block(name, m):
+        t = m['word']
+        m['word'] += 1                                   # draw
+        yield
+        if t == 0:
+            m['share'] = name                            # sc1 stores, drained
+            yield
+            m['word'] += 1                               # bump: -> 2 (partner still to draw) or 3
+            yield
+        else:
+            assert t in (1, 2), t
+            polls = 0
+            while m['word'] != 3:                        # t != 0: the partner drew first, so it is in its item end
+                polls += 1
+                assert polls < 64, 'waits for a block that makes no progress'
+                yield
+            assert m['share'] not in (None, name)        # reads what the OTHER block stored
+            m['result'].append(name)
+            yield
+            m['word'] = 0
+            yield
+
+    tickets_seen = set()
+    for launches in (1, 2):                              # (two launches in a row on the same word)
+        for sched in itertools.product((0, 1), repeat=9):
+            m = dict(word=0, share=None, result=[])
+            for _ in range(launches):
+                m['share'], m['result'] = None, []
+                gens = [block('a', m), block('b', m)]
+                done = [False, False]
+                order = list(sched) + [0, 1] * 40               # the schedule, then a fair tail: both blocks are RUNNING
+                for k in order:
+                    if done[k]:
+                        continue
+                    w0 = m['word']
+                    try:
+                        next(gens[k])
+                    except StopIteration:
+                        done[k] = True
+                    if m['word'] == w0 + 1 and w0 in (1, 2) and m['share'] is None:
+                        tickets_seen.add(w0)
+                assert all(done) and m['word'] == 0 and len(m['result']) == 1, (sched, m)
+    assert tickets_seen <= {1, 2}
+
+
 @pytest.mark.parametrize('geo', [0, 1])
 def test_halo_stores_are_bank_conflict_free(geo):
     """The halo goes global -> registers -> LDS: lane e of a load piece holds 16 bytes (a channel quad) of one pixel and
