@@ -66,6 +66,8 @@ SIGNATURES = {
     'egn_bn_stats_f32': (_i, [_p, _i, _i, _i, C.c_float, _p, _p, _p, _p, _p, C.c_float, _p, _p]),
     'egn_conv2d_bnstats_rows': (C.c_long, [_i] * 12),
     'egn_conv2d_bnstats_f32': (_i, [_p] * 5 + [_i] * 12 + [_p, C.c_long, _p]),
+    'egn_conv2d_ticket_words': (C.c_long, [_i] * 12),
+    'egn_conv2d_ex_f32': (_i, [_p] * 6 + [_i] * 13 + [_p, C.c_long, _p, C.c_long, _p]),
     'egn_bn_stats_finalize_f32': (_i, [_p, C.c_long, _i, _i, C.c_float, _p, _p, _p, _p, _p, C.c_float, _p]),
     'egn_bn_act_fwd_f32': (_i, [_p, _p, _p, _p, _p, _p, C.c_float, _i, _p, _p, _i, _i, _i, _p]),
     'egn_bn_bwd_sums_f32': (_i, [_p, _p, _p, C.c_float, _p, _p, _p, _p, _i, _p, _i, _i, _i, _p, _p, _p, _p]),

@@ -27,6 +27,7 @@ int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, int geo, hipStream_t 
 bool egn_conv_wino4_applies(const ConvArgs& a, int geo);
 size_t egn_conv_wino4_lds_bytes(int geo);
 int egn_conv_wino4_tickets(const ConvArgs& a, int geo);
+int egn_conv_wino4_stats_rows(const ConvArgs& a, int geo);
 int egn_conv_launch_fc(const ConvArgs& a, hipStream_t stream);                          // conv_fc.hip
 bool egn_conv_fc_applies(const ConvArgs& a);
 size_t egn_conv_wino_lds_bytes(int variant, int cout);
@@ -411,6 +412,7 @@ int egn_conv_plan(ConvArgs& a, int& cfg_id, size_t& lds_bytes) {
 int egn_conv_stats_rows(const ConvArgs& a, int cfg_id) {
   if (cfg_id < 1 || cfg_id > kNumConfigs) return 0;
   const ConvConfig& cf = kConfigs[cfg_id - 1];
+  if (cf.dma == 7) return cf.bi ? 0 : egn_conv_wino4_stats_rows(a, cf.ai);     // [round 5] conv_wino4s_kernel
   return cf.dma == 5 ? egn_conv_wino_stats_rows(a, cf.bi) : 0;
 }
 

@@ -50,6 +50,7 @@
 #include <stdlib.h>
 
 #include "conv_common.h"
+#include "wino4_pack.h"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_w4_t;
 
@@ -115,6 +116,7 @@ static_assert(W4G<0>::QPP * W4G<0>::RH * W4G<0>::RWP <= W4G<0>::NP * W4_NW * 64 
 static_assert(W4G<2>::imgbase(3) + W4G<2>::RH * W4G<2>::XD <= W4G<2>::PLANE && w4_lds_bytes<2>() + 12 * 96 * 8 <= 160 * 1024 - 512,
               "GEO 2: four images fit a plane, the buffers fit the CU");
 constexpr int W4_UKG = W4_NW * 3 * 64 * 4;            // filter floats of one (co-tile, stage, k-group): 9216 (9 of 12 used)
+static_assert(W4_UKG == W4P_UKG && W4_CO == W4P_CO, "wino4_pack.h packs this kernel's layout");
 constexpr unsigned W4_PAST = 0x80000000u;             // scalar byte offset past every buffer (tensors stay below 2 GB)
 }  // namespace
 
@@ -297,7 +299,11 @@ __device__ __forceinline__ void w4_transform(unsigned hb0, unsigned vw0) {
 // bit 5 bank-conflict-free halo reads, bit 6 s_memtime stamps (tools/wino4_clk.py).
 // (Round 4 also measured two other stage schedules -- the last transform third moved to mid-stage: no change; every
 // wave weaving its third between its own MFMA groups: 20-35 % slower -- profiles/r4_wino4_experiments.txt.)
-template <int ABL, int GEO, int KS = 1>
+// ST [round 5]: the training tape's build -- BatchNorm batch statistics in the item end (the sums / sums of squares of
+// what the lane stores, per block and output channel, as conv_wino9_kernel writes them: egn_bn_stats_finalize_f32 adds
+// the rows of all blocks in a fixed order).  A block's items all have the same co-tile (the grid is a multiple of
+// 8 x co-tiles x KS, tests/test_wino4_design_cpu.py), so its row covers 48 channels and is zero elsewhere.
+template <int ABL, int GEO, int KS = 1, bool ST = false>
 __device__ __forceinline__ void w4_body(const ConvArgs& a) {
   typedef W4G<GEO> Q;
   extern __shared__ float4 w4_smem[];
@@ -394,6 +400,14 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
     }                                                                                   \
   }
   W4_CLK()
+  // ST: per-(wave, statistic, channel li) sums in doubles above the stage buffers (the stamp area of the ABL & 64 build);
+  // slot (wave, ., li) is written by the wave's lanes kq == 0 only; zeroed here, read after the last item (barriers between)
+  double* sS = reinterpret_cast<double*>(reinterpret_cast<char*>(w4_smem) + w4_lds_bytes<GEO>());
+  int ct_blk = 0;
+  if constexpr (ST) {
+    static_assert(ABL == 0, "the statistics build has no ablations");
+    for (int e = tid; e < W4_NW * 2 * 16; e += W4_NTH) sS[e] = 0.0;
+  }
   for (int w = blockIdx.x; w < nwork; w += gsz) {
     // item -> (region, co-tile): blocks w, w + 8, ... stay on one XCD (conv_wino.hip: wino8_grid)
     const unsigned wi = (unsigned)__builtin_amdgcn_readfirstlane(w);
@@ -412,6 +426,7 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
       reg = (int)qq / KS; ct = (int)((q_ - qq * ((unsigned)nct >> 3)) * 8u + xq); ks = (int)qq % KS;
     }
     if (reg >= nreg) continue;                         // (uniform) padding of the last round of the XCDs
+    ct_blk = ct;
     const unsigned n_ = w4_udiv((unsigned)reg, a.mg_txy);
     const unsigned r_ = (unsigned)reg - n_ * (unsigned)regs_xy;
     const unsigned ry_ = w4_udiv(r_, a.mg_tx);
@@ -661,6 +676,7 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
       W4_COLS(4)
 #undef W4_COLS
 #undef W4_M
+      float st1 = 0.f, st2 = 0.f;        // ST: this lane's 16 stored values of the round (one channel)
 #pragma unroll
       for (int oa = 0; oa < 4; ++oa) {
         float yo[4];
@@ -673,6 +689,7 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
           for (int ob = 0; ob < 4; ++ob) {
             const float v = fmaxf(__builtin_fmaf(yo[ob], sc, sh) + rv[oa][ob], act_lo);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, vo, oa * rowpitch + ob * colpitch, 0);
+            if constexpr (ST) { st1 += v; st2 = __builtin_fmaf(v, v, st2); }
           }
         }
       }
@@ -709,8 +726,20 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
             __syncthreads();
             if (tid == 0) __hip_atomic_fetch_add(tkw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           } else {
-            if (tid == 0)
-              while (__hip_atomic_load(tkw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 3u) __builtin_amdgcn_s_sleep(2);
+            if (tid == 0) {
+              // bounded [round 5, ADVICE r4]: a word that is not zero at launch (a program run beside itself, a caller
+              // that shares words between streams) would make both halves wait for ever; after ~2^22 polls (seconds)
+              // the block gives up, raises the launch's error word (the one behind the item pairs' words: zero in a
+              // healthy run, checked by the tests) and goes on with whatever y holds
+              unsigned spins = 0;
+              while (__hip_atomic_load(tkw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 3u) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 22)) {
+                  __hip_atomic_store(a.tickets + nreg * nct, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  break;
+                }
+              }
+            }
             __syncthreads();
             float pv[4][4];
 #pragma unroll
@@ -724,9 +753,20 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
               for (int ob = 0; ob < 4; ++ob) {
                 const float v = fmaxf(__builtin_fmaf(yc[oa][ob] + pv[oa][ob], sc, sh) + rv[oa][ob], act_lo);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, vo, oa * rowpitch + ob * colpitch, 0);
+                if constexpr (ST) { st1 += v; st2 = __builtin_fmaf(v, v, st2); }
               }
             if (tid == 0) __hip_atomic_store(tkw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+        }
+      }
+      if constexpr (ST) {
+        // 16 values per lane in fp32, the four tiles of a channel (kq) by shuffles, then into the wave's doubles
+        if (vo == EGN_OOB) { st1 = 0.f; st2 = 0.f; }          // (GEO 2: an image past N stores nothing)
+        st1 += __shfl_xor(st1, 16); st1 += __shfl_xor(st1, 32);
+        st2 += __shfl_xor(st2, 16); st2 += __shfl_xor(st2, 32);
+        if (kq == 0) {
+          sS[(wave * 2 + 0) * 16 + li] += (double)st1;
+          sS[(wave * 2 + 1) * 16 + li] += (double)st2;
         }
       }
       asm volatile("" ::: "memory");
@@ -734,6 +774,22 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
       __builtin_amdgcn_s_barrier();      // the exchange buffer is free again (next round / next item's DMA)
       asm volatile("" ::: "memory");
       W4_CLK()    /* round: end */
+    }
+  }
+  if constexpr (ST) {
+    // the block's row of the partial table: [2][Cout] doubles, its co-tile's 48 channels, zeros elsewhere
+    __syncthreads();
+    double* row = a.stats + (size_t)blockIdx.x * 2 * Co;
+    for (int e = tid; e < 2 * Co; e += W4_NTH) {
+      const int which = e / Co, c = e - which * Co;
+      const int cl = c - ct_blk * W4_CO;
+      double v = 0.0;
+      if (cl >= 0 && cl < W4_CO) {
+        const int nt_ = cl >> 4, l_ = cl & 15;       // the lanes of waves 4 nt .. 4 nt + 3 store co sub-tile nt
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v += sS[((4 * nt_ + k) * 2 + which) * 16 + l_];
+      }
+      row[e] = v;
     }
   }
   if constexpr ((ABL & 64) != 0) {
@@ -754,6 +810,9 @@ template <int ABL>      // conv_wino4b_kernel with the input channels of an item
 __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4bk_kernel(ConvArgs a) { w4_body<ABL, 1, 2>(a); }
 template <int ABL, int KS>
 __global__ __launch_bounds__(W4_NTH, 1) void conv_wino4c_kernel(ConvArgs a) { w4_body<ABL, 2, KS>(a); }
+// the training tape's builds (BatchNorm statistics in the item end, `ConvArgs::stats`): every geometry / K split above
+template <int GEO, int KS>
+__global__ __launch_bounds__(W4_NTH, 1) void conv_wino4s_kernel(ConvArgs a) { w4_body<0, GEO, KS, true>(a); }
 
 // second pass of the K-split form: y holds the sum of the items' raw outputs; y = act(y * scale + shift + res) in place
 __global__ __launch_bounds__(256) void conv_wino4_finish_kernel(float* __restrict__ y, const float* __restrict__ res,
@@ -785,12 +844,13 @@ bool egn_conv_wino4_applies(const ConvArgs& a, int geo) {
          a.Cout % W4_CO == 0 && a.cs_out == a.Cout && !a.out_nchw && map_ok && !(a.act & EGN_ACT_RES_AFTER) &&
          ((a.act & EGN_ACT_MASK) == EGN_ACT_NONE || (a.act & EGN_ACT_MASK) == EGN_ACT_RELU);
 }
-// ticket words a K-split launch wants (zeroed once; every launch leaves them zero): one per (region, co-tile); 0 = none
+// ticket words a K-split launch wants (zeroed once; every launch leaves them zero): one per (region, co-tile) + one; 0 = none
 // (a: planned -- tiles_x / tiles_y are the regions of an image)
 int egn_conv_wino4_tickets(const ConvArgs& a, int geo) {
   if (!(geo & 4) || !egn_conv_wino4_applies(a, geo)) return 0;
   const int nimg = (geo & 3) == 2 ? 4 : 1;
-  return a.tiles_x * a.tiles_y * ((a.N + nimg - 1) / nimg) * (a.Cout / W4_CO);
+  // one word per (region, co-tile) + the launch's error word behind them (raised by a block whose wait ran out)
+  return a.tiles_x * a.tiles_y * ((a.N + nimg - 1) / nimg) * (a.Cout / W4_CO) + 1;
 }
 size_t egn_conv_wino4_lds_bytes(int geo) {      // (+ the stamp area of the ABL & 64 build)
   return ((geo & 3) == 2 ? w4_lds_bytes<2>() : w4_lds_bytes<0>()) + 12 * 96 * 8;
@@ -811,46 +871,7 @@ __global__ __launch_bounds__(256) void wino4_pack_weight_kernel(const float* __r
   const int n_out = dgrad ? Cin : Cout, n_in = dgrad ? Cout : Cin;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_out * n_in; e += gridDim.x * blockDim.x) {
     const int o = e / n_in, i = e - o * n_in;
-    double g[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b)
-        g[a][b] = dgrad ? (double)w[((size_t)i * Cin + o) * 9 + (2 - a) * 3 + (2 - b)]
-                        : (double)w[((size_t)o * Cin + i) * 9 + a * 3 + b];
-    // rows of G (points 0, +-1, +-2, inf): [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
-    double t[6][3];   // G g
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const double g0 = g[0][b], g1 = g[1][b], g2 = g[2][b];
-      t[0][b] = g0 / 4.0;
-      t[1][b] = -(g0 + g1 + g2) / 6.0;
-      t[2][b] = -(g0 - g1 + g2) / 6.0;
-      t[3][b] = g0 / 24.0 + g1 / 12.0 + g2 / 6.0;
-      t[4][b] = g0 / 24.0 - g1 / 12.0 + g2 / 6.0;
-      t[5][b] = g2;
-    }
-    const int ct = o / W4_CO, nt = (o % W4_CO) >> 4, li = o & 15;
-    const int h = i >> 2, kq = i & 3;
-    float* base = dst + ((size_t)ct * (n_in >> 2) + h) * W4_UKG + (16 * kq + li) * 4;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      const double t0 = t[a][0], t1 = t[a][1], t2 = t[a][2];
-      const double u[6] = {t0 / 4.0, -(t0 + t1 + t2) / 6.0, -(t0 - t1 + t2) / 6.0, t0 / 24.0 + t1 / 12.0 + t2 / 6.0,
-                           t0 / 24.0 - t1 / 12.0 + t2 / 6.0, t2};
-#pragma unroll
-      for (int b = 0; b < 6; ++b) {
-        const int pt = a * 6 + b, wave = pt / 3, p = 3 * (pt % 3) + nt;       // value p = 4 q + r of (wave, lane)
-        base[(size_t)wave * 768 + (p >> 2) * 256 + (p & 3)] = (float)u[b];
-      }
-    }
-    if (nt == 0) {
-#pragma unroll
-      for (int wave = 0; wave < W4_NW; ++wave) {
-        float* pad = base + (size_t)wave * 768 + 2 * 256;
-        pad[1] = 0.f; pad[2] = 0.f; pad[3] = 0.f;
-      }
-    }
+    w4p_pack_pair(w, Cin, dgrad, o, i, n_in, dst);
   }
 }
 extern "C" long long egn_wino4_pack_weight_floats(int Cout, int Cin, int dgrad) {
@@ -866,21 +887,43 @@ extern "C" int egn_wino4_pack_weight_f32(const float* w, int Cout, int Cin, int 
 
 static unsigned w4_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d); }
 
-template <int ABL, int GEO, int KS>
-static int wino4_launch(ConvArgs a, size_t lds, hipStream_t stream) {
-  static bool raised[EGN_MAX_DEVICES];
+static int w4_cus() {
   static int cus = 0;
-  auto kern = GEO == 2 ? &conv_wino4c_kernel<ABL, KS> : (GEO == 0 ? &conv_wino4_kernel<ABL> : (KS > 1 ? &conv_wino4bk_kernel<ABL> : &conv_wino4b_kernel<ABL>));
-  if (egn_first_use_on_device(raised)) {
-    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024 - 512));
-  }
   if (!cus) {
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     if (cus <= 0) cus = 256;
   }
+  return cus;
+}
+// persistent grid: one block per CU in whole XCD rounds of (co-tile, K half) -- a multiple of 8 nct KS, so that the
+// items w, w + grid, ... of a block share the co-tile (and the K half): its BatchNorm partial row covers one co-tile
+static int w4_grid(int nwork, int nck) {
+  int cap = w4_cus() / (8 * nck) * (8 * nck);
+  if (cap <= 0) cap = 8 * nck;
+  return nwork < cap ? nwork : cap;
+}
+// rows of the BatchNorm partial table a launch with ConvArgs::stats writes (a: planned): one per block; 0 = none
+int egn_conv_wino4_stats_rows(const ConvArgs& a, int geo) {
+  if (!egn_conv_wino4_applies(a, geo)) return 0;
+  const int g = geo & 3, ks = (geo & 4) ? 2 : 1, nimg = g == 2 ? 4 : 1;
+  const int nct = a.Cout / W4_CO;
+  const int nreg = a.tiles_x * a.tiles_y * ((a.N + nimg - 1) / nimg);
+  return w4_grid(w4_item_count(w4_item_mode(nct), nreg, nct, ks), nct * ks);
+}
+
+template <int ABL, int GEO, int KS, bool ST = false>
+static int wino4_launch(ConvArgs a, size_t lds, hipStream_t stream) {
+  static bool raised[EGN_MAX_DEVICES];
+  void (*kern)(ConvArgs);
+  if constexpr (ST) kern = &conv_wino4s_kernel<GEO, KS>;
+  else kern = GEO == 2 ? &conv_wino4c_kernel<ABL, KS> : (GEO == 0 ? &conv_wino4_kernel<ABL> : (KS > 1 ? &conv_wino4bk_kernel<ABL> : &conv_wino4b_kernel<ABL>));
+  if (egn_first_use_on_device(raised)) {
+    EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 512));
+  }
+  if (ST && KS > 1 && !a.tickets) return EGN_E_BADARG;   // (the three-launch form applies the epilogue in another kernel)
   const int nct = a.Cout / W4_CO, nck = nct * KS;
   const int nreg = a.tiles_x * a.tiles_y * ((a.N + W4G<GEO>::NIMG - 1) / W4G<GEO>::NIMG);
   const int imode = w4_item_mode(nct);
@@ -892,9 +935,7 @@ static int wino4_launch(ConvArgs a, size_t lds, hipStream_t stream) {
   a.mg_nct = imode == 1 ? 0u : w4_magic(imode == 2 ? nct / 8 : nck);
   a.mg_txy = w4_magic(a.tiles_x * a.tiles_y);
   a.mg_tx = w4_magic(a.tiles_x);
-  int cap = cus / (8 * nck) * (8 * nck);              // one block per CU, whole XCD rounds
-  if (cap <= 0) cap = 8 * nck;
-  const int grid = nwork < cap ? nwork : cap;
+  const int grid = w4_grid(nwork, nck);               // one block per CU, whole XCD rounds
   if (KS > 1 && !a.tickets) {
     const size_t n = (size_t)a.N * a.Ho * a.Wo * a.Cout;
     EGN_CHECK_HIP(hipMemsetAsync(a.y, 0, n * sizeof(float), stream));
@@ -908,7 +949,18 @@ static int wino4_launch(ConvArgs a, size_t lds, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, int geo, hipStream_t stream) {
-  if (!egn_conv_wino4_applies(a, geo) || a.stats) return EGN_E_BADARG;
+  if (!egn_conv_wino4_applies(a, geo)) return EGN_E_BADARG;
+  if (a.stats) {                       // the training tape: BatchNorm statistics in the item end
+    if (abl) return EGN_E_BADARG;
+    switch (geo) {
+      case 0: return wino4_launch<0, 0, 1, true>(a, lds, stream);
+      case 1: return wino4_launch<0, 1, 1, true>(a, lds, stream);
+      case 5: return wino4_launch<0, 1, 2, true>(a, lds, stream);
+      case 2: return wino4_launch<0, 2, 1, true>(a, lds, stream);
+      case 6: return wino4_launch<0, 2, 2, true>(a, lds, stream);
+      default: return EGN_E_BADARG;
+    }
+  }
   if ((geo & 3) == 2) {
     if (abl) return EGN_E_BADARG;
     return (geo & 4) ? wino4_launch<0, 2, 2>(a, lds, stream) : wino4_launch<0, 2, 1>(a, lds, stream);

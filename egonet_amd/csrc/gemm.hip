@@ -36,6 +36,8 @@
 // Shapes: M % BM == 0, N % BN == 0, K % 32 == 0 (per split), leading dimensions % 4 == 0; anything else stays on
 // the conv-kernel route (egn_gemm_supported).  Numerics: an fp32 fmaf chain in k order per split, splits added
 // in a fixed order -- deterministic.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 typedef __attribute__((address_space(3))) void* lds_ptr_gemm_t;
@@ -56,6 +58,7 @@ struct GemmArgs {
   int M, N, K;        // K = k range of ONE split
   int lda, ldb, ldc;
   int tiles_m, tiles_n, splits;
+  int raster;         // block -> (split, tile) order, see the kernel (EGONET_AMD_GEMM_RASTER=0: round 4's order)
   size_t a_bytes, b_bytes;
 };
 
@@ -108,11 +111,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(GemmA
   // block -> (split, tile).  b % 8 = XCD: the blocks of an XCD take consecutive n-tiles of the same m-tile rows
   // (their A rows are fetched into that XCD's L2 once; B is small enough to be resident everywhere)
   const int ntiles = g.tiles_m * g.tiles_n;
-  const int per = (ntiles + 7) >> 3;                 // tile slots per XCD (the launcher's grid = 8 * per * splits)
+  const int per = (ntiles + 7) >> 3;                 // tile slots per XCD and split (the launcher's grid = 8 * per * splits)
   const int b = blockIdx.x;
-  const int split = b / (8 * per);
-  int t = b - split * 8 * per;
-  {
+  int split, t;
+  if (g.raster) {
+    // [round 5] the XCD owns a contiguous run of the list of (split, tile) pairs: with split K (the weight gradient:
+    // 4 splits x 64 tiles) an XCD works on ONE K slice and four rows of tiles -- 2 MB of A and 4 MB of B per XCD
+    // instead of a panel of A and all of B of EVERY slice (profiles/r4_pmc_traffic.json: 168 MB per launch against
+    // 37.7 MB algorithmic).  With one split this is the order of the other branch.
+    const int x = b & 7, q = b >> 3;                 // XCD, slot on it (per * splits slots)
+    const int l = x * per * g.splits + q;
+    split = l / ntiles;
+    t = l - split * ntiles;
+    if (split >= g.splits) return;                   // (ntiles % 8 != 0: rounded-up grid)
+  } else {
+    split = b / (8 * per);
+    t = b - split * 8 * per;
     const int x = t & 7, q = t >> 3;                 // XCD, slot on it
     t = x * per + q;                                 // tiles [x*per, (x+1)*per) live on XCD x
     if (t >= ntiles) return;                         // (ntiles % 8 != 0: rounded-up grid)
@@ -287,20 +301,22 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void gemm_kernel(GemmA
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const float bj = g.bias ? g.bias[n0 + wn * TN + j * 16 + li] : 0.f;
-        float s1 = 0.f, s2 = 0.f;
+        // [round 5, ADVICE r4] in doubles from the first add: with fp32 squares a column whose |mean| is 1e3 x its
+        // deviation lost several digits of E[x^2] - mean^2 (tests/test_gpu_gemm.py: the large-mean case)
+        double s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = acc[i][j][r] + bj;
+            const double v = (double)(acc[i][j][r] + bj);
             s1 += v;
             s2 += v * v;
           }
         s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
         if (kq == 0) {
-          sS[(wave * 2 + 0) * TN + j * 16 + li] = (double)s1;
-          sS[(wave * 2 + 1) * TN + j * 16 + li] = (double)s2;
+          sS[(wave * 2 + 0) * TN + j * 16 + li] = s1;
+          sS[(wave * 2 + 1) * TN + j * 16 + li] = s2;
         }
       }
     }
@@ -356,6 +372,8 @@ int gemm_launch(GemmArgs g, hipStream_t st) {
     EGN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   g.tiles_m = g.M / BM;
   g.tiles_n = g.N / BN;
+  static const int raster = [] { const char* e = getenv("EGONET_AMD_GEMM_RASTER"); return e && e[0] == '0' ? 0 : 1; }();
+  g.raster = raster;
   const int ntiles = g.tiles_m * g.tiles_n;
   const int grid = ((ntiles + 7) / 8) * 8 * g.splits;      // 8 * per tile slots per split (kernel: XCD remap)
   hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), lds, st, g);

@@ -91,6 +91,51 @@ extern "C" int egn_conv2d_bnstats_f32(const float* x, const float* wpack, const 
   return egn_conv_launch(a, cfg, (hipStream_t)stream);
 }
 
+// egn_conv2d_f32 with the two optional side tables of the training tape [round 5]:
+//   partials / partial_rows: BatchNorm partial statistics of the stored output, as egn_conv2d_bnstats_f32 (NULL: none;
+//                            else egn_conv2d_bnstats_rows(cfg) must be > 0 and <= partial_rows);
+//   tickets / ticket_words:  zeroed words for the K-split configurations (egn_conv2d_ticket_words(cfg) of them): the
+//                            layer then runs as ONE kernel as inside a program and leaves the words zero; launches that
+//                            share the words must be ordered (one stream).  NULL: the three-launch form.
+extern "C" long egn_conv2d_ticket_words(int N, int H, int W, int Cin, int cs_in, int Cout, int cs_out, int KH, int KW,
+                                        int stride, int pad, int cfg) {
+  ConvArgs a;
+  if (fill_conv_args(a, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, N, H, W, Cin, cs_in, Cout, cs_out, KH,
+                     KW, stride, pad, 0, 0))
+    return 0;
+  size_t lds;
+  if (cfg < 1 || egn_conv_plan(a, cfg, lds)) return 0;
+  return egn_conv_ticket_count(a, cfg);
+}
+
+extern "C" int egn_conv2d_ex_f32(const float* x, const float* wpack, const float* scale, const float* shift,
+                                 const float* res, float* y, int N, int H, int W, int Cin, int cs_in, int Cout,
+                                 int cs_out, int KH, int KW, int stride, int pad, int act, int cfg, double* partials,
+                                 long partial_rows, unsigned* tickets, long ticket_words, void* stream) {
+  g_egn_direct_convs.fetch_add(1, std::memory_order_relaxed);
+  ConvArgs a;
+  int rc = fill_conv_args(a, x, wpack, scale, shift, res, y, N, H, W, Cin, cs_in, Cout, cs_out, KH, KW, stride, pad,
+                          act, 0);
+  if (rc) return rc;
+  if (cfg < 1) return EGN_E_BADARG;
+  size_t lds;
+  rc = egn_conv_plan(a, cfg, lds);
+  if (rc) return rc;
+  if (partials) {
+    const int rows = egn_conv_stats_rows(a, cfg);
+    if (rows <= 0 || partial_rows < rows) return EGN_E_BADARG;
+    a.stats = partials;
+  }
+  if (tickets) {
+    const int ntk = egn_conv_ticket_count(a, cfg);
+    if (ntk > 0) {
+      if (ticket_words < ntk) return EGN_E_BADARG;
+      a.tickets = tickets;
+    }
+  }
+  return egn_conv_launch(a, cfg, (hipStream_t)stream);
+}
+
 extern "C" int egn_conv_plan_query(int N, int H, int W, int Cin, int cs_in, int Cout, int cs_out, int KH,
                                    int KW, int stride, int pad, int out_nchw, int cfg, int* out) {
   if (!out) return EGN_E_BADARG;
@@ -143,7 +188,30 @@ struct egn_program {
   hipStream_t side[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_fork = nullptr;
   hipEvent_t ev_join[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+  // "a program never runs beside itself" (one arena, one set of side streams, one set of ticket words) is enforced, not
+  // assumed [round 5]: every eager run / replay records ev_done on its stream, and a run on ANOTHER stream waits for it
+  hipEvent_t ev_done = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool ran = false;
 };
+
+// order this run behind the previous one of the same program if that was issued on another stream (same stream: already
+// ordered).  Not while the stream is being captured (the graph's own edges order a replay; replays are ordered below).
+static int order_behind_last_run(egn_program* p, hipStream_t s, bool* capturing) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  *capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+  if (*capturing) return 0;
+  if (!p->ev_done) EGN_CHECK_HIP(hipEventCreateWithFlags(&p->ev_done, hipEventDisableTiming));
+  if (p->ran && p->last_stream != s) EGN_CHECK_HIP(hipStreamWaitEvent(s, p->ev_done, 0));
+  return 0;
+}
+static int mark_run_issued(egn_program* p, hipStream_t s, bool capturing) {
+  if (capturing) return 0;
+  EGN_CHECK_HIP(hipEventRecord(p->ev_done, s));
+  p->last_stream = s;
+  p->ran = true;
+  return 0;
+}
 
 static inline void* resolve(const egn_program* p, const egn_ref& r) {
   if (r.slot < 0) return nullptr;
@@ -170,6 +238,7 @@ extern "C" void egn_program_destroy(egn_program* p) {
     if (p->ev_join[k]) hipEventDestroy(p->ev_join[k]);
   }
   if (p->ev_fork) hipEventDestroy(p->ev_fork);
+  if (p->ev_done) hipEventDestroy(p->ev_done);
   delete p;
 }
 
@@ -208,12 +277,17 @@ extern "C" int egn_program_add_conv2d(egn_program* p, egn_ref x, egn_ref wpack, 
   op.lane = p->cur_lane;
   // K-split configurations (conv_wino4.hip) run as one kernel when the op brings a ticket word per item pair: they
   // belong to the op (a program never runs beside itself), are zeroed here and left zero by every launch
-  const int ntk = egn_conv_ticket_count(op.conv, cfg);
+  // (EGONET_AMD_NO_TICKETS=1: no words -- the three-launch form of such a layer, for A/B runs and as a fallback)
+  static const bool no_tickets = [] { const char* e = getenv("EGONET_AMD_NO_TICKETS"); return e && e[0] == '1'; }();
+  const int ntk = no_tickets ? 0 : egn_conv_ticket_count(op.conv, cfg);
   if (ntk > 0) {
     void* d = nullptr;
     EGN_CHECK_HIP(hipMalloc(&d, (size_t)ntk * sizeof(unsigned)));
     p->owned.push_back(d);
+    // (programs run on the caller's non-blocking streams, which do not order themselves behind the legacy stream: the
+    // words are zero in memory before this call returns -- a non-zero ticket would make both halves of a pair wait)
     EGN_CHECK_HIP(hipMemset(d, 0, (size_t)ntk * sizeof(unsigned)));
+    EGN_CHECK_HIP(hipDeviceSynchronize());
     op.conv.tickets = static_cast<unsigned*>(d);
   }
   p->ops.push_back(op);
@@ -398,6 +472,9 @@ extern "C" int egn_program_run(egn_program* p, void* stream) {
   if (!p) return EGN_E_BADARG;
   hipStream_t main = (hipStream_t)stream;
   bool used[kMaxLanes] = {false, false, false, false};
+  bool capturing = false;
+  int rc_o = order_behind_last_run(p, main, &capturing);
+  if (rc_o) return rc_o;
   for (Op& op : p->ops) {
     if (op.kind == OP_FORK) {
       int rc = ensure_lanes(p);
@@ -426,7 +503,7 @@ extern "C" int egn_program_run(egn_program* p, void* stream) {
     int rc = launch_op(p, op, s);
     if (rc) return rc;
   }
-  return 0;
+  return mark_run_issued(p, main, capturing);
 }
 
 extern "C" int egn_program_run_timed(egn_program* p, void* stream, float* ms, int n_ms) {
@@ -479,5 +556,9 @@ extern "C" int egn_program_replay(egn_program* p, void* stream) {
   long nk = 0;
   for (const Op& op : p->ops) nk += (op.kind != OP_FORK && op.kind != OP_JOIN);
   g_launches.fetch_add(nk, std::memory_order_relaxed);
-  return (int)hipGraphLaunch(p->exec, (hipStream_t)stream);
+  bool capturing = false;
+  int rc = order_behind_last_run(p, (hipStream_t)stream, &capturing);
+  if (rc) return rc;
+  EGN_CHECK_HIP(hipGraphLaunch(p->exec, (hipStream_t)stream));
+  return mark_run_issued(p, (hipStream_t)stream, capturing);
 }

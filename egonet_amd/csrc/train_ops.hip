@@ -12,6 +12,7 @@
 // BatchNorm(+ReLU+dropout) forward / backward, column sums, MSE and Adam.
 // Activations are row-major [rows, ld] fp32 = NHWC [rows,1,1,ld]; ld % 4 == 0.
 #include "egn_internal.h"
+#include "wino4_pack.h"
 
 static inline int grid_for(size_t work_items, int block) {
   size_t g = (work_items + block - 1) / block;
@@ -912,6 +913,21 @@ __global__ __launch_bounds__(256) void pack_conv_weights_batch_kernel(const egn_
     }
     const egn_pack_desc d = descs[lo];
     const long long le = e - d.begin;
+    if (d.dgrad & 4) {
+      // [round 5] F(4x4,3x3) filter in conv_wino4.hip's register-feed layout (wino4_pack.h); one unit = one (co, ci)
+      // pair = 36 stores.  A wavefront covers the 16 channels li x 4 input channels kq of one (co sub-tile, k-group):
+      // each of its store instructions fills one 1 KB block of the (co-tile, k-group, wave) slab.
+      const int dg = d.dgrad & 1;
+      const int n_out = dg ? d.Cin : d.Cout, n_in = dg ? d.Cout : d.Cin;
+      const int li = (int)(le & 15), kq = (int)((le >> 4) & 3);
+      long long r_ = le >> 6;
+      const int nt = (int)(r_ % 3);
+      r_ /= 3;
+      const int h = (int)(r_ % (n_in >> 2));
+      const int ct = (int)(r_ / (n_in >> 2));
+      if (ct * W4P_CO < n_out) w4p_pack_pair(d.w, d.Cin, dg, ct * W4P_CO + nt * 16 + li, 4 * h + kq, n_in, d.dst);
+      continue;
+    }
     if (d.dgrad & 2) {
       // Winograd filter U = G g G^T (conv_wino.hip layout [co-tile][chunk][f][quad][48][4]); one unit =
       // one (co-tile, chunk, quad, co) = 4 input channels x 16 frequencies = 16 coalesced float4 stores

@@ -93,6 +93,7 @@ class FCModel(nn.Module):
     def train(self, mode=True):
         if mode:                 # the weights are about to change: drop programs and packed blobs
             self._engine = None
+        self.__dict__.pop('_hook_dicts', None)      # (heatmapModel.hrnet._has_submodule_hooks' cache)
         return super().train(mode)
 
     def _hip_engine(self):

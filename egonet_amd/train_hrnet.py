@@ -143,21 +143,29 @@ class PackedFilters(object):
         self.ptrs = None
 
     def get(self, weight, dgrad, stream, wino=False):
-        """``wino``: the Winograd-transformed filter (conv_wino.hip kernels) instead of the direct pack."""
-        code = int(dgrad) | (2 if wino else 0)
+        """``wino``: the Winograd-transformed filter instead of the direct pack -- True / 1: F(2x2,3x3) (conv_wino.hip,
+        egn_conv_config_kind 1), 3: F(4x4,3x3) in conv_wino4.hip's register-feed layout (kind 3)."""
+        wino = int(wino)
+        code = int(dgrad) | (4 if wino == 3 else (2 if wino else 0))
         ent = self.entries.get((id(weight), code))
         if ent is not None and self.table is not None:
             return ent[1]
         cout, cin, kh, kw = weight.shape
         if ent is None:
-            nfl = self.L.egn_wino_weight_floats(cout, cin, dgrad) if wino else \
-                self.L.egn_packed_weight_floats(cout, cin, kh, kw, dgrad)
+            nfl = self.L.egn_wino4_pack_weight_floats(cout, cin, dgrad) if wino == 3 else \
+                (self.L.egn_wino_weight_floats(cout, cin, dgrad) if wino else
+                 self.L.egn_packed_weight_floats(cout, cin, kh, kw, dgrad))
+            if nfl <= 0:
+                raise ValueError('no packed layout %d for a %s filter' % (wino, tuple(weight.shape)))
             wp = torch.empty(nfl, dtype=torch.float32, device=self.dev)
             self.entries[(id(weight), code)] = (weight, wp)
             self.table = None
         else:
             wp = ent[1]
-        if wino:
+        if wino == 3:
+            _lib.check(self.L.egn_wino4_pack_weight_f32(_lib.ptr(weight), cout, cin, dgrad, _lib.ptr(wp), stream),
+                       'wino4 pack')
+        elif wino:
             _lib.check(self.L.egn_wino_pack_weight_f32(_lib.ptr(weight), cout, cin, dgrad, _lib.ptr(wp), stream),
                        'wino pack')
         else:
@@ -179,7 +187,7 @@ class PackedFilters(object):
         for i, ((_, code), (w, wp)) in enumerate(self.entries.items()):
             cout, cin, kh, kw = w.shape
             desc[i] = (w.data_ptr(), wp.data_ptr(), cout, cin, kh * kw, code, begin)
-            begin += wp.numel() // (64 if code & 2 else 4)     # work units (egonet_hip.h)
+            begin += wp.numel() // (48 if code & 4 else (64 if code & 2 else 4))     # work units (egonet_hip.h)
         self.total = begin
         self.table = torch.from_numpy(desc.view(np.uint8)).to(self.dev)
         self.ptrs = self._pointers()
@@ -271,8 +279,23 @@ class _Tape(object):
         from the step's PackedFilters like the direct one."""
         key = (n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, False, False)
         can_wino = weight is not None and act in (ACT_NONE, ACT_RELU) and self.o.allow_wino
-        cfg = tuner.choose(self.dev, key, allow_wino=can_wino)
-        if can_wino and cfg > 0 and self.L.egn_conv_config_kind(cfg) == 1:
+        # [round 5] F(4x4,3x3) (csrc/conv_wino4.hip, filter kind 3) in the tape: the filter is transformed on the device
+        # with all the others (PackedFilters), BatchNorm statistics come from conv_wino4s_kernel's item end, the K-split
+        # configurations get the owner's ticket words (one stream: launches that share them are ordered)
+        can_f43 = can_wino and self.o.allow_f43 in (('all',) if dgrad else ('all', 'fwd'))
+        cfg = tuner.choose(self.dev, key, allow_wino=can_wino, allow_f43=can_f43)
+        kind = self.L.egn_conv_config_kind(cfg) if cfg > 0 else 0
+        ntk = 0
+        if kind == 3:
+            ntk = self.L.egn_conv2d_ticket_words(n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, cfg)
+            if ntk > 0 and (ntk > self.o.tickets.numel() or (res is not None and res.data_ptr() == y.data_ptr())):
+                # (the K split writes a raw share into y before the residual is read: not for the in-place gradient add)
+                cfg = tuner.choose(self.dev, key, allow_wino=can_wino, allow_f43=False)
+                kind = self.L.egn_conv_config_kind(cfg) if cfg > 0 else 0
+                ntk = 0
+        if kind == 3:
+            wp = self.o.packs.get(weight, dgrad, self.st, wino=3)
+        elif can_wino and kind == 1:
             wp = self.o.packs.get(weight, dgrad, self.st, wino=True)
         elif wp is None:
             wp = self._pack(weight, dgrad)
@@ -287,7 +310,14 @@ class _Tape(object):
         if tm is not None:         # bench.py: hipEvents around every forward / data-gradient conv launch
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.dev))
-        if stats is not None:
+        if kind == 3:
+            _lib.check(self.L.egn_conv2d_ex_f32(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(self.o.ones), _lib.ptr(shift),
+                                                _lib.ptr(res), _lib.ptr(y), n, h, w, cin, cs_in, cout, cs_out, kh, kw,
+                                                stride, pad, act, cfg, None if stats is None else _lib.ptr(stats[0]),
+                                                0 if stats is None else stats[1],
+                                                _lib.ptr(self.o.tickets) if ntk > 0 else None, self.o.tickets.numel(),
+                                                self.st), 'conv (F(4x4,3x3))')
+        elif stats is not None:
             _lib.check(self.L.egn_conv2d_bnstats_f32(_lib.ptr(x), _lib.ptr(wp), _lib.ptr(self.o.ones), _lib.ptr(shift),
                                                      _lib.ptr(y), n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride,
                                                      pad, cfg, _lib.ptr(stats[0]), stats[1], self.st), 'conv+stats')
@@ -580,6 +610,14 @@ class TapeOwner(object):
         # 3x3 stride-1 forward / data-gradient convolutions may run on the fused Winograd kernels
         # (csrc/conv_wino.hip) where they measured faster (EGONET_AMD_TRAIN_WINO=0: direct kernels only)
         self.allow_wino = os.environ.get('EGONET_AMD_TRAIN_WINO', '1') != '0'
+        # ... and on the F(4x4,3x3) kernels (csrc/conv_wino4.hip) [round 5]: EGONET_AMD_TRAIN_F43 = all (forward and
+        # data-gradient convolutions), fwd (forward only), 0 (F(2x2,3x3) / direct only)
+        f43 = os.environ.get('EGONET_AMD_TRAIN_F43', 'all')
+        self.allow_f43 = {'1': 'all', 'all': 'all', 'fwd': 'fwd'}.get(f43, '0')
+        # ticket words of the K-split configurations (cfg 83 / 84): zero between launches, shared by the launches of
+        # the tape's one stream
+        self.tickets = torch.zeros(1 << 16, dtype=torch.int32, device=self.dev)
+        torch.cuda.current_stream(self.dev).synchronize()      # (zero in memory before any stream's first launch)
         self.fuse_bn_stats = os.environ.get('EGONET_AMD_FUSE_BN_STATS', '1') != '0'
         self.fuse_grad_add = os.environ.get('EGONET_AMD_FUSE_GRAD_ADD', '1') != '0'
 

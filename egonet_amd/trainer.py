@@ -70,10 +70,11 @@ def _barrier():
 _HOST_GROUP = None
 
 
-def _wait_for_rank0():
-    """Ranks != 0 wait here while rank 0 validates.  A host-side (gloo) group with a long timeout is used where it can
-    be made: a GPU barrier kernel would sit on the device for the whole validation and is subject to the NCCL watchdog
-    timeout of the training group.  Falls back to the default group's barrier."""
+def _make_host_group():
+    """The host-side (gloo) group the waiting ranks use during rank 0's validation, created ONCE at the start of
+    ``train`` -- where every rank arrives together (``dist.new_group`` is itself a collective: made lazily at the first
+    mid-epoch evaluation, ranks != 0 would sit in it for the whole validation and could time out while rank 0 is still
+    evaluating).  False = could not be made (the default group's barrier is used)."""
     global _HOST_GROUP
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
@@ -81,10 +82,19 @@ def _wait_for_rank0():
     if _HOST_GROUP is None:
         import datetime
         try:
-            # collective: every rank reaches its first wait in the same place of the loop
             _HOST_GROUP = dist.new_group(backend='gloo', timeout=datetime.timedelta(hours=12))
         except Exception:
             _HOST_GROUP = False
+
+
+def _wait_for_rank0():
+    """Ranks != 0 wait here while rank 0 validates: a barrier of the host-side (gloo) group (12 h timeout) where it
+    could be made -- a GPU barrier kernel would sit on the device for the whole validation and is subject to the NCCL
+    watchdog timeout of the training group -- else the default group's barrier."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return
+    _make_host_group()          # (a no-op after train()'s call; callers outside train() make it at their first wait)
     if _HOST_GROUP:
         dist.barrier(group=_HOST_GROUP)
     else:
@@ -267,6 +277,8 @@ def train(train_dataset, model, loss_func, optim, sche, cfgs, logger, metric_fun
     dev = step.dev
     x_buffer, y_buffer = [], []
     frozen = False
+    if eval_during:
+        _make_host_group()      # all ranks are here together: the group exists before anyone has to wait in it
     try:
         for epoch in range(1, total_epochs + 1):
             if epoch > 1 and is_hc:
@@ -318,9 +330,9 @@ def train(train_dataset, model, loss_func, optim, sche, cfgs, logger, metric_fun
                     # (ts['eval_all_ranks'] restores one evaluation per rank), the others wait for it.
                     # CONTRACT: unless 'eval_all_ranks' is set, `evaluate_fn` runs on rank 0 ONLY -- it must
                     # not contain collectives or DistributedSampler logic (they would wait for ranks that never call
-                    # them).  The waiting ranks block on a HOST-side broadcast of a done flag (gloo-style object
-                    # broadcast over the default group), not on a GPU barrier kernel, and the wait is bounded by the
-                    # process group's own timeout: choose `timeout=` in init_process_group for the longest validation.
+                    # them).  The waiting ranks block in a barrier of a HOST-side gloo group made at the start of
+                    # train() (12 h timeout), not on a GPU barrier kernel; if that group could not be made, in the
+                    # default group's barrier (bounded by ITS timeout: choose `timeout=` in init_process_group).
                     if _rank() == 0 or ts.get('eval_all_ranks', False):
                         evaluate_fn(valid_dataset, model, epoch)
                     _wait_for_rank0()

@@ -320,6 +320,24 @@ int egn_conv2d_bnstats_f32(const float* x, const float* wpack, const float* ones
                            int Cin, int cs_in, int Cout, int cs_out, int KH, int KW,
                            int stride, int pad, int cfg, double* partials,
                            long partial_rows, void* stream);
+/* [round 5] egn_conv2d_f32 with the two optional side tables of the native training tape
+ * (replaces the MIOpen convolutions under libs/trainer/trainer.py:191-197 for the 3x3 s1 layers of
+ * libs/model/heatmapModel/hrnet.py:63-92 on the F(4x4,3x3) kernels):
+ *   partials / partial_rows  BatchNorm partial statistics of the stored output, as egn_conv2d_bnstats_f32
+ *                            (NULL = none; else egn_conv2d_bnstats_rows(cfg) rows are written);
+ *   tickets / ticket_words   zeroed `unsigned` words for the K-split configurations (cfg 83 / 84):
+ *                            egn_conv2d_ticket_words(...) of them (0 = the configuration uses none).  With
+ *                            them the layer is ONE kernel launch, as inside a program, and leaves the words
+ *                            zero; launches that share the words must be ordered (one stream).  NULL = the
+ *                            three-launch form of egn_conv2d_f32. */
+long egn_conv2d_ticket_words(int N, int H, int W, int Cin, int cs_in, int Cout,
+                             int cs_out, int KH, int KW, int stride, int pad, int cfg);
+int egn_conv2d_ex_f32(const float* x, const float* wpack, const float* scale,
+                      const float* shift, const float* res, float* y, int N, int H,
+                      int W, int Cin, int cs_in, int Cout, int cs_out, int KH, int KW,
+                      int stride, int pad, int act, int cfg, double* partials,
+                      long partial_rows, unsigned* tickets, long ticket_words,
+                      void* stream);
 int egn_bn_stats_finalize_f32(const double* partials, long nrows, int rows, int cols,
                               float eps, float* mean, float* invstd,
                               float* var_unbiased, float* running_mean,
@@ -418,7 +436,9 @@ int egn_pack_conv_weight_f32(const float* w, int Cout, int Cin, int KH, int KW,
  * (egn_pack_desc_bytes() bytes each), `begin` = running sum of the work units of the
  * preceding descriptors: egn_packed_weight_floats()/4 (one float4 each) for the direct
  * layouts (dgrad 0 / 1), egn_wino_weight_floats()/64 for the Winograd layout
- * (dgrad | 2: taps must be 9; one unit = 4 input channels x 16 frequencies). */
+ * (dgrad | 2: taps must be 9; one unit = 4 input channels x 16 frequencies),
+ * egn_wino4_pack_weight_floats()/48 for the F(4x4,3x3) layout of conv_wino4.hip
+ * (dgrad | 4: taps must be 9; one unit = one (output, input) channel pair). */
 int egn_pack_desc_bytes(void);
 int egn_pack_conv_weights_batch_f32(const void* descs_dev, int n, long total_float4,
                                     void* stream);

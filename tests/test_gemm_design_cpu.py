@@ -149,3 +149,30 @@ def test_xcd_tile_remap_is_a_bijection():
         per = (ntiles + 7) // 8
         seen = sorted((t & 7) * per + (t >> 3) for t in range(ntiles))
         assert seen == list(range(ntiles))
+
+
+def test_split_k_block_order_gives_an_xcd_one_k_slice():
+    """[round 5] gemm_kernel's block -> (split, tile) order with g.raster: every (split, tile) exactly once, also with a
+    rounded-up grid; with one split it is the order above; with the weight gradient's 4 splits x 64 tiles an XCD works
+    on ONE K slice and whole rows of tiles (the panels of A it shares), where round 4's order gave it a row of every
+    slice."""
+    def order(ntiles, splits):
+        per = (ntiles + 7) // 8
+        out = {}
+        for b in range(8 * per * splits):
+            x, q = b & 7, b >> 3
+            l = x * per * splits + q
+            split, t = divmod(l, ntiles)
+            if split < splits:
+                out[b] = (split, t)
+        return out
+    for ntiles, splits in ((64, 4), (256, 1), (64, 1), (24, 2), (9, 3), (72, 8)):
+        o = order(ntiles, splits)
+        assert sorted(o.values()) == [(s, t) for s in range(splits) for t in range(ntiles)]
+    per = 32
+    assert all(order(256, 1)[b] == (0, (b & 7) * per + (b >> 3)) for b in range(256))
+    o = order(64, 4)
+    for x in range(8):
+        mine = [o[b] for b in o if (b & 7) == x]
+        assert {s for s, _ in mine} == {x >> 1}                              # one K slice
+        assert {t // 8 for _, t in mine} == set(range(4 * (x & 1), 4 * (x & 1) + 4))    # four whole rows of 8 tiles

@@ -180,7 +180,10 @@ def test_w48_training_step_at_bench_batch_32_vs_oracle():
     L = _lib.lib()
     kinds = [L.egn_conv_config_kind(c) if c > 0 else -9 for (c, _, _, _) in tr.timing]
     print('conv launches of the step: %d, left to the cost model: %d' % (len(kinds), sum(1 for k in kinds if k == -9)))
-    assert sum(1 for k in kinds if k == 1) >= 400, 'the 3x3 s1 forward / data-gradient convs run the Winograd family'
+    n23, n43 = sum(1 for k in kinds if k == 1), sum(1 for k in kinds if k == 3)
+    print('F(2x2,3x3) launches: %d, F(4x4,3x3) launches: %d (EGONET_AMD_TRAIN_F43 = %s)' % (n23, n43, tr.allow_f43))
+    assert n23 + n43 >= 400, 'the 3x3 s1 forward / data-gradient convs run the Winograd families'
+    assert n43 >= (100 if tr.allow_f43 == 'fwd' else 200) or tr.allow_f43 == '0', 'F(4x4,3x3) in the tape [round 5]'
     assert len(chk.wgrad) == 306 and len(chk.dgrad) == 305 and len(chk.bn) >= 300
     worst = chk.worst()
     print('launch-local worst relative errors at B=32:', worst)

@@ -168,6 +168,31 @@ def test_gemm_forward_epilogue_leaves_batchnorm_partial_sums(M, N, K, variant):
                              N, variant, None, 0, st) != 0
 
 
+def test_gemm_epilogue_statistics_with_a_large_column_mean():
+    """[round 5, ADVICE r4] columns whose mean is ~1e3 x their deviation (a large bias): the epilogue accumulates sums
+    and squares in doubles from the first add, so variance / 1/sigma of the finalise stage still agree with the
+    float64 statistics of the stored z (fp32 squares lost several digits of E[x^2] - mean^2 there)."""
+    L = _lib.lib()
+    st = _lib.current_stream()
+    M, N, K = 1024, 128, 64
+    g = torch.Generator().manual_seed(77)
+    A = torch.randn(M, K, generator=g).cuda()
+    B = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    bias = (1000.0 + 50.0 * torch.randn(N, generator=g)).cuda()
+    nrow = L.egn_gemm_stats_rows(M)
+    part = torch.empty((nrow, 2, N), dtype=torch.float64, device='cuda')
+    z = torch.empty(M, N, device='cuda')
+    _lib.check(L.egn_gemm_ex_f32(0, _lib.ptr(A), _lib.ptr(B), _lib.ptr(z), _lib.ptr(bias), None, _lib.ptr(part), nrow,
+                                 M, N, K, K, K, N, 0, None, 0, st))
+    mean, istd, varu = (torch.empty(N, device='cuda') for _ in range(3))
+    _lib.check(L.egn_bn_stats_finalize_f32(_lib.ptr(part), nrow, M, N, 1e-5, _lib.ptr(mean), _lib.ptr(istd), _lib.ptr(varu),
+                                           None, None, 0.1, st))
+    torch.cuda.synchronize()
+    zd = z.double()
+    np.testing.assert_allclose(mean.cpu().numpy(), zd.mean(0).cpu().numpy(), rtol=2e-7)
+    np.testing.assert_allclose(istd.cpu().numpy(), (zd.var(0, unbiased=False) + 1e-5).rsqrt().cpu().numpy(), rtol=1e-5)
+
+
 def test_gemm_data_gradient_epilogue_adds_the_skip_path():
     """egn_gemm_ex_f32(form 1, addend): da = dz W + d_skip in one launch (the residual block's `out = x + y`,
     FCmodel.py:49-51, in the backward); equal to the plain product plus the addend, refused for the other forms."""

@@ -429,6 +429,111 @@ def test_all_filters_packed_in_one_launch_equal_the_single_packs():
     assert pf.pack_all(_st()) is False
 
 
+def test_f43_filters_in_the_one_launch_packer_equal_the_single_packs():
+    """[round 5] descriptor code 4 (+ dgrad): the F(4x4,3x3) filter of conv_wino4.hip packed with all the others
+    (egn_pack_conv_weights_batch_f32) == egn_wino4_pack_weight_f32 == engine.pack_wino4_weight (the host transform the
+    inference engine uses), bit for bit, beside direct and F(2x2,3x3) entries of the same table."""
+    from egonet_amd import engine
+    from egonet_amd.train_hrnet import PackedFilters
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(12)
+    ws = [torch.randn(*s, generator=g).cuda() for s in ((48, 48, 3, 3), (96, 48, 3, 3), (48, 192, 3, 3), (384, 32, 3, 3))]
+    pf = PackedFilters(torch.device('cuda', torch.cuda.current_device()))
+    for w in ws:
+        for dgrad in (0, 1):
+            cout, cin = w.shape[:2]
+            if L.egn_wino4_pack_weight_floats(cout, cin, dgrad) > 0:
+                pf.get(w, dgrad, _st(), wino=3)
+            pf.get(w, dgrad, _st(), wino=True)
+            pf.get(w, dgrad, _st())
+    pf.finalize()
+    for w in ws:
+        w.mul_(0.75).add_(0.125)
+    for _, wp in pf.entries.values():
+        wp.fill_(float('nan'))
+    assert pf.pack_all(_st()) is True
+    n43 = 0
+    for w in ws:
+        cout, cin = w.shape[:2]
+        for dgrad in (0, 1):
+            nfl = L.egn_wino4_pack_weight_floats(cout, cin, dgrad)
+            if nfl <= 0:
+                continue
+            n43 += 1
+            want = torch.full((nfl,), float('nan'), device='cuda')
+            _lib.check(L.egn_wino4_pack_weight_f32(_lib.ptr(w), cout, cin, dgrad, _lib.ptr(want), _st()))
+            got = pf.get(w, dgrad, _st(), wino=3)
+            assert not torch.isnan(got).any() and torch.equal(got, want)
+            if not dgrad:
+                assert torch.equal(got.cpu(), engine.pack_wino4_weight(w.cpu()).reshape(-1))
+            nf2 = L.egn_wino_weight_floats(cout, cin, dgrad)
+            want2 = torch.zeros(nf2, device='cuda')
+            _lib.check(L.egn_wino_pack_weight_f32(_lib.ptr(w), cout, cin, dgrad, _lib.ptr(want2), _st()))
+            assert torch.equal(pf.get(w, dgrad, _st(), wino=True), want2)
+    assert n43 >= 6
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,cfg', [
+    (5, 64, 64, 48, 48, 70),      # 16 x 32 regions, two m-tiles, several items per block
+    (3, 32, 32, 96, 96, 70),      # two co-tiles
+    (7, 16, 16, 192, 192, 80),    # 16 x 16 regions, 16-channel stages, four co-tiles (co-tiles on the XCDs)
+    (6, 16, 16, 96, 48, 84),      # ... K split over two blocks (ticket words)
+    (9, 8, 8, 384, 384, 83),      # four 8 x 8 images per region (the last one partial), K split, eight co-tiles
+    (5, 8, 8, 64, 96, 82),        # ... without the split
+    (700, 16, 16, 32, 48, 80),    # more items than blocks: a block's items share its co-tile
+])
+def test_bn_statistics_fused_into_the_f43_item_end(n, h, w, cin, cout, cfg):
+    """[round 5] conv_wino4s_kernel through egn_conv2d_ex_f32 (partials, ticket words): the conv output bit for bit
+    that of the inference build (egn_conv2d_f32, for the K split its three-launch form), and finalised statistics ==
+    egn_bn_stats_f32 on that output; the ticket words are zero again afterwards."""
+    from egonet_amd import engine
+    L = _lib.lib()
+    st = _lib.current_stream()
+    g = torch.Generator().manual_seed(cfg + n)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    wu = engine.pack_wino4_weight(wt).reshape(-1).cuda()
+    ones, zeros = torch.ones(cout + 16).cuda(), torch.zeros(cout + 16).cuda() + 0.5          # a shift: nonzero means
+    rows = n * h * w
+    dims = (n, h, w, cin, cin, cout, cout, 3, 3, 1, 1)
+    nrows = L.egn_conv2d_bnstats_rows(*dims, cfg)
+    ntk = L.egn_conv2d_ticket_words(*dims, cfg)
+    assert nrows > 0 and (ntk > 0) == (cfg in (83, 84))
+    tickets = torch.zeros(max(ntk, 1) + 3, dtype=torch.int32, device='cuda')
+    part = torch.full((nrows * 2 * cout,), float('nan'), dtype=torch.float64, device='cuda')
+    y1, y2 = torch.empty(n, h, w, cout).cuda(), torch.empty(n, h, w, cout).cuda()
+    for _ in range(2):          # twice: the words are left zero
+        _lib.check(L.egn_conv2d_ex_f32(_lib.ptr(x), _lib.ptr(wu), _lib.ptr(ones), _lib.ptr(zeros), None, _lib.ptr(y1),
+                                       *dims, 0, cfg, _lib.ptr(part), nrows, _lib.ptr(tickets), tickets.numel(), st))
+    _lib.check(L.egn_conv2d_f32(_lib.ptr(x), _lib.ptr(wu), _lib.ptr(ones), _lib.ptr(zeros), None, _lib.ptr(y2),
+                                *dims, 0, 0, cfg, st))
+    assert torch.equal(y1, y2) and not torch.isnan(part).any() and int(tickets.abs().sum()) == 0
+    if ntk > 0:                 # statistics need the one-kernel form; too few words are refused
+        assert L.egn_conv2d_ex_f32(_lib.ptr(x), _lib.ptr(wu), _lib.ptr(ones), _lib.ptr(zeros), None, _lib.ptr(y1),
+                                   *dims, 0, cfg, _lib.ptr(part), nrows, None, 0, st) != 0
+        assert L.egn_conv2d_ex_f32(_lib.ptr(x), _lib.ptr(wu), _lib.ptr(ones), _lib.ptr(zeros), None, _lib.ptr(y1),
+                                   *dims, 0, cfg, None, 0, _lib.ptr(tickets), ntk - 1, st) != 0
+    assert L.egn_conv2d_ex_f32(_lib.ptr(x), _lib.ptr(wu), _lib.ptr(ones), _lib.ptr(zeros), None, _lib.ptr(y1),
+                               *dims, 0, cfg, _lib.ptr(part), nrows - 1, _lib.ptr(tickets), tickets.numel(), st) != 0
+    outs = []
+    for fused in (True, False):
+        mean, istd, varu = (torch.empty(cout).cuda() for _ in range(3))
+        rm, rv = torch.zeros(cout).cuda() + 0.25, torch.ones(cout).cuda()
+        if fused:
+            _lib.check(L.egn_bn_stats_finalize_f32(_lib.ptr(part), nrows, rows, cout, 1e-5, _lib.ptr(mean),
+                                                   _lib.ptr(istd), _lib.ptr(varu), _lib.ptr(rm), _lib.ptr(rv), 0.1, st))
+        else:
+            ws = torch.empty(L.egn_colreduce_ws_bytes(cout) // 4).cuda()
+            _lib.check(L.egn_bn_stats_f32(_lib.ptr(y2), rows, cout, cout, 1e-5, _lib.ptr(mean), _lib.ptr(istd),
+                                          _lib.ptr(varu), _lib.ptr(rm), _lib.ptr(rv), 0.1, _lib.ptr(ws), st))
+        outs.append([t.cpu().numpy() for t in (mean, istd, varu, rm, rv)])
+    z = y2.double().reshape(rows, cout).cpu()
+    np.testing.assert_allclose(outs[0][0], z.mean(0).numpy(), rtol=0, atol=2e-6)
+    np.testing.assert_allclose(outs[0][1], (1.0 / torch.sqrt(z.var(0, unbiased=False) + 1e-5)).numpy(), rtol=2e-5)
+    for a, b in zip(outs[0], outs[1]):
+        np.testing.assert_allclose(a, b, rtol=3e-6, atol=3e-7)
+
+
 def test_bad_arguments_are_refused():
     L = _lib.lib()
     a = torch.zeros(16, device='cuda')

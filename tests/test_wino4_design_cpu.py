@@ -275,6 +275,42 @@ def test_item_orders_visit_every_region_cotile_and_half_once():
                     assert all(seen[(r, c, 0)] == seen[(r, c, 1)] for r in range(nreg) for c in range(nct))
 
 
+def test_every_item_of_a_block_has_the_same_cotile():
+    """conv_wino4s_kernel (the training tape's build, round 5) writes ONE BatchNorm partial row per block that covers one
+    co-tile: with the launcher's grid (w4_grid: whole XCD rounds of (co-tile, K half) up to one block per CU) the items
+    w, w + grid, ... of a block decode to the same co-tile in all three item orders."""
+    def mode(nct):
+        if nct % 8 == 0:
+            return 2
+        return 1 if nct == 4 else 0
+    def count(m, nreg, nct, ks):
+        if m == 2:
+            return nreg * nct * ks
+        if m == 1:
+            return 8 * ((nreg * ks + 8 // nct - 1) // (8 // nct))
+        return ((nreg + 7) >> 3) * nct * ks * 8
+    def cotile(m, w, nct, KS):
+        xq, q = w & 7, w >> 3
+        if m == 0:
+            return (q % (nct * KS)) // KS
+        if m == 1:
+            return xq & (nct - 1)
+        c8 = nct >> 3
+        return (q % c8) * 8 + xq
+    for cus in (256, 304, 64, 8):
+        for nct in (1, 2, 3, 4, 6, 8, 16):
+            for KS in (1, 2):
+                nck = nct * KS
+                for nreg in (1, 5, 16, 64, 512, 2048):
+                    m = mode(nct)
+                    nwork = count(m, nreg, nct, KS)
+                    cap = cus // (8 * nck) * (8 * nck) or 8 * nck
+                    grid = min(nwork, cap)
+                    for b in range(grid):
+                        cts = {cotile(m, w, nct, KS) for w in range(b, nwork, grid)}
+                        assert len(cts) == 1, (cus, nct, KS, nreg, b, cts)
+
+
 def test_ticket_hand_off_of_the_k_split_in_every_interleaving():
     """The protocol of w4_body's K-split item end as a state machine over its atomic steps, run under every schedule of
     the two blocks of a pair: block = draw a ticket (fetch_add on the pair's word); ticket 0 -> store the share, bump the

@@ -50,7 +50,10 @@ def inflight(queue):
 
 # the geometries of the body (GEO 0 / 1 / 2, the last one without and with the K split), product builds
 KERNELS = ('conv_wino4_kernelILi0E', 'conv_wino4b_kernelILi0E', 'conv_wino4bk_kernelILi0E', 'conv_wino4c_kernelILi0ELi1E',
-           'conv_wino4c_kernelILi0ELi2E')
+           'conv_wino4c_kernelILi0ELi2E',
+           # the training tape's builds (BatchNorm statistics in the item end) [round 5]
+           'conv_wino4s_kernelILi0ELi1E', 'conv_wino4s_kernelILi1ELi1E', 'conv_wino4s_kernelILi1ELi2E',
+           'conv_wino4s_kernelILi2ELi1E', 'conv_wino4s_kernelILi2ELi2E')
 
 
 def check(path, kernel='conv_wino4_kernelILi0E'):
