@@ -408,10 +408,11 @@ extern "C" int egn_program_op_info(const egn_program* p, int i, int* kind, doubl
 // kernel launches issued through programs since the library was loaded (egn_launch_count): lets a
 // caller PROVE that a forward ran on this library's kernels and not on some other route
 static std::atomic<long> g_launches{0};
+static thread_local bool t_recording = false;   // this thread is inside egn_program_capture
 extern "C" long egn_launch_count(void) { return g_launches.load(std::memory_order_relaxed); }
 
 static int launch_op(egn_program* p, Op& op, hipStream_t s) {
-  g_launches.fetch_add(1, std::memory_order_relaxed);
+  if (!t_recording) g_launches.fetch_add(1, std::memory_order_relaxed);
   switch (op.kind) {
     case OP_CONV: {
       ConvArgs a = op.conv;
@@ -541,7 +542,9 @@ extern "C" int egn_program_capture(egn_program* p, void* stream) {
       break;
     }
   EGN_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  t_recording = true;      // (recorded, not executed: egn_launch_count counts launches that ran -- replays count themselves)
   int rc = egn_program_run(p, stream);
+  t_recording = false;
   hipGraph_t g = nullptr;
   hipError_t e = hipStreamEndCapture(s, &g);
   if (rc) { if (g) hipGraphDestroy(g); return rc; }

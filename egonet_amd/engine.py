@@ -544,6 +544,8 @@ class HRNetEngine(object):
         self.programs = {}        # (device, N, H, W, decode) -> Program
         self._stamp = _Stamp(model)
         self.lanes = os.environ.get('EGONET_AMD_LANES', '1') != '0'   # branch-level concurrency
+        # batches up to this size replay their program as one hipGraph (_forward_graphed); 0 = never
+        self.graph_max_n = int(os.environ.get('EGONET_AMD_GRAPH_MAX_N', '16'))
         # fuse output i -> branch i of the next module on the same lane, no join in between
         self.chain_regions = os.environ.get('EGONET_AMD_CHAIN', '1') != '0'
 
@@ -749,6 +751,9 @@ class HRNetEngine(object):
         x = x.contiguous()
         with torch.cuda.device(x.device):
             prog = self.program(x, decode_mode, slot)
+            if not timed and x.shape[0] <= self.graph_max_n and not torch.cuda.is_current_stream_capturing():
+                return self._forward_graphed(prog, x, decode_mode)
+            prog.captured = False             # (the bindings below replace the static ones of a captured graph)
             shp = prog.out_shapes
             maps = torch.empty(shp['maps'], dtype=torch.float32, device=x.device)
             prog.bind(SLOT_USER0, x)
@@ -774,6 +779,60 @@ class HRNetEngine(object):
             else:
                 prog.run()
         return outs if dec is None else (outs, dec)
+
+
+    def _forward_graphed(self, prog, x, decode_mode):
+        """Small batches (n <= EGONET_AMD_GRAPH_MAX_N, default 16: BASELINE configs[4]'s per-GPU shard and configs[0]'s
+        single crop) are launch-bound -- ~320 launches of 5-15 us each: from its third run on, a program is replayed as
+        ONE hipGraph (``egn_program_capture``: the launch lanes become graph edges).  Measured on MI355X
+        (profiles/r5_small_batch.txt): 16 crops 5.68 -> 4.89 ms, 4 crops 4.22 -> 3.80, one crop 3.79 -> 3.62, outputs
+        bit-identical.  A captured graph holds addresses, so the program owns static input / output tensors: the
+        caller's crops are copied in (12.6 MB at 16 crops) and the outputs copied out -- the results are fresh tensors
+        as in the eager path.  tools/inference.py:135-199 (the reference's per-image forward) is this regime."""
+        shp = prog.out_shapes
+        st = getattr(prog, 'static', None)
+        if st is None:
+            dev = x.device
+            st = dict(x=torch.empty_like(x), maps=torch.empty(shp['maps'], dtype=torch.float32, device=dev))
+            if 'coords' in shp:
+                st['coords'] = torch.empty(shp['coords'], dtype=torch.float32, device=dev)
+            if decode_mode is not None:
+                n, k = shp['maps'][:2]
+                st['xy'] = torch.empty(n, k, 2, dtype=torch.float32, device=dev)
+                st['mx'] = torch.empty(n, k, 1, dtype=torch.float32, device=dev)
+                st['idx'] = torch.empty(n, k, dtype=torch.int32, device=dev)
+            prog.static, prog.runs, prog.captured = st, 0, False
+        prog.bind(SLOT_USER0, st['x'])            # (same address: a captured graph stays valid)
+        prog.bind(SLOT_USER0 + 1, st['maps'])
+        if 'coords' in st:
+            prog.bind(SLOT_USER0 + 2, st['coords'])
+        if decode_mode is not None:
+            s = shp['decode_slot']
+            prog.bind(s, st['xy'])
+            prog.bind(s + 1, st['mx'])
+            prog.bind(s + 2, st['idx'])
+        st['x'].copy_(x)
+        if prog.captured:
+            prog.replay()
+        else:
+            prog.run()
+            prog.runs += 1
+            if prog.runs >= 2:                    # (short-lived programs -- nn.DataParallel replicas -- never pay a capture)
+                # captured on a stream of its own: the caller's current stream may be the legacy default stream, which
+                # cannot be captured; the graph is then launched on whatever stream is current
+                cur = torch.cuda.current_stream(x.device)
+                cs = torch.cuda.Stream(device=x.device)
+                cs.wait_stream(cur)
+                with torch.cuda.stream(cs):
+                    prog.capture()
+                cur.wait_stream(cs)
+                prog.captured = True
+        outs = st['maps'].clone()
+        if 'coords' in st:
+            outs = (outs, st['coords'].clone())
+        if decode_mode is None:
+            return outs
+        return outs, (st['xy'].clone(), st['mx'].clone(), st['idx'].clone())
 
 
 # ---------------------------------------------------------------------------

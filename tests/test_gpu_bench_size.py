@@ -112,12 +112,20 @@ def test_w48_forward_and_decode_at_bench_batch_64_vs_oracle():
     # a 300-layer network (1e-4 on maps spanning +-20) the index is not defined by the mathematics; such
     # maps must still pick one of the tied maxima, and there may be at most a handful of them -- each one is
     # listed above (and in gpurun_out/parity/argmax_ties_64.json -> profiles/) with the oracle's top-2 gap
+    allowed = {(int(n_), int(k_)) for n_, k_ in _committed_ties(64)}
     for t in ties:
+        assert (t['n'], t['k']) in allowed, 'arg-max mismatch that is not in tests/golden/argmax_ties.json: %s' % t
         assert t['oracle_at_hip_idx'] >= t['oracle_max'] - 1e-4 and t['oracle_top2_gap'] <= 1e-4, t
-    assert len(differ) <= 3, len(differ)
     np.testing.assert_allclose(mx.cpu().numpy(), wmax, rtol=0, atol=5e-4)
     sxy, _ = decode_oracle.soft_arg_max(want)
     np.testing.assert_allclose(xy.cpu().numpy(), sxy, rtol=0, atol=1e-3)
+
+
+def _committed_ties(batch):
+    """[(crop, joint), ...] of tests/golden/argmax_ties.json for this batch size: the ONLY maps whose arg-max index may
+    differ from the oracle's (the allowance is a committed list, not a count)."""
+    with open(os.path.join(ROOT, 'tests', 'golden', 'argmax_ties.json')) as f:
+        return json.load(f).get(str(batch), [])
 
 
 @pytest.mark.parametrize('n', [1, 8, 128])
@@ -148,10 +156,11 @@ def test_w48_forward_at_the_other_baseline_batch_sizes_vs_oracle(n):
     got_idx = idx.cpu().numpy().astype(np.int64)[sel]
     differ = np.argwhere(got_idx != widx)
     flat = want.reshape(len(sel), 33, -1)
-    for i, k in differ:                                   # only where the oracle itself has a tie within fp32 noise
+    allowed = {(int(n_), int(k_)) for n_, k_ in _committed_ties(n)}
+    for i, k in differ:                                   # only committed, tie-justified maps (none recorded so far)
+        assert (int(sel[i]), int(k)) in allowed, 'arg-max mismatch not in tests/golden/argmax_ties.json: %s' % ((n, i, k),)
         top2 = np.sort(flat[i, k])[-2:]
         assert top2[1] - top2[0] <= 1e-4 and flat[i, k, got_idx[i, k]] >= wmax[i, k, 0] - 1e-4, (n, i, k)
-    assert len(differ) <= 1
     print('n = %d: arg-max %d of %d maps exact' % (n, len(sel) * 33 - len(differ), len(sel) * 33))
     sxy, _ = decode_oracle.soft_arg_max(want)
     np.testing.assert_allclose(xy.cpu().numpy()[sel], sxy, rtol=0, atol=1e-3)
@@ -187,6 +196,8 @@ def test_w48_training_step_at_bench_batch_32_vs_oracle():
     assert len(chk.wgrad) == 306 and len(chk.dgrad) == 305 and len(chk.bn) >= 300
     worst = chk.worst()
     print('launch-local worst relative errors at B=32:', worst)
+    for e, shp in sorted(chk.dgrad, key=lambda r: -r[0])[:12]:
+        print('  data gradient %s (n, h, w, cin, cout, k, stride): %.2e' % (shp, e))
     for e, tag, shp, errs in sorted(chk.bn, key=lambda r: -r[0])[:4]:
         print('  BatchNorm %-40s %s  [dz, dbeta, dgamma, dres, mean, istd] = %s' % (tag, shp, ['%.1e' % v for v in errs]))
     assert worst['wgrad'] < 5e-6 and worst['dgrad'] < 2e-5 and worst['bn'] < 5e-6, worst

@@ -431,8 +431,8 @@ def test_all_filters_packed_in_one_launch_equal_the_single_packs():
 
 def test_f43_filters_in_the_one_launch_packer_equal_the_single_packs():
     """[round 5] descriptor code 4 (+ dgrad): the F(4x4,3x3) filter of conv_wino4.hip packed with all the others
-    (egn_pack_conv_weights_batch_f32) == egn_wino4_pack_weight_f32 == engine.pack_wino4_weight (the host transform the
-    inference engine uses), bit for bit, beside direct and F(2x2,3x3) entries of the same table."""
+    (egn_pack_conv_weights_batch_f32) == egn_wino4_pack_weight_f32 bit for bit (and engine.pack_wino4_weight, the host
+    transform the inference engine uses, to the last fp32 bit or two), beside direct and F(2x2,3x3) entries of the same table."""
     from egonet_amd import engine
     from egonet_amd.train_hrnet import PackedFilters
     L = _lib.lib()
@@ -464,8 +464,9 @@ def test_f43_filters_in_the_one_launch_packer_equal_the_single_packs():
             _lib.check(L.egn_wino4_pack_weight_f32(_lib.ptr(w), cout, cin, dgrad, _lib.ptr(want), _st()))
             got = pf.get(w, dgrad, _st(), wino=3)
             assert not torch.isnan(got).any() and torch.equal(got, want)
-            if not dgrad:
-                assert torch.equal(got.cpu(), engine.pack_wino4_weight(w.cpu()).reshape(-1))
+            if not dgrad:       # the host transform (einsum with G in float64) rounds the last bit differently here and there
+                np.testing.assert_allclose(got.cpu().numpy(), engine.pack_wino4_weight(w.cpu()).reshape(-1).numpy(),
+                                           rtol=3e-7, atol=1e-9)
             nf2 = L.egn_wino_weight_floats(cout, cin, dgrad)
             want2 = torch.zeros(nf2, device='cuda')
             _lib.check(L.egn_wino_pack_weight_f32(_lib.ptr(w), cout, cin, dgrad, _lib.ptr(want2), _st()))
