@@ -49,7 +49,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_HBM_GBPS = 8000.0
 # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_r4.sh + tools/pmc_traffic.py), newest first
-TRAFFIC_JSONS = [os.path.join(ROOT, 'profiles', n) for n in ('r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json')]
+TRAFFIC_JSONS = [os.path.join(ROOT, 'profiles', n) for n in ('r5_pmc_traffic.json', 'r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json')]
 WINO_EXECUTED = 16.0 / 36.0       # fused Winograd F(2x2,3x3): multiplies executed per direct-algorithm multiply
 WINO4_EXECUTED = 36.0 / 144.0     # F(4x4,3x3): 36 multiplies per 16 outputs instead of 144
 
@@ -137,8 +137,12 @@ def kernel_tables(prog, ms):
         if meta['kind'] in ('fork', 'join'):
             continue
         cfg = meta.get('cfg', 0)
-        sym = _symbol(cfg, _klass_cout(meta.get('klass'))) if meta['kind'] == 'conv' \
-            else meta['kind'] + '_kernel'
+        if meta['kind'] == 'conv':
+            sym = _symbol(cfg, _klass_cout(meta.get('klass')))
+        elif meta['kind'] == 'pwpair':      # csrc/conv_pw.hip: layer1's 1x1 pair (fused) / its one-product form
+            sym = 'void conv_pw_kernel<%s>(PwArgs)' % ('true' if '->64@' in meta['klass'] else 'false')
+        else:
+            sym = meta['kind'] + '_kernel'
         ex = meta['flops'] * (_executed(cfg) if meta['kind'] == 'conv' else 1.0)
         for table, key in ((by_class, meta['klass']), (by_symbol, sym)):
             a = table.setdefault(key, dict(name=key, kind=meta['kind'], launches=0, ms=0.0, flops=0.0, xflops=0.0,
@@ -340,8 +344,17 @@ def _dominant(timing):
     launches of one step (launches, avg_us, share of the timed launches beside it)."""
     torch.cuda.synchronize()
     by = {}
-    for cfg, flops, e0, e1 in timing:
-        a = by.setdefault(_symbol(cfg) or 'cfg%d' % cfg, [0, 0.0, 0.0, 0.0])
+    stats_sym = {'void conv_wino4_kernel<0>(ConvArgs)': 'void conv_wino4s_kernel<0, 1>(ConvArgs)',
+                 'void conv_wino4b_kernel<0>(ConvArgs)': 'void conv_wino4s_kernel<1, 1>(ConvArgs)',
+                 'void conv_wino4bk_kernel<0>(ConvArgs)': 'void conv_wino4s_kernel<1, 2>(ConvArgs)',
+                 'void conv_wino4c_kernel<0, 1>(ConvArgs)': 'void conv_wino4s_kernel<2, 1>(ConvArgs)',
+                 'void conv_wino4c_kernel<0, 2>(ConvArgs)': 'void conv_wino4s_kernel<2, 2>(ConvArgs)'}
+    for rec in timing:
+        cfg, flops, e0, e1 = rec[:4]
+        sym = _symbol(cfg) or 'cfg%d' % cfg
+        if len(rec) > 4 and rec[4]:          # the training tape's build with BatchNorm statistics in the item end
+            sym = stats_sym.get(sym, sym)
+        a = by.setdefault(sym, [0, 0.0, 0.0, 0.0])
         a[0] += 1
         a[1] += e0.elapsed_time(e1)
         a[2] += flops

@@ -106,6 +106,8 @@ SIGNATURES = {
     'egn_program_add_nchw_to_nhwc': (_i, [_p, Ref, Ref, _i, _i, _i, _i, _i]),
     'egn_program_add_nhwc_to_nchw': (_i, [_p, Ref, Ref, _i, _i, _i, _i, _i]),
     'egn_program_add_pixel_shuffle': (_i, [_p, Ref, Ref, _i, _i, _i, _i, _i, _i]),
+    'egn_program_add_pw_pair': (_i, [_p] + [Ref] * 8 + [_i, _i]),
+    'egn_pw_pair_f32': (_i, [_p] * 8 + [_i, _i, _p]),
     'egn_program_add_ramps': (_i, [_p, Ref, _i, _i, _i, _i, _i]),
     'egn_program_add_decode': (_i, [_p, Ref, _i, _i, _i, _i, _i, Ref, Ref, Ref]),
     'egn_program_fork': (_i, [_p]),

@@ -161,7 +161,7 @@ extern "C" int egn_conv_plan_query(int N, int H, int W, int Cin, int cs_in, int 
 // programs
 // ---------------------------------------------------------------------------
 enum OpKind { OP_CONV = 1, OP_FUSE = 2, OP_NCHW2NHWC = 3, OP_NHWC2NCHW = 4, OP_RAMPS = 5, OP_DECODE = 6,
-              OP_FORK = 7, OP_JOIN = 8, OP_PIXSHUF = 9 };
+              OP_FORK = 7, OP_JOIN = 8, OP_PIXSHUF = 9, OP_PWPAIR = 10 };
 constexpr int kMaxLanes = 4;  // concurrent launch lanes (HRNet has at most 4 branches)
 
 struct Op {
@@ -358,6 +358,25 @@ extern "C" int egn_program_add_decode(egn_program* p, egn_ref hm, int N, int K, 
   return 0;
 }
 
+// layer1's 1x1 pair (conv_pw.hip, egn_pw_pair_f32): out = act(h . w3^T + shift3 (+ res)), hn = relu(out . w1^T + shift1);
+// w1 / shift1 / hn with slot < 0: the first product alone
+extern "C" int egn_program_add_pw_pair(egn_program* p, egn_ref h, egn_ref res, egn_ref w3, egn_ref shift3, egn_ref w1,
+                                       egn_ref shift1, egn_ref out, egn_ref hn, int M, int relu1) {
+  if (!p || M <= 0 || M % 32 || h.slot < 0 || w3.slot < 0 || shift3.slot < 0 || out.slot < 0) return EGN_E_BADARG;
+  if ((w1.slot < 0) != (hn.slot < 0) || (w1.slot >= 0 && shift1.slot < 0)) return EGN_E_BADARG;
+  Op op;
+  op.kind = OP_PWPAIR;
+  op.r[0] = h; op.r[1] = res; op.r[2] = w3; op.r[3] = shift3; op.r[4] = w1; op.r[5] = shift1; op.r[6] = out; op.r[7] = hn;
+  for (int k = 0; k < 8; ++k)
+    if (!ref_ok(p, op.r[k])) return EGN_E_BADARG;
+  op.i[0] = M; op.i[1] = relu1;
+  op.flops = 2.0 * M * 64.0 * 256.0 * (w1.slot >= 0 ? 2.0 : 1.0);
+  op.bytes = 4.0 * M * (64.0 + 256.0 * (res.slot >= 0 ? 2.0 : 1.0) + (w1.slot >= 0 ? 64.0 : 0.0));
+  op.lane = p->cur_lane;
+  p->ops.push_back(op);
+  return 0;
+}
+
 extern "C" int egn_program_fork(egn_program* p) {
   if (!p) return EGN_E_BADARG;
   Op op;
@@ -446,6 +465,11 @@ static int launch_op(egn_program* p, Op& op, hipStream_t s) {
     case OP_RAMPS:
       return egn_fill_coord_ramps_f32((float*)resolve(p, op.r[0]), op.i[0], op.i[1], op.i[2], op.i[3],
                                       op.i[4], s);
+    case OP_PWPAIR:
+      return egn_pw_pair_f32((const float*)resolve(p, op.r[0]), (const float*)resolve(p, op.r[1]),
+                             (const float*)resolve(p, op.r[2]), (const float*)resolve(p, op.r[3]),
+                             (const float*)resolve(p, op.r[4]), (const float*)resolve(p, op.r[5]),
+                             (float*)resolve(p, op.r[6]), (float*)resolve(p, op.r[7]), op.i[0], op.i[1], s);
     case OP_DECODE:
       return egn_decode_heatmaps_f32((const float*)resolve(p, op.r[0]), op.i[0], op.i[1], op.i[2], op.i[3],
                                      op.i[4], (float*)resolve(p, op.r[1]), (float*)resolve(p, op.r[2]),

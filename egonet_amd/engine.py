@@ -142,6 +142,15 @@ def fold_scale_shift(cout, bias=None, bn=None):
     return out_s, out_b
 
 
+def fold_pw(weight, bn):
+    """A 1x1 filter [Cout,Cin,1,1] + eval-mode BatchNorm for csrc/conv_pw.hip: (W' [Cout*Cin] = scale * W, shift [Cout]),
+    float64 arithmetic, one rounding to fp32 -- the kernel's lanes read float4 pieces of the row-major matrix as it lies."""
+    cout, cin = weight.shape[:2]
+    scale, shift = fold_scale_shift(cout, None, bn)
+    w = weight.detach().double().cpu().reshape(cout, cin) * scale[:cout].double()[:, None]
+    return w.float().reshape(-1).contiguous(), shift[:cout].clone()
+
+
 # ---------------------------------------------------------------------------
 # symbolic recording
 # ---------------------------------------------------------------------------
@@ -249,6 +258,24 @@ class _Recorder(object):
         self._touch(y, *[t for t, _ in terms])
         self._push('fuse', dict(y=y, terms=terms, relu=int(relu), tag=tag))
         return y
+
+    def pw_pair(self, h, conv3, bn3, res, relu1, conv1=None, bn1=None, tag=''):
+        """layer1's 1x1 pair as one launch (csrc/conv_pw.hip): out = act(bn3(conv3(h)) (+ res)) [64 -> 256] and, with
+        conv1, hn = relu(bn1(conv1(out))) [256 -> 64].  Returns (out, hn or None)."""
+        assert tuple(conv3.weight.shape) == (256, 64, 1, 1) and h.c == 64 and h.cs == 64, (conv3.weight.shape, h.c, h.cs)
+        out = self.new(h.n, h.h, h.w, 256, name=tag + '.out')
+        w3, s3 = fold_pw(conv3.weight, bn3)
+        op = dict(h=h, res=res, out=out, hn=None, w3=self.weight(w3), shift3=self.weight(s3), w1=None, shift1=None,
+                  relu1=int(relu1), m=h.n * h.h * h.w, tag=tag)
+        hn = None
+        if conv1 is not None:
+            assert tuple(conv1.weight.shape) == (64, 256, 1, 1), conv1.weight.shape
+            hn = self.new(h.n, h.h, h.w, 64, name=tag + '.next')
+            w1, s1 = fold_pw(conv1.weight, bn1)
+            op.update(hn=hn, w1=self.weight(w1), shift1=self.weight(s1))
+        self._touch(h, res, out, hn)
+        self._push('pwpair', op)
+        return out, hn
 
     def nchw_to_nhwc(self, x_ext, n, c, h, w, tag=''):
         y = self.new(n, h, w, c, name=tag)
@@ -440,6 +467,17 @@ class Program(object):
             _lib.check(L.egn_program_add_pixel_shuffle(h, x.ref(), op['y'], x.n, op['c'], x.h, x.w, x.cs, op['up']))
             nbytes = 8.0 * x.n * x.h * x.w * op['c'] * op['up'] ** 2
             klass = 'pixel_shuffle%d %d@%dx%d' % (op['up'], op['c'], x.h, x.w)
+        elif kind == 'pwpair':
+            hb, rb, ob, nb = op['h'], op['res'], op['out'], op['hn']
+            none = NULL_REF
+            _lib.check(L.egn_program_add_pw_pair(h, hb.ref(), rb.ref() if rb is not None else none, op['w3'], op['shift3'],
+                                                 op['w1'] if nb is not None else none,
+                                                 op['shift1'] if nb is not None else none, ob.ref(),
+                                                 nb.ref() if nb is not None else none, op['m'], op['relu1']))
+            flops = 2.0 * op['m'] * 64 * 256 * (2 if nb is not None else 1)
+            nbytes = 4.0 * op['m'] * (64 + 256 * (2 if rb is not None else 1) + (64 if nb is not None else 0))
+            klass = 'pwpair%d%d 64->256%s@%dx%d' % (int(rb is not None), op['relu1'], '->64' if nb is not None else '',
+                                                    hb.h, hb.w)
         elif kind == 'ramps':
             y = op['y']
             _lib.check(L.egn_program_add_ramps(h, y.ref(), y.n, y.h, y.w, y.cs, op['c0']))
@@ -546,6 +584,7 @@ class HRNetEngine(object):
         self.lanes = os.environ.get('EGONET_AMD_LANES', '1') != '0'   # branch-level concurrency
         # batches up to this size replay their program as one hipGraph (_forward_graphed); 0 = never
         self.graph_max_n = int(os.environ.get('EGONET_AMD_GRAPH_MAX_N', '16'))
+        self.fuse_layer1 = os.environ.get('EGONET_AMD_PW_FUSE', '1') != '0'      # layer1's 1x1 pairs on csrc/conv_pw.hip
         # fuse output i -> branch i of the next module on the same lane, no join in between
         self.chain_regions = os.environ.get('EGONET_AMD_CHAIN', '1') != '0'
 
@@ -569,6 +608,46 @@ class HRNetEngine(object):
                 y = r.conv(y, conv.weight, None, bn, ACT_RELU, res, conv.stride[0], conv.padding[0],
                            tag='%s.conv%d' % (tag, i))
         return y
+
+    def _layer1(self, r, x, blocks):
+        """layer1 (hrnet.py:325, 512-529: four Bottlenecks, 64 -> 256 channels).  Where the recorder has ``pw_pair`` (the
+        inference recorder; the training tape walks the blocks layer by layer) each block's conv3 + residual + ReLU and
+        the NEXT block's conv1 + ReLU are ONE launch of csrc/conv_pw.hip, the downsample conv and the last conv3 the same
+        kernel's one-product form: the 256-channel tensor crosses HBM once per direction (EGONET_AMD_PW_FUSE=0: the
+        general conv kernels, one launch per layer)."""
+        def plain():
+            t = x
+            for k, blk in enumerate(blocks):
+                t = self._block(r, t, blk, 'layer1.%d' % k)
+            return t
+
+        def is11(conv, cout, cin):
+            return tuple(conv.weight.shape) == (cout, cin, 1, 1) and conv.stride[0] == 1 and conv.bias is None
+        ok = self.fuse_layer1 and hasattr(r, 'pw_pair') and x.c == 64 and x.cs == 64 and (x.n * x.h * x.w) % 32 == 0 \
+            and len(blocks) >= 1 and all(getattr(b, 'depth', 0) == 3 for b in blocks)
+        if ok:
+            for k, b in enumerate(blocks):
+                ok = ok and is11(b.conv1, 64, 64 if k == 0 else 256) and is11(b.conv3, 256, 64) and \
+                    tuple(b.conv2.weight.shape) == (64, 64, 3, 3) and b.conv2.stride[0] == 1
+                if k == 0:
+                    ok = ok and b.downsample is not None and is11(b.downsample[0], 256, 64)
+                else:
+                    ok = ok and b.downsample is None
+        if not ok:
+            return plain()
+        b0 = blocks[0]
+        h = r.conv(x, b0.conv1.weight, None, b0.bn1, ACT_RELU, None, 1, 0, tag='layer1.0.conv1')
+        t = x
+        for k, b in enumerate(blocks):
+            h = r.conv(h, b.conv2.weight, None, b.bn2, ACT_RELU, None, 1, 1, tag='layer1.%d.conv2' % k)
+            if k == 0:
+                res, _ = r.pw_pair(t, b.downsample[0], b.downsample[1], None, False, tag='layer1.0.downsample')
+            else:
+                res = t
+            nxt = blocks[k + 1] if k + 1 < len(blocks) else None
+            t, h = r.pw_pair(h, b.conv3, b.bn3, res, True, nxt.conv1 if nxt is not None else None,
+                             nxt.bn1 if nxt is not None else None, tag='layer1.%d.conv3' % k)
+        return t
 
     def _unit_chain(self, r, x, seq_of_units, tag):
         """Sequential of Sequential(conv, bn[, relu]) (transition / fuse down paths)."""
@@ -633,8 +712,7 @@ class HRNetEngine(object):
         x = r.nchw_to_nhwc(Ref(SLOT_USER0, 0), n, cin, h, w, tag='input')
         t = r.conv(x, m.conv1.weight, None, m.bn1, ACT_RELU, None, 2, 1, tag='conv1')
         t = r.conv(t, m.conv2.weight, None, m.bn2, ACT_RELU, None, 2, 1, tag='conv2')
-        for k, blk in enumerate(m.layer1):
-            t = self._block(r, t, blk, 'layer1.%d' % k)
+        t = self._layer1(r, t, m.layer1)
         ys = [t]
         for idx in (1, 2, 3):
             trans = getattr(m, 'transition%d' % idx)

@@ -328,7 +328,7 @@ class _Tape(object):
         if tm is not None:
             e1.record(torch.cuda.current_stream(self.dev))
             ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
-            tm.append((cfg, 2.0 * n * ho * wo * cout * cin * kh * kw, e0, e1))
+            tm.append((cfg, 2.0 * n * ho * wo * cout * cin * kh * kw, e0, e1, stats is not None and kind == 3))
         return stats
 
     def _wgrad(self, x, xd, dy, cs_out, weight, stride, pad):

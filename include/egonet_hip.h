@@ -320,6 +320,18 @@ int egn_conv2d_bnstats_f32(const float* x, const float* wpack, const float* ones
                            int Cin, int cs_in, int Cout, int cs_out, int KH, int KW,
                            int stride, int pad, int cfg, double* partials,
                            long partial_rows, void* stream);
+/* [round 5] The 1x1 convolutions around layer1's 256-channel tensor as ONE streaming launch (csrc/conv_pw.hip).
+ * Replaces, for a Bottleneck of libs/model/heatmapModel/hrnet.py:95-133 and the first line of the next one,
+ *     out = relu(bn3(conv3(h)) + residual)    (1x1, 64 -> 256)    and    hn = relu(bn1(conv1(out)))    (1x1, 256 -> 64):
+ *     out[M][256] = act1(h[M][64] . w3^T + shift3 (+ res[M][256])),    hn[M][64] = relu(out . w1^T + shift1)
+ * with the block's tile of `out` kept in LDS between the two products (the 256-channel tensor crosses HBM once per
+ * direction).  w3 [256][64] / w1 [64][256]: the 1x1 filters as torch holds them ([Cout][Cin], row-major) with the
+ * folded BatchNorm scale multiplied in per output channel; shift: the folded shift.  act1 = ReLU if relu1 else none.
+ * w1 = shift1 = hn = NULL: the first product alone (the downsample conv, the last block's conv3).
+ * M = N*H*W pixels, M % 32 == 0; NHWC rows without padding; res != out, h != hn. */
+int egn_pw_pair_f32(const float* h, const float* res, const float* w3, const float* shift3,
+                    const float* w1, const float* shift1, float* out, float* hn, int M,
+                    int relu1, void* stream);
 /* [round 5] egn_conv2d_f32 with the two optional side tables of the native training tape
  * (replaces the MIOpen convolutions under libs/trainer/trainer.py:191-197 for the 3x3 s1 layers of
  * libs/model/heatmapModel/hrnet.py:63-92 on the F(4x4,3x3) kernels):
@@ -542,6 +554,10 @@ int egn_program_run_timed(egn_program* p, void* stream, float* ms, int n_ms);
 /* capture the op sequence into a hipGraph (bindings frozen) / replay it */
 int egn_program_capture(egn_program* p, void* stream);
 int egn_program_replay(egn_program* p, void* stream);
+/* [round 5] layer1's 1x1 pair as one op (egn_pw_pair_f32 below); w1 / shift1 / hn with slot < 0: the first product alone */
+int egn_program_add_pw_pair(egn_program* p, egn_ref h, egn_ref res, egn_ref w3, egn_ref shift3,
+                            egn_ref w1, egn_ref shift1, egn_ref out, egn_ref hn, int M,
+                            int relu1);
 /* number of kernel launches issued through egn_program_run / _run_timed / _replay
  * since the library was loaded (process wide, all devices).  Test hook: a caller
  * can prove that a forward went through this library's kernels. */

@@ -41,6 +41,9 @@ def _symbols(prog):
         if m['kind'] == 'conv':
             out.setdefault(bench._symbol(m['cfg'], bench._klass_cout(m['klass'])), 0)
             out[bench._symbol(m['cfg'], bench._klass_cout(m['klass']))] += 1
+        elif m['kind'] == 'pwpair':       # csrc/conv_pw.hip (layer1's 1x1 pair / its one-product form)
+            sym = 'void conv_pw_kernel<%s>(PwArgs)' % ('true' if '->64@' in m['klass'] else 'false')
+            out[sym] = out.get(sym, 0) + 1
     return out
 
 
@@ -64,7 +67,7 @@ def test_w48_forward_and_decode_at_bench_batch_64_vs_oracle():
     wino = {s: n for s, n in syms.items() if 'wino' in s}
     assert sum(wino.values()) >= 200, syms                         # the 3x3 s1 layers run the Winograd family
     # ... and it is what the committed bench line of this round reports
-    lines = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r4_bench_n1*.json')))
+    lines = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r5_bench_n1*.json')))
     if lines:
         with open(lines[-1]) as f:
             rep = json.load(f)
@@ -187,7 +190,7 @@ def test_w48_training_step_at_bench_batch_32_vs_oracle():
         loss = tr.step(x.cuda(), tgt.cuda(), jt, update=False)
     torch.cuda.synchronize()
     L = _lib.lib()
-    kinds = [L.egn_conv_config_kind(c) if c > 0 else -9 for (c, _, _, _) in tr.timing]
+    kinds = [L.egn_conv_config_kind(t[0]) if t[0] > 0 else -9 for t in tr.timing]
     print('conv launches of the step: %d, left to the cost model: %d' % (len(kinds), sum(1 for k in kinds if k == -9)))
     n23, n43 = sum(1 for k in kinds if k == 1), sum(1 for k in kinds if k == 3)
     print('F(2x2,3x3) launches: %d, F(4x4,3x3) launches: %d (EGONET_AMD_TRAIN_F43 = %s)' % (n23, n43, tr.allow_f43))

@@ -654,3 +654,55 @@ def test_geometry_kernels_vs_fixtures():
     want_in = ((want - stats['mean_in']) / stats['std_in']).astype(np.float32)
     np.testing.assert_allclose(lin.cpu().numpy()[:, :66], want_in, rtol=0, atol=1e-6)
     assert float(lin[:, 66:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('m,fused,use_res,relu1', [
+    (32 * 5, True, True, 1),            # fewer tiles than blocks
+    (32 * 777, True, True, 1),          # several tiles per block, ragged last round
+    (32 * 1201, True, False, 1),        # no residual: the item end only writes
+    (32 * 600, False, False, 0),        # the downsample conv: one product, no residual, no ReLU
+    (32 * 2048, False, True, 1),        # the last block's conv3
+    (64 * 64 * 16, True, True, 1),      # 16 crops of layer1
+])
+def test_pw_pair_kernel(m, fused, use_res, relu1):
+    """[round 5] csrc/conv_pw.hip through egn_pw_pair_f32: layer1's conv3 (+ residual) + ReLU and the next block's conv1 +
+    ReLU (libs/model/heatmapModel/hrnet.py:95-133) against torch's fp32 CPU convolutions + eval-mode BatchNorm; the
+    BatchNorm scales are folded into the filters as the engine does (engine.fold_pw)."""
+    from egonet_amd import _lib, engine
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(m + 7 * fused + use_res)
+    h = torch.randn(m, 64, generator=g)
+    res = torch.randn(m, 256, generator=g) if use_res else None
+    w3 = (torch.rand(256, 64, 1, 1, generator=g) * 2 - 1) / 8 * 1.7
+    w1 = (torch.rand(64, 256, 1, 1, generator=g) * 2 - 1) / 16 * 1.7
+    bn3, bn1 = _bn(256, g), _bn(64, g)
+    with torch.no_grad():
+        want = bn3(F.conv2d(h.t().reshape(1, 64, m, 1), w3)).reshape(256, m).t()
+        if res is not None:
+            want = want + res
+        if relu1:
+            want = F.relu(want)
+        want_n = F.relu(bn1(F.conv2d(want.t().reshape(1, 256, m, 1), w1))).reshape(64, m).t() if fused else None
+    f3, s3 = engine.fold_pw(w3, bn3)
+    f1, s1 = engine.fold_pw(w1, bn1)
+    d = lambda t: None if t is None else t.contiguous().cuda()             # noqa: E731
+    out = torch.full((m, 256), float('nan'), device='cuda')
+    hn = torch.full((m, 64), float('nan'), device='cuda') if fused else None
+    hd, rd, f3d, s3d, f1d, s1d = d(h), d(res), d(f3), d(s3), d(f1), d(s1)
+    for _ in range(2):
+        _lib.check(L.egn_pw_pair_f32(_lib.ptr(hd), _lib.ptr(rd), _lib.ptr(f3d), _lib.ptr(s3d),
+                                     _lib.ptr(f1d) if fused else None, _lib.ptr(s1d) if fused else None, _lib.ptr(out),
+                                     _lib.ptr(hn), m, relu1, _lib.current_stream()), 'pw pair')
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert float((out.cpu() - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    if fused:
+        assert torch.isfinite(hn).all()
+        assert float((hn.cpu() - want_n).abs().max()) < 3e-5 * max(1.0, float(want_n.abs().max()))
+    # refused: ragged M, in-place forms, half a second product
+    assert L.egn_pw_pair_f32(_lib.ptr(hd), None, _lib.ptr(f3d), _lib.ptr(s3d), None, None, _lib.ptr(out), None, m + 8, 1,
+                             _lib.current_stream()) != 0
+    assert L.egn_pw_pair_f32(_lib.ptr(hd), _lib.ptr(out), _lib.ptr(f3d), _lib.ptr(s3d), None, None, _lib.ptr(out), None, m, 1,
+                             _lib.current_stream()) != 0
+    assert L.egn_pw_pair_f32(_lib.ptr(hd), None, _lib.ptr(f3d), _lib.ptr(s3d), _lib.ptr(f1d), _lib.ptr(s1d), _lib.ptr(out),
+                             None, m, 1, _lib.current_stream()) != 0

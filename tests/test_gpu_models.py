@@ -347,6 +347,7 @@ def test_eval_mode_cuda_forward_always_runs_the_hip_program():
     lif = hip_fc.get_fc_model(1, cfg, 10, 12)
     lif.load_state_dict(synth.synth_state_dict(lif.state_dict(), seed=4))
     lif = lif.eval().cuda()
+    lif(torch.randn(9, 10).cuda())          # (shapes outside the shipped table are tuned on first use: programs of their own)
     c0 = L.egn_launch_count()
     y = lif(torch.randn(9, 10).cuda())                      # grad mode on
     assert L.egn_launch_count() - c0 == 6 + 1 and not y.requires_grad      # input relayout + six fused GEMMs
@@ -468,3 +469,25 @@ def test_small_batches_replay_their_program_as_a_hipgraph(head, monkeypatch):
         y4 = net(xs[0])
     l1, l2, l3, l4 = (torch.utils._pytree.tree_leaves(t)[0] for t in (y1, y2, y3, y4))
     assert float((l1 - l2).abs().max()) > 0 and torch.equal(l2, l3) and torch.equal(l3, l4)
+
+
+def test_layer1_on_the_pw_pair_kernel_equals_the_layerwise_program(monkeypatch):
+    """[round 5] engine._layer1: conv3 + residual + ReLU + the next block's conv1 + ReLU as ONE launch of csrc/conv_pw.hip
+    (the downsample conv and the last conv3 its one-product form) against the same engine with EGONET_AMD_PW_FUSE=0
+    (one general conv launch per layer): 3 launches fewer, 5 pw launches, outputs equal to fp32 rounding (the BatchNorm
+    scale is folded into the 1x1 filters instead of applied in the epilogue)."""
+    cfg = configs.w48_config('heatmap')
+    net, sd = _model(cfg, 9)
+    x = synth.synth_crops(2, 3, 256, 256, seed=31).cuda()
+    outs, kinds = [], []
+    for fuse in ('0', '1'):
+        monkeypatch.setenv('EGONET_AMD_PW_FUSE', fuse)
+        net._engine = None
+        eng = net._hip_engine()
+        outs.append(eng.forward(x).cpu())
+        prog = eng.program(x)
+        kinds.append([m['kind'] for m in prog.meta if m['kind'] not in ('fork', 'join')])
+    assert kinds[0].count('pwpair') == 0 and kinds[1].count('pwpair') == 5
+    assert len(kinds[0]) - len(kinds[1]) == 3        # 4 x conv3 + 3 x conv1 -> 3 pairs + the last conv3
+    scale = float(outs[0].abs().max())
+    assert float((outs[0] - outs[1]).abs().max()) < 2e-5 * scale
