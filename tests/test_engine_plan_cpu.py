@@ -48,7 +48,11 @@ def test_program_structure_w48():
     rec, nslots, shapes = _record(configs.w48_config('coordinates'), n=1)
     kinds = [k for k, _ in rec.ops]
     convs = [op for k, op in rec.ops if k == 'conv']
-    assert len(convs) == 306 - 1 + 1          # 306 Conv2d modules: every one is exactly one launch
+    # 306 Conv2d modules: every one is exactly one launch -- except layer1's 1x1 convolutions around the 256-channel
+    # tensor [round 5]: 4 x conv3 + 3 x conv1 + the downsample conv = 8 modules in 5 launches of csrc/conv_pw.hip
+    pws = [op for k, op in rec.ops if k == 'pwpair']
+    assert len(pws) == 5 and sum(2 if op['hn'] is not None else 1 for op in pws) == 8
+    assert len(convs) + 8 == 306
     assert kinds.count('fuse') == 2 + 4 * 3 + 2 * 4 + 1      # one per fuse output of the 8 HR modules
     # branches + fuse outputs of 8 modules = 16 regions; the fuse region of a module runs on into the
     # branches of the next module of its stage (3 times in stage 3, twice in stage 4): 11
@@ -59,6 +63,7 @@ def test_program_structure_w48():
     assert [k for k in kinds16 if k not in ('fork', 'join')] == [k for k in kinds if k not in ('fork', 'join')]
     assert shapes['maps'] == (1, 33, 64, 64) and shapes['coords'] == (1, 33, 2)
     flops = sum(2.0 * op['ho'] * op['wo'] * op['cout'] * op['cin'] * op['kh'] * op['kw'] for op in convs)
+    flops += sum(2.0 * op['m'] * 64 * 256 * (2 if op['hn'] is not None else 1) for op in pws)
     assert abs(flops / 1e9 - 42.035) < 0.02   # GFLOP per crop
     # every lane index stays inside the 4 launch lanes and lanes > 0 only occur inside regions
     inside = False
