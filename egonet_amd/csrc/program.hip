@@ -228,8 +228,17 @@ extern "C" egn_program* egn_program_create(int nslots) {
   return p;
 }
 
+// A captured graph (and the side streams / ticket words of a program) must not be released while a run or replay of
+// the program is still executing: wait for the event its last run recorded.  (Before round 5 programs were only captured
+// by tools and tests that synchronised themselves; the engine now replays small batches as graphs and drops programs
+// whenever the weights change -- right behind an asynchronous replay.)
+static void wait_for_last_run(egn_program* p) {
+  if (p->ev_done && p->ran) hipEventSynchronize(p->ev_done);
+}
+
 extern "C" void egn_program_destroy(egn_program* p) {
   if (!p) return;
+  wait_for_last_run(p);
   if (p->exec) hipGraphExecDestroy(p->exec);
   if (p->graph) hipGraphDestroy(p->graph);
   for (void* d : p->owned) hipFree(d);
@@ -245,6 +254,7 @@ extern "C" void egn_program_destroy(egn_program* p) {
 extern "C" int egn_program_bind(egn_program* p, int slot, void* base) {
   if (!p || slot < 0 || slot >= (int)p->slots.size()) return EGN_E_BADARG;
   if (p->slots[slot] != base && p->exec) {  // a captured graph holds the old addresses
+    wait_for_last_run(p);
     hipGraphExecDestroy(p->exec); p->exec = nullptr;
     hipGraphDestroy(p->graph); p->graph = nullptr;
   }
@@ -557,7 +567,7 @@ extern "C" int egn_program_run_timed(egn_program* p, void* stream, float* ms, in
 extern "C" int egn_program_capture(egn_program* p, void* stream) {
   if (!p) return EGN_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  if (p->exec) { hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+  if (p->exec) { wait_for_last_run(p); hipGraphExecDestroy(p->exec); p->exec = nullptr; }
   if (p->graph) { hipGraphDestroy(p->graph); p->graph = nullptr; }
   for (const Op& op : p->ops)  // side streams / events must exist before the capture starts
     if (op.kind == OP_FORK) {

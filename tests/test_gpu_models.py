@@ -6,6 +6,8 @@
 Bars (BASELINE.json north_star): key-point coordinates and lifted 3D points
 within 1e-3 abs (fp32), heat-map arg-max indices bit exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -421,54 +423,19 @@ def test_program_timing_and_graph_replay():
 
 
 @pytest.mark.parametrize('head', ['heatmap', 'coordinates'])
-def test_small_batches_replay_their_program_as_a_hipgraph(head, monkeypatch):
-    """[round 5] engine.HRNetEngine._forward_graphed: batches of <= EGONET_AMD_GRAPH_MAX_N crops (configs[4]'s 16-crop
-    shard, configs[0]'s single crop: launch-bound) run their program eagerly twice, then replay it as ONE hipGraph with
-    static input / output tensors.  Same bits as the eager engine for every call and every new input, fresh output
-    tensors per call, the launch counter advances by the program's launches (no fallback), a weight change drops the
-    graph with the program, and the default stream (which cannot be captured) is a legal caller."""
-    from egonet_amd import _lib
-    cfg = configs.tiny_config(head)
-    net, sd = _model(cfg, 4)
-    xs = [synth.synth_crops(3, 3, 64, 64, seed=20 + i).cuda() for i in range(5)]
-    monkeypatch.setenv('EGONET_AMD_GRAPH_MAX_N', '0')
-    net._engine = None
-    want = []
-    for x in xs:
-        o = net._hip_engine().forward(x, decode_mode=1)
-        want.append(o)
-    assert not hasattr(net._hip_engine().program(xs[0], 1), 'static')
-    monkeypatch.setenv('EGONET_AMD_GRAPH_MAX_N', '16')
-    net._engine = None
-    eng = net._hip_engine()
-    L = _lib.lib()
-    prev = None
-    for i, x in enumerate(xs):
-        n0 = L.egn_launch_count()
-        got = eng.forward(x, decode_mode=1)              # on the default stream
-        prog = eng.program(x, 1)
-        assert prog.captured == (i >= 1), (i, prog.captured)
-        nk = sum(1 for m in prog.meta if m['kind'] not in ('fork', 'join'))
-        assert L.egn_launch_count() - n0 == nk
-        flat_g = torch.utils._pytree.tree_leaves(got)
-        flat_w = torch.utils._pytree.tree_leaves(want[i])
-        assert len(flat_g) == len(flat_w)
-        for a, b in zip(flat_g, flat_w):
-            assert torch.equal(a, b)
-        if prev is not None:                              # fresh tensors: the previous call's results are untouched
-            for a, b in zip(prev, torch.utils._pytree.tree_leaves(want[i - 1])):
-                assert torch.equal(a, b)
-        prev = flat_g
-    # module forward (the drop-in entry point) takes the same path; a weight change rebuilds program and graph
-    with torch.no_grad():
-        y1 = net(xs[0])
-        first = next(net.parameters())
-        first.mul_(1.25)
-        y2 = net(xs[0])
-        y3 = net(xs[0])
-        y4 = net(xs[0])
-    l1, l2, l3, l4 = (torch.utils._pytree.tree_leaves(t)[0] for t in (y1, y2, y3, y4))
-    assert float((l1 - l2).abs().max()) > 0 and torch.equal(l2, l3) and torch.equal(l3, l4)
+def test_small_batches_replay_their_program_as_a_hipgraph(head):
+    """[round 5] engine.HRNetEngine._forward_graphed (opt-in: EGONET_AMD_GRAPH_MAX_N=<n>): batches of up to n crops run
+    their program eagerly twice, then replay it as ONE hipGraph with static input / output tensors.  The case itself is
+    tests/graph_case.py; it runs in a process of its own: inside the whole suite ``hipGraphLaunch`` crashed the
+    interpreter (host segmentation fault in the runtime, reproducibly after tests/test_gpu_autograd.py had run in the
+    same process, never alone or after any other module: profiles/r5_graph_replay_crash.txt) -- which is also why the
+    feature is off by default."""
+    import subprocess
+    import sys
+    env = dict(os.environ, EGONET_AMD_GRAPH_MAX_N='16')
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'graph_case.py'), head],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and 'graph case ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_layer1_on_the_pw_pair_kernel_equals_the_layerwise_program(monkeypatch):
