@@ -28,6 +28,9 @@ bool egn_conv_wino4_applies(const ConvArgs& a, int geo);
 size_t egn_conv_wino4_lds_bytes(int geo);
 int egn_conv_wino4_tickets(const ConvArgs& a, int geo);
 int egn_conv_wino4_stats_rows(const ConvArgs& a, int geo);
+int egn_conv_launch_s2r(const ConvArgs& a, hipStream_t stream);                         // conv_s2r.hip
+bool egn_conv_s2r_applies(const ConvArgs& a);
+size_t egn_conv_s2r_lds_bytes();
 int egn_conv_launch_fc(const ConvArgs& a, hipStream_t stream);                          // conv_fc.hip
 bool egn_conv_fc_applies(const ConvArgs& a);
 size_t egn_conv_wino_lds_bytes(int variant, int cout);
@@ -121,6 +124,7 @@ static const ConvConfig kConfigs[] = {
     {82, 12, 1, 1, 3, 2, 0, 7},    // conv_wino4c_kernel<0, 1>: F(4x4,3x3) on 8 x 8 maps, four images per region (ai = geometry 2); filter kind 3
     {83, 12, 1, 1, 3, 6, 0, 7},    // conv_wino4c_kernel<0, 2>: 82 with the input channels of an item split over two blocks (ai bit 2): memset, atomic adds, conv_wino4_finish_kernel
     {84, 12, 1, 1, 3, 5, 0, 7},    // conv_wino4bk_kernel: 80 with the input channels of an item split over two blocks (ai bit 2), as 83
+    {85, 3, 1, 1, 3, 0, 0, 9},     // conv_s2r_kernel [round 5]: 3x3 stride 2 from the 48-channel branch, filter slice in registers (conv_s2r.hip); direct-packed filter
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -177,6 +181,7 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   if (c.dma == 7 && (c.ai & 3) == 2) { snprintf(buf, len, "void conv_wino4c_kernel<%d, %d>(ConvArgs)", c.bi, (c.ai & 4) ? 2 : 1); return 0; }
   if (c.dma == 7) { snprintf(buf, len, "void conv_wino4%s_kernel<%d>(ConvArgs)", c.ai == 5 ? "bk" : (c.ai ? "b" : ""), c.bi); return 0; }
   if (c.dma == 8) { snprintf(buf, len, "conv_fc_kernel(ConvArgs)"); return 0; }
+  if (c.dma == 9) { snprintf(buf, len, "conv_s2r_kernel(ConvArgs)"); return 0; }
   if (c.dma == 5 && (c.bi & 15) == 10) { snprintf(buf, len, "void conv_wino43_kernel<0>(ConvArgs)"); return 0; }
   if (c.dma == 5 && ((c.bi & 15) == 11 || (c.bi & 15) == 12)) {
     snprintf(buf, len, "void conv_wino9_kernel<%s, 4, 3, 0, 2>(ConvArgs)", (c.bi & 15) == 11 ? "8, 16, 1" : "8, 8, 2");
@@ -224,6 +229,7 @@ static size_t lds_bytes_for(const ConvArgs& a, const ConvConfig& cf) {
   if (cf.dma == 6) return egn_conv_stem_lds_bytes();
   if (cf.dma == 7) return egn_conv_wino4_lds_bytes(cf.ai);
   if (cf.dma == 8) return 0;
+  if (cf.dma == 9) return egn_conv_s2r_lds_bytes();
   if (cf.dma == 5) return egn_conv_wino_lds_bytes(cf.bi, a.Cout);
   if (cf.dma == 4 && cf.bi == 2) return (size_t)(3 * 336 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // chunk ring + filter
   if (cf.dma == 4) return (size_t)(2 * 3 * 192 * EGN_CKQ + 3 * 9 * EGN_CKQ * 48) * 16;  // 2 halo buffers + filter
@@ -253,6 +259,16 @@ static bool plan_tile(ConvArgs& a, const ConvConfig& cf, size_t lds_budget, doub
     a.npix = 16; a.npixp = 16; a.tps = 1;
     a.tiles_x = 1;
     a.tiles_y = 1;
+    if (cost_out) *cost_out = 0.0;
+    return true;
+  }
+  if (cf.dma == 9) {
+    // conv_s2r.hip: 2 x 8 output pixels per tile, 48-channel co-groups
+    if (!egn_conv_s2r_applies(a)) return false;
+    a.TH = 2; a.TW = 8; a.TNB = 1; a.HH = 5; a.HW = 17;
+    a.npix = a.HH * a.HW; a.npixp = (a.npix + 15) & ~15; a.tps = 9;
+    a.tiles_x = a.Wo / a.TW;
+    a.tiles_y = a.Ho / a.TH;
     if (cost_out) *cost_out = 0.0;
     return true;
   }
@@ -433,6 +449,7 @@ int egn_conv_launch(const ConvArgs& a, int cfg_id, hipStream_t stream) {
   if (cf.dma == 6) return egn_conv_launch_stem(a, lds, stream);
   if (cf.dma == 7) return egn_conv_launch_wino4(a, lds, cf.bi, cf.ai, stream);
   if (cf.dma == 8) return egn_conv_launch_fc(a, stream);
+  if (cf.dma == 9) return egn_conv_launch_s2r(a, stream);
   if (cf.dma == 5) return egn_conv_launch_wino(a, lds, cf.bi, stream);
   if (cf.dma == 4) return egn_conv_launch_c48(a, lds, cf.bi == 2 ? -1 : cf.bi == 1 ? 0 : cf.wm, stream);
   if (cf.dma == 3) return EGN_E_BADARG;

@@ -706,3 +706,28 @@ def test_pw_pair_kernel(m, fused, use_res, relu1):
                              _lib.current_stream()) != 0
     assert L.egn_pw_pair_f32(_lib.ptr(hd), None, _lib.ptr(f3d), _lib.ptr(s3d), _lib.ptr(f1d), _lib.ptr(s1d), _lib.ptr(out),
                              None, m, 1, _lib.current_stream()) != 0
+
+
+@pytest.mark.parametrize('n,h,w,cout,act', [
+    (2, 64, 64, 48, 1),          # 48 -> 48 @ 32 x 32 (fuse down path, first step)
+    (2, 64, 64, 96, 0),          # 48 -> 96 @ 32 x 32 (last step of a chain: no ReLU), two co-groups
+    (3, 32, 32, 192, 1),         # 48 -> 192 @ 16 x 16
+    (5, 16, 16, 384, 0),         # 48 -> 384 @ 8 x 8: more co-groups than a tile row, odd batch
+    (1, 4, 16, 48, 1),           # one tile: every tap row / column touches the border
+    (70, 16, 32, 96, 1),         # more items than blocks
+])
+def test_conv_s2r_kernel(n, h, w, cout, act):
+    """[round 5] csrc/conv_s2r.hip (cfg 85): 3x3 stride-2 convolution from the 48-channel branch with the filter slice in
+    registers and the im2col gather by LDS-DMA, through egn_conv2d_f32 with the direct-packed filter, against torch's fp32
+    CPU conv + eval-mode BatchNorm (+ ReLU); refused where it does not apply."""
+    import ctypes as C
+    from egonet_amd import _lib
+    L = _lib.lib()
+    out = (C.c_int * 12)()
+    assert L.egn_conv_config_kind(85) == 0
+    assert L.egn_conv_plan_query(n, h, w, 48, 48, cout, cout, 3, 3, 2, 1, 0, 85, out) == 0
+    err = _conv_case(n, h, w, 48, cout, 3, 2, 1, act=act, cfg=85, seed=cout + n)
+    assert err < 2e-4, err
+    for bad in ((n, h, w, 96, 96, cout, cout, 3, 3, 2, 1), (n, h, w, 48, 48, cout, cout, 3, 3, 1, 1),
+                (n, h, w, 48, 48, 64, 64, 3, 3, 2, 1), (n, h, 12, 48, 48, cout, cout, 3, 3, 2, 1)):
+        assert L.egn_conv_plan_query(*bad, 0, 85, out) != 0

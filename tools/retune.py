@@ -32,7 +32,7 @@ def main():
     changed = 0
     for key in sorted(table):
         m = KEY.match(key)
-        if not m or a.match not in key:
+        if not m or not all(part in key for part in a.match.split(',')):      # (--match a,b: every part)
             continue
         args = tuple(int(v) for v in m.groups())
         again = {int(v) for v in a.retime.split(',') if v}
