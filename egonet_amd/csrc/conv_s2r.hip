@@ -21,6 +21,9 @@
 //     the others' MFMAs (EGN_S2R_BPC=<1..5>: fewer, for A/B runs);
 //   * epilogue straight from the accumulators: acc * scale + shift, ReLU or none, dword stores (16 lanes = 64 contiguous
 //     bytes of a pixel).
+// Measured (profiles/r5_s2r_probe*.txt, r5_retune_s2r.log): 48 -> 48 @ 32 x 32 at 64 crops 55 -> 33-38 us, 48 -> 96 70 -> 57-61, one
+// crop 23 -> 12 us; 4 or 5 blocks per CU are equally fast; TWO co-groups per block sharing one gathered tile (6 waves, half
+// the gather traffic) is 12-17 % SLOWER -- what counts is the number of independent blocks, not the gather bytes.
 // Applies to: 3x3, stride 2, pad 1, Cin == 48 (unpadded), Cout % 48 == 0 (unpadded), even input maps, Wo % 8 == 0,
 // Ho % 2 == 0, NHWC output, no residual, activation none / ReLU.  Filter kind 0 (egn_pack_conv_weight_f32).
 #include <stdlib.h>

@@ -114,6 +114,7 @@ CONV_CASES = [
     (44, (64, 64, 64, 48, 48, 3, 1, 1), True),       # conv_c48t_kernel (filter resident, chunk ring)
     (42, (64, 64, 64, 48, 48, 3, 1, 1), True),       # conv_c48_kernel<8>
     (64, (64, 256, 256, 3, 64, 3, 2, 1), False),     # conv_stem_kernel
+    (85, (64, 64, 64, 48, 96, 3, 2, 1), False),      # conv_s2r_kernel [round 5] (gathering LDS-DMA, vmcnt(0) only)
 ]
 
 
@@ -234,5 +235,35 @@ def test_gemm_kernels_are_bit_identical_beside_two_busy_streams(form):
                                   _lib.ptr(ws), need, st), 'gemm')
     bad, overlapped, checks = _stress(launch, Cm, _Hogs('conv'))
     print('gemm form %d: %d of %d repetitions differ; side streams busy at %d of %d checkpoints' % (form, bad, REPS, overlapped, checks))
+    assert overlapped >= checks // 2
+    assert bad == 0, bad
+
+
+@pytest.mark.parametrize('fused,use_res', [(True, True), (False, True), (False, False)])
+def test_pw_pair_is_bit_identical_beside_two_busy_streams(fused, use_res):
+    """[round 5] conv_pw_kernel (layer1's 1x1 pair, csrc/conv_pw.hip: LDS-DMA into the tile it later rewrites in place,
+    vmcnt(0) waits only) at 64 crops: 50 repetitions beside the bandwidth hog and the MFMA hog, both outputs checked."""
+    L = _lib.lib()
+    m = 64 * 64 * 64
+    g = torch.Generator().manual_seed(17 + fused + 2 * use_res)
+    h = torch.randn(m, 64, generator=g).cuda()
+    res = torch.randn(m, 256, generator=g).cuda() if use_res else None
+    w3 = (torch.randn(256 * 64, generator=g) / 8).cuda()
+    w1 = (torch.randn(64 * 256, generator=g) / 16).cuda()
+    s3, s1 = torch.randn(256, generator=g).cuda(), torch.randn(64, generator=g).cuda()
+    # one tensor for both outputs so that _stress compares them together: [m, 256 + 64]
+    both = torch.empty(m * 320, device='cuda')
+    out, hn = both[:m * 256], both[m * 256:]
+    st = _lib.current_stream()
+
+    def launch():
+        _lib.check(L.egn_pw_pair_f32(_lib.ptr(h), _lib.ptr(res), _lib.ptr(w3), _lib.ptr(s3), _lib.ptr(w1) if fused else None,
+                                     _lib.ptr(s1) if fused else None, _lib.ptr(out), _lib.ptr(hn) if fused else None, m, 1,
+                                     st), 'pw pair')
+        if not fused:
+            hn.zero_()
+    bad, overlapped, checks = _stress(launch, both, _Hogs('conv'))
+    print('pw pair fused=%s res=%s: %d of %d repetitions differ; side streams busy at %d of %d checkpoints'
+          % (fused, use_res, bad, REPS, overlapped, checks))
     assert overlapped >= checks // 2
     assert bad == 0, bad
