@@ -627,6 +627,7 @@ class HRNetEngine(object):
         def is11(conv, cout, cin):
             return tuple(conv.weight.shape) == (cout, cin, 1, 1) and conv.stride[0] == 1 and conv.bias is None
         ok = self.fuse_layer1 and hasattr(r, 'pw_pair') and x.c == 64 and x.cs == 64 and (x.n * x.h * x.w) % 32 == 0 \
+            and x.n * x.h * x.w * 256 * 4 < 2 ** 31 \
             and len(blocks) >= 1 and all(getattr(b, 'depth', 0) == 3 for b in blocks)
         if ok:
             for k, b in enumerate(blocks):
