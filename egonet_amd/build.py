@@ -34,6 +34,37 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _compile_objects(hipcc, flags, probes, force, verbose):
+    """One object per source under csrc/_obj/ (git-ignored), rebuilt when the source, any header or the flags are
+    newer -- the sources are independent translation units, so a one-file edit costs one compile; up to 8 at once."""
+    from concurrent.futures import ThreadPoolExecutor
+    odir = os.path.join(CSRC, '_obj', 'probes' if probes else 'product')
+    os.makedirs(odir, exist_ok=True)
+    hdrs = glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(os.path.dirname(HERE), 'include', 'egonet_hip.h')]
+    th = max(os.path.getmtime(h) for h in hdrs)
+    stamp = os.path.join(odir, 'flags.txt')
+    flag_text = ' '.join([hipcc] + flags)
+    if not os.path.isfile(stamp) or open(stamp).read() != flag_text:
+        force = True
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(odir, os.path.basename(src) + '.o')
+        objs.append(obj)
+        if force or not os.path.isfile(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), th):
+            jobs.append([hipcc] + flags + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    workers = int(os.environ.get('EGONET_AMD_BUILD_JOBS', '8'))
+    with ThreadPoolExecutor(max_workers=max(1, workers)) as ex:
+        list(ex.map(run, jobs))
+    with open(stamp, 'w') as f:
+        f.write(flag_text)
+    return objs
+
+
 PROBES_OUT = os.path.join(os.path.dirname(HERE), 'tools', '_build', 'libegonet_hip_probes.so')
 
 
@@ -51,9 +82,10 @@ def build(force=False, verbose=True, probes=False):
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     tmp = out + '.tmp'
-    cmd = [hipcc, '--offload-arch=' + ARCH, '-O3', '-std=c++17', '-shared', '-fPIC',
-           '-Wno-unused-result', '-Wno-unused-value', '-Wno-inline-asm'] + (['-DEGN_PROBES'] if probes else []) + \
-        ['-o', tmp] + sources()
+    flags = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result', '-Wno-unused-value',
+             '-Wno-inline-asm'] + (['-DEGN_PROBES'] if probes else [])
+    objs = _compile_objects(hipcc, flags, probes, force, verbose)
+    cmd = [hipcc, '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', tmp] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     try:

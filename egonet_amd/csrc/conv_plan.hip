@@ -125,6 +125,8 @@ static const ConvConfig kConfigs[] = {
     {83, 12, 1, 1, 3, 6, 0, 7},    // conv_wino4c_kernel<0, 2>: 82 with the input channels of an item split over two blocks (ai bit 2): memset, atomic adds, conv_wino4_finish_kernel
     {84, 12, 1, 1, 3, 5, 0, 7},    // conv_wino4bk_kernel: 80 with the input channels of an item split over two blocks (ai bit 2), as 83
     {85, 3, 1, 1, 3, 0, 0, 9},     // conv_s2r_kernel [round 5]: 3x3 stride 2 from the 48-channel branch, filter slice in registers (conv_s2r.hip); direct-packed filter
+    {86, 12, 1, 1, 3, 9, 0, 7},    // conv_wino4w_kernel [round 6]: F(4x4,3x3), 16 x 16 pixel regions x 96 output channels per item (ai bit 3; conv_wino4w.hip); filter kind 3
+    {87, 12, 1, 1, 3, 9, 64, 7},   // 86 with s_memtime stamps (tools/wino4_clk.py)
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -179,6 +181,7 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 6) { snprintf(buf, len, "conv_stem_kernel(ConvArgs)"); return 0; }
   if (c.dma == 7 && (c.ai & 3) == 2) { snprintf(buf, len, "void conv_wino4c_kernel<%d, %d>(ConvArgs)", c.bi, (c.ai & 4) ? 2 : 1); return 0; }
+  if (c.dma == 7 && c.ai == 9) { snprintf(buf, len, "void conv_wino4w_kernel<%d>(ConvArgs)", c.bi); return 0; }
   if (c.dma == 7) { snprintf(buf, len, "void conv_wino4%s_kernel<%d>(ConvArgs)", c.ai == 5 ? "bk" : (c.ai ? "b" : ""), c.bi); return 0; }
   if (c.dma == 8) { snprintf(buf, len, "conv_fc_kernel(ConvArgs)"); return 0; }
   if (c.dma == 9) { snprintf(buf, len, "conv_s2r_kernel(ConvArgs)"); return 0; }

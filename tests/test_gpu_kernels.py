@@ -279,6 +279,49 @@ def test_conv_wino4b_kernel(n, h, w, cin, cout, res, act):
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout,res,act', [
+    (2, 16, 16, 32, 96, True, 1),       # one region per image, 2 stages, one co-tile pair
+    (64, 32, 32, 96, 96, True, 1),      # the 96-channel branch at BASELINE's 64 crops: 256 items, 6 stages
+    (3, 16, 16, 192, 192, True, 1),     # two co-tile pairs, 12 stages
+    (3, 32, 48, 48, 96, False, 0),      # 2 x 3 regions, 3 stages (odd: pair loop + tail), no activation, no residual
+    (70, 16, 16, 48, 192, True, 1),     # more items than one round of persistent blocks; pairs on the item axis
+    (5, 32, 32, 96, 384, False, 1),     # four co-tile pairs (item mode 1: pairs on the XCD axis), odd batch
+    (2, 16, 32, 32, 768, True, 1),      # eight co-tile pairs (item mode 2)
+])
+def test_conv_wino4w_kernel(n, h, w, cin, cout, res, act):
+    """Config 86, conv_wino4w_kernel (csrc/conv_wino4w.hip, round 6): F(4x4,3x3) on 16 x 16 pixel regions with 96 output
+    channels (two co-tiles of the same filter pack) per item -- half the input transforms, halo bytes and barriers per
+    MFMA of config 80.  The arithmetic per output is config 80's (same transform, same K order, same item end):
+    bit-identical to it; oracle and tolerance as config 70 (hrnet.py:68-92 at 96 channels)."""
+    import ctypes as C
+    from egonet_amd import _lib, ops
+    L = _lib.lib()
+    assert L.egn_conv_config_kind(86) == 3 and L.egn_conv_config_kind(87) == -1
+    out = (C.c_int * 12)()
+    assert L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, 86, out) == 0
+    assert list(out)[5:8] == [16, 16, 1] and out[10] == n * (h // 16) * (w // 16)
+    err = _conv_case(n, h, w, cin, cout, 3, 1, 1, act=act, use_res=res, cfg=86, seed=n + h + cin)
+    assert err < 5e-4, err
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    pc = ops.PackedConv(wt, None, _bn(cout, g), kind=3)
+    r = torch.randn(n, h, w, cout, generator=g).cuda() if res else None
+    ya = ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=86)
+    yb = ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=80)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+    # refused: Cout not a multiple of 96, a single 16-channel stage, maps that are not whole 16 x 16 regions, stride 2
+    assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 48, 48, 3, 3, 1, 1, 0, 86, out) != 0
+    assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 144, 144, 3, 3, 1, 1, 0, 86, out) != 0
+    assert L.egn_conv_plan_query(2, 16, 16, 16, 16, 96, 96, 3, 3, 1, 1, 0, 86, out) != 0
+    assert L.egn_conv_plan_query(2, 8, 8, 96, 96, 96, 96, 3, 3, 1, 1, 0, 86, out) != 0
+    assert L.egn_conv_plan_query(2, 32, 32, 96, 96, 96, 96, 3, 3, 2, 1, 0, 86, out) != 0
+    # no training build, no K split: no statistics rows, no ticket words
+    assert L.egn_conv2d_bnstats_rows(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 86) == 0
+    assert L.egn_conv2d_ticket_words(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 86) == 0
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,res,act', [
     (2, 16, 16, 32, 48, True, 1),       # one stage per half
     (3, 16, 16, 192, 192, True, 1),     # the 16 x 16 maps of the 192-channel branch at a small batch: 6 stages per half
     (16, 16, 16, 192, 192, True, 1),    # BASELINE configs[4]'s per-GPU shard: 64 regions x 4 co-tiles x 2 halves

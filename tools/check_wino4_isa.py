@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Static check of conv_wino4_kernel's compiled ISA (csrc/conv_wino4.hip).
+"""Static check of the F(4x4,3x3) kernels' compiled ISA (csrc/conv_wino4.hip, csrc/conv_wino4w.hip).
 
 The kernel loads its MFMA B operands (the transformed filter) with raw `buffer_load_dword` instructions and
 waits for them with hand-counted `s_waitcnt vmcnt(N)`: the compiler does not know that the destination
@@ -20,9 +20,9 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def compile_isa():
-    src = os.path.join(ROOT, 'egonet_amd', 'csrc', 'conv_wino4.hip')
-    out = os.path.join(tempfile.mkdtemp(prefix='w4isa'), 'conv_wino4.s')
+def compile_isa(name='conv_wino4'):
+    src = os.path.join(ROOT, 'egonet_amd', 'csrc', name + '.hip')
+    out = os.path.join(tempfile.mkdtemp(prefix='w4isa'), name + '.s')
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-c', '-S', '--cuda-device-only', '-o', out, src],
                    check=True, stderr=subprocess.DEVNULL)
@@ -54,6 +54,11 @@ KERNELS = ('conv_wino4_kernelILi0E', 'conv_wino4b_kernelILi0E', 'conv_wino4bk_ke
            # the training tape's builds (BatchNorm statistics in the item end) [round 5]
            'conv_wino4s_kernelILi0ELi1E', 'conv_wino4s_kernelILi1ELi1E', 'conv_wino4s_kernelILi1ELi2E',
            'conv_wino4s_kernelILi2ELi1E', 'conv_wino4s_kernelILi2ELi2E')
+
+
+# conv_wino4w.hip [round 6]: 96 output channels per item
+KERNELS_W = ('conv_wino4w_kernelILi0E',)
+FILES = (('conv_wino4', KERNELS), ('conv_wino4w', KERNELS_W))
 
 
 def check(path, kernel='conv_wino4_kernelILi0E'):
@@ -111,12 +116,15 @@ def check(path, kernel='conv_wino4_kernelILi0E'):
 
 
 if __name__ == '__main__':
-    path = sys.argv[1] if len(sys.argv) > 1 else compile_isa()
     bad = 0
-    for kern in KERNELS:
-        problems, nload, nwait = check(path, kern)
-        print('%s: %d filter / residual loads, %d vmcnt waits, %d problems' % (kern, nload, nwait, len(problems)))
-        for p in problems[:40]:
-            print('  ' + p)
-        bad += len(problems)
+    for name, kernels in FILES:
+        if len(sys.argv) > 1 and os.path.splitext(os.path.basename(sys.argv[1]))[0] != name:
+            continue
+        path = sys.argv[1] if len(sys.argv) > 1 else compile_isa(name)
+        for kern in kernels:
+            problems, nload, nwait = check(path, kern)
+            print('%s: %d filter / residual loads, %d vmcnt waits, %d problems' % (kern, nload, nwait, len(problems)))
+            for p in problems[:40]:
+                print('  ' + p)
+            bad += len(problems)
     sys.exit(1 if bad else 0)

@@ -2,7 +2,7 @@
 """Timeline of conv_wino4_kernel (cfg 78 = cfg 70 built with s_memtime stamps): cycles between the stamps of a
 stage / an item, median over blocks and waves, per third of the waves (the thirds transform at different points).
 
-    python tools/wino4_clk.py [N,H,W,Cin,Cout ...]
+    python tools/wino4_clk.py [--cfg=78|87] [N,H,W,Cin,Cout ...]      (87: conv_wino4w_kernel, 96 output channels per item)
 """
 import os
 import sys
@@ -17,6 +17,11 @@ NTK, NW = 96, 12
 STAGE = ['filter k-group 2s landed', 'issue loads / pieces (+ transform, third 0)', 'multiply g = 0',
          'filter k-group 2s+1 landed', 'issue loads (+ transform third 1), multiply g = 1 (+ transform third 2)',
          'own pieces landed, V written', 'barrier']
+
+
+STAGE_W = ['filter k-group 4s landed', '(transform third 0 +) load k-group 4s+1', 'multiply k-group 0',
+           'filter k-group 4s+1 landed', '(transform third 1 +) load, multiply k-group 1', 'wait, load, multiply k-group 2',
+           'wait (+ transform third 2), load, halo pieces, multiply k-group 3', 'own pieces landed, V written', 'barrier']
 
 
 def run(shape, cfg=78):
@@ -45,8 +50,12 @@ def run(shape, cfg=78):
     us = e0.elapsed_time(e1) * 100.0
     t = stamps.cpu().numpy().view(np.uint64).reshape(nblk, NW * NTK + 1)
     nt = int(t[0, 0])
-    S = cin // 8
-    per_item = 5 + 7 * S + 1 + 8
+    wide = cfg == 87                 # conv_wino4w_kernel: 16-channel stages of four k-groups, 9 stamps per stage
+    NS = 9 if wide else 7
+    stage_names = STAGE_W if wide else STAGE
+    mfma_issue = 6912 if wide else 3456
+    S = cin // (16 if wide else 8)
+    per_item = 5 + NS * S + 1 + 8
     tk = t[:, 1:].reshape(nblk, NW, NTK).astype(np.int64)
     print('shape %s: %d stamps per wave, %d stages per item, %d stamps per item; launch %.1f us' % (shape, nt, S, per_item, us))
     if nt < 1 + per_item:
@@ -61,16 +70,16 @@ def run(shape, cfg=78):
         ws = slice(4 * third, 4 * third + 4)
         print('  waves %d..%d (transform third %d):' % (4 * third, 4 * third + 3, third))
         prev = tk[:, ws, ks]
-        tot = np.zeros(7)
+        tot = np.zeros(NS)
         for s in range(S):
-            for k in range(7):
-                cur = tk[:, ws, ks + 1 + 7 * s + k]
+            for k in range(NS):
+                cur = tk[:, ws, ks + 1 + NS * s + k]
                 tot[k] += med(cur - prev)
                 prev = cur
-        for k in range(7):
-            print('    stage     %-72s %7.0f' % (STAGE[k], tot[k] / S))
-        print('    stage total %.0f cycles   [MFMA issue of the SIMD\'s three waves: 3456]' % (tot.sum() / S))
-    ke = ks + 7 * S + 1      # "K loop done"
+        for k in range(NS):
+            print('    stage     %-72s %7.0f' % (stage_names[k], tot[k] / S))
+        print('    stage total %.0f cycles   [MFMA issue of the SIMD\'s three waves: %d]' % (tot.sum() / S, mfma_issue))
+    ke = ks + NS * S + 1      # "K loop done"
     print('  K loop: %.0f cycles' % med(tk[:, :, ke] - tk[:, :, ks]))
     names = ['round 0: accumulators written', 'exchange barrier', 'output transform, stores issued', 'barrier',
              'round 1: accumulators written', 'exchange barrier', 'output transform, stores issued', 'barrier']
@@ -80,7 +89,11 @@ def run(shape, cfg=78):
 
 
 if __name__ == '__main__':
-    shapes = [tuple(int(v) for v in s.split(',')) for s in sys.argv[1:]] or [(64, 64, 64, 48, 48), (64, 32, 32, 96, 96)]
+    args = sys.argv[1:]
+    cfg = 78
+    if args and args[0].startswith('--cfg='):
+        cfg = int(args.pop(0)[6:])
+    shapes = [tuple(int(v) for v in s.split(',')) for s in args] or [(64, 64, 64, 48, 48), (64, 32, 32, 96, 96)]
     torch.cuda.set_device(0)
     for s in shapes:
-        run(s)
+        run(s, cfg)
