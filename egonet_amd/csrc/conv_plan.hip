@@ -127,6 +127,10 @@ static const ConvConfig kConfigs[] = {
     {85, 3, 1, 1, 3, 0, 0, 9},     // conv_s2r_kernel [round 5]: 3x3 stride 2 from the 48-channel branch, filter slice in registers (conv_s2r.hip); direct-packed filter
     {86, 12, 1, 1, 3, 9, 0, 7},    // conv_wino4w_kernel [round 6]: F(4x4,3x3), 16 x 16 pixel regions x 96 output channels per item (ai bit 3; conv_wino4w.hip); filter kind 3
     {87, 12, 1, 1, 3, 9, 64, 7},   // 86 with s_memtime stamps (tools/wino4_clk.py)
+    {88, 6, 1, 1, 3, 17, 0, 7},    // (probe builds only: NEGATIVE result) conv_wino4h_kernel [round 6]: F(4x4,3x3) in half-size blocks (6 waves, 16 tiles x 48 channels, 62 KB), two independent blocks per CU (ai bit 4; conv_wino4h.hip); filter kind 3
+    {89, 6, 1, 1, 3, 17, 64, 7},   // 88 with s_memtime stamps (tools/wino4_clk.py)
+    {90, 12, 1, 1, 3, 49, 0, 7},   // (probe builds only: NEGATIVE result) conv_wino4d_kernel [round 6]: 88's two blocks of a CU as the independent halves of ONE 12-wave workgroup (ai bit 5: LDS-counter barriers per half); filter kind 3
+    {91, 12, 1, 1, 3, 49, 64, 7},  // 90 with s_memtime stamps (tools/wino4_clk.py)
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -150,7 +154,7 @@ extern "C" int egn_conv_config_info(int cfg, int* tile_m, int* tile_n) {
 static bool probe_only(const ConvConfig& c) {
   if (c.dma == 4) return c.id == 41 || c.id == 43;
   if (c.dma == 5) return (c.bi >> 4) != 0 || (c.bi & 15) <= 1 || (c.bi & 15) >= 10;
-  if (c.dma == 7) return c.bi != 0;
+  if (c.dma == 7) return c.bi != 0 || (c.ai & 16) != 0;    // stamp builds; the half-block kernels (88 / 90: measured slower, profiles/r6_wino4h_*.txt)
   return false;
 }
 extern "C" int egn_conv_config_kind(int cfg) {
@@ -181,6 +185,8 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 6) { snprintf(buf, len, "conv_stem_kernel(ConvArgs)"); return 0; }
   if (c.dma == 7 && (c.ai & 3) == 2) { snprintf(buf, len, "void conv_wino4c_kernel<%d, %d>(ConvArgs)", c.bi, (c.ai & 4) ? 2 : 1); return 0; }
+  if (c.dma == 7 && c.ai == 49) { snprintf(buf, len, "void conv_wino4d_kernel<%d>(ConvArgs)", c.bi); return 0; }
+  if (c.dma == 7 && c.ai == 17) { snprintf(buf, len, "void conv_wino4h_kernel<%d>(ConvArgs)", c.bi); return 0; }
   if (c.dma == 7 && c.ai == 9) { snprintf(buf, len, "void conv_wino4w_kernel<%d>(ConvArgs)", c.bi); return 0; }
   if (c.dma == 7) { snprintf(buf, len, "void conv_wino4%s_kernel<%d>(ConvArgs)", c.ai == 5 ? "bk" : (c.ai ? "b" : ""), c.bi); return 0; }
   if (c.dma == 8) { snprintf(buf, len, "conv_fc_kernel(ConvArgs)"); return 0; }

@@ -25,33 +25,35 @@ constexpr int W4_CO = 48;
 template <int GEO>
 struct W4G {
   static constexpr int NIMG = GEO == 2 ? 4 : 1;         // images of a region (GEO 2: whole 8 x 8 maps)
-  static constexpr int RH = GEO == 2 ? 10 : 18, RW = GEO == 0 ? 34 : (GEO == 1 ? 18 : 10);     // halo pixels of an image
+  static constexpr int RH = GEO == 2 ? 10 : 18, RW = GEO == 0 ? 34 : (GEO == 2 ? 10 : 18);     // halo pixels of an image
   // load-element row pitch: a 16-lane store group = 8 (GEO 0) / 4 ALIGNED pixels of one row
-  static constexpr int RWP = GEO == 0 ? 40 : (GEO == 1 ? 20 : 12);
-  static constexpr int XD = GEO == 0 ? 10 : (GEO == 1 ? 5 : 3);      // slots per row and plane (x div 4: 0..8 / 0..4 / 0..2)
+  static constexpr int RWP = GEO == 0 ? 40 : (GEO == 2 ? 12 : 20);
+  static constexpr int XD = GEO == 0 ? 10 : (GEO == 2 ? 3 : 5);      // slots per row and plane (x div 4: 0..8 / 0..4 / 0..2)
   // plane / pair pitches carry a bank skew for the halo STORES (ds_write_b64 is served in groups of 16 lanes: 8 pixels x
   // 2 quads, GEO 1 / 2: 4 pixels x 4 quads; without the skew the quads of a pixel fell on one bank: 2- / 4-way conflicts).
   // GEO 0: pixel x -> 8 (x & 3) + 2 (x >> 2) dwords, quad -> + 4: 32 banks.  GEO 1 / 2: pixel -> 2 (x & 3), quad -> 8 q.
+  // GEO 3 (conv_wino4h.hip: GEO 1's region with GEO 0's 8-channel stages -- 8 pixels x 2 quads per store group): GEO 0's rule.
   // The transform's READS are per (i, j) and per pair plane: they only see XD and the image bases (bank-free as before).
-  static constexpr int PLANE = GEO == 0 ? RH * XD : (GEO == 1 ? 97 : 145);     // 2 PLANE mod 32 = 8 / 2 / 2 dwords
-  static constexpr int PAIR = GEO == 0 ? 4 * PLANE + 1 : (GEO == 1 ? 394 : 586);   // 8-byte slots per channel pair; 4 PAIR mod 32 = 4 / 8 / 8 dwords
-  static constexpr int QPP = GEO ? 4 : 2;               // channel quads per pixel and stage (16 / 8 channels)
+  static constexpr int PLANE = GEO == 0 ? RH * XD : (GEO == 1 ? 97 : (GEO == 2 ? 145 : 100));     // 2 PLANE mod 32 = 8 / 2 / 2 / 8 dwords
+  static constexpr int PAIR = GEO == 0 || GEO == 3 ? 4 * PLANE + 1 : (GEO == 1 ? 394 : 586);   // 8-byte slots per channel pair; 4 PAIR mod 32 = 4 / 8 / 8 / 4 dwords
+  static constexpr int QPP = GEO == 1 || GEO == 2 ? 4 : 2;           // channel quads per pixel and stage (16 / 8 channels)
   static constexpr int NP = GEO == 2 ? 3 : 2;           // halo load pieces per wave and stage
-  static constexpr int HSLOT = 2 * QPP * PAIR;          // 2884 / 3152 / 4688 slots
-  static constexpr int HBYTES = (GEO == 2 ? 38 : 26) * 1024;   // halo slots + 1 KB parking for the idle load lanes
+  static constexpr int HSLOT = 2 * QPP * PAIR;          // 2884 / 3152 / 4688 / 1604 slots
+  static constexpr int HBYTES = (GEO == 2 ? 38 : (GEO == 3 ? 13 : 26)) * 1024;   // halo slots + 1 KB parking for the idle load lanes (GEO 3: none)
   static constexpr int SBYTES = 16 * QPP;               // bytes of a pixel's channels of one stage
-  static constexpr int NMT = GEO ? 1 : 2;               // m-tiles of a region
-  static constexpr int NKK = GEO ? 2 : 1;               // k-groups multiplied per filter wait ("k-group pair")
-  static constexpr int TWX = GEO == 0 ? 8 : (GEO == 1 ? 4 : 2);      // tiles per image row
-  static constexpr int RGW = GEO == 0 ? 32 : (GEO == 1 ? 16 : 8);    // region width in pixels
+  static constexpr int NMT = GEO == 0 ? 2 : 1;          // m-tiles of a region
+  static constexpr int NKK = GEO == 1 || GEO == 2 ? 2 : 1;           // k-groups multiplied per filter wait ("k-group pair")
+  static constexpr int TWX = GEO == 0 ? 8 : (GEO == 2 ? 2 : 4);      // tiles per image row
+  static constexpr int RGW = GEO == 0 ? 32 : (GEO == 2 ? 8 : 16);    // region width in pixels
   static constexpr int RGH = GEO == 2 ? 8 : 16;                      // region height
+  static constexpr int VPT = GEO == 3 ? 512 : 1024;     // bytes of a frequency point in a V buffer ([k-groups of a stage][64 lanes] floats)
   // slot of image `img` inside a plane (GEO 2): 30 slots per image + a skew of 4 per image and 4 more per image PAIR, so
   // that the 16 tiles of a read group (img 0..3 x ty 0..1 (12 slots) x tx 0..1) fall on 16 different even dwords mod 32
   __host__ __device__ static constexpr int imgbase(int img) { return GEO == 2 ? 34 * img + 4 * (img >> 1) : 0; }
   // halo slot of lane tile `li` (pixel (0, 0) of the tile, x & 3 == 0 plane)
   __host__ __device__ static constexpr int tileslot(int li, int tw) {
     return GEO == 0 ? 4 * XD * (2 * (tw >> 1) + (li >> 3)) + (li & 7)
-                    : (GEO == 1 ? 4 * XD * (li >> 2) + (li & 3) : imgbase(li >> 2) + 4 * XD * ((li >> 1) & 1) + (li & 1));
+                    : (GEO == 2 ? imgbase(li >> 2) + 4 * XD * ((li >> 1) & 1) + (li & 1) : 4 * XD * (li >> 2) + (li & 3));
   }
 };
 // GEO 1 (tests/test_wino4_design_cpu.py): slot (4 XD ty + tx) -> dword 40 ty + 2 tx + (kq & 1): ty 0..3 -> banks
@@ -98,6 +100,7 @@ __device__ __forceinline__ void w4_tie6(float (&a)[6]) {
 // issue time behind the barrier, profiles/r3_wino4_timeline_v1.txt)
 template <int OFF>
 __device__ __forceinline__ f32x4 w4_gld4(u32x4 rsrc, unsigned voff, unsigned soff) {
+  static_assert(OFF >= 0 && OFF < 4096, "the immediate offset of a buffer instruction has 12 bits (the assembler truncates silently)");
   f32x4 v;
   asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(v) : "v"(voff), "s"(rsrc), "s"(soff), "n"(OFF));
   return v;
@@ -194,7 +197,7 @@ __device__ __forceinline__ void w4_transform(unsigned hb0, unsigned vw0) {
   static_assert(Q::HBYTES + (3 * Q::PLANE + 5 * Q::XD + 1) * 8 < 65536, "halo immediates");
   constexpr int HO = P ? Q::HBYTES : 0;
 #define W4_D(I, J) w4_lds<HO + (((J) & 3) * Q::PLANE + (I)*Q::XD + ((J) >> 2)) * 8>(hb0)
-#define W4_WR(PT, VAL) asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(vw0), "v"(VAL), "n"((PT)*1024) : "memory")
+#define W4_WR(PT, VAL) asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(vw0), "v"(VAL), "n"((PT)*Q::VPT) : "memory")
 #define W4_ROW(FI, O)                                                                                   \
   W4_WR((FI)*6 + 0, (O)[0]); W4_WR((FI)*6 + 1, (O)[1]); W4_WR((FI)*6 + 2, (O)[2]);                      \
   W4_WR((FI)*6 + 3, (O)[3]); W4_WR((FI)*6 + 4, (O)[4]); W4_WR((FI)*6 + 5, (O)[5]);

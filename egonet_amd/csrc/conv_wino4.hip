@@ -592,7 +592,13 @@ __global__ __launch_bounds__(256) void conv_wino4_finish_kernel(float* __restric
 // bit 3 (geo 9) [round 6]: 96 output channels per item on geometry 1 -- conv_wino4w.hip
 bool egn_conv_wino4w_applies(const ConvArgs& a);
 int egn_conv_launch_wino4w(ConvArgs a, size_t lds, int abl, hipStream_t stream);
+// bit 4 (geo 17) [round 6]: half-size blocks (6 waves, 16 tiles), two per CU -- conv_wino4h.hip
+bool egn_conv_wino4h_applies(const ConvArgs& a);
+// bit 5 (geo 49): the two blocks of a CU as the halves of ONE 12-wave workgroup (conv_wino4d_kernel)
+size_t egn_conv_wino4h_lds_bytes(int dual);
+int egn_conv_launch_wino4h(ConvArgs a, size_t lds, int abl, int dual, hipStream_t stream);
 bool egn_conv_wino4_applies(const ConvArgs& a, int geo) {
+  if (geo & 16) return (geo == 17 || geo == 49) && egn_conv_wino4h_applies(a);
   if (geo & 8) return geo == 9 && egn_conv_wino4w_applies(a);
   const int g = geo & 3, ks = (geo & 4) ? 2 : 1;
   if (g > 2 || (ks > 1 && g == 0)) return false;
@@ -612,6 +618,7 @@ int egn_conv_wino4_tickets(const ConvArgs& a, int geo) {
   return a.tiles_x * a.tiles_y * ((a.N + nimg - 1) / nimg) * (a.Cout / W4_CO) + 1;
 }
 size_t egn_conv_wino4_lds_bytes(int geo) {      // (+ the stamp area of the ABL & 64 build)
+  if (geo & 16) return egn_conv_wino4h_lds_bytes(geo & 32);
   return ((geo & 3) == 2 ? w4_lds_bytes<2>() : w4_lds_bytes<0>()) + 12 * 96 * 8;
 }
 // floats of the packed filter (engine.pack_wino4_weight): [co-tile][k-group = Cin / 4][wave][9 of 12][64]
@@ -665,7 +672,7 @@ static int w4_grid(int nwork, int nck) {
 }
 // rows of the BatchNorm partial table a launch with ConvArgs::stats writes (a: planned): one per block; 0 = none
 int egn_conv_wino4_stats_rows(const ConvArgs& a, int geo) {
-  if ((geo & 8) || !egn_conv_wino4_applies(a, geo)) return 0;      // (the wide items have no training build)
+  if ((geo & 24) || !egn_conv_wino4_applies(a, geo)) return 0;      // (the wide items / half blocks have no training build)
   const int g = geo & 3, ks = (geo & 4) ? 2 : 1, nimg = g == 2 ? 4 : 1;
   const int nct = a.Cout / W4_CO;
   const int nreg = a.tiles_x * a.tiles_y * ((a.N + nimg - 1) / nimg);
@@ -709,6 +716,7 @@ static int wino4_launch(ConvArgs a, size_t lds, hipStream_t stream) {
 }
 int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, int geo, hipStream_t stream) {
   if (!egn_conv_wino4_applies(a, geo)) return EGN_E_BADARG;
+  if (geo & 16) return a.stats ? EGN_E_BADARG : egn_conv_launch_wino4h(a, lds, abl, geo & 32, stream);
   if (geo & 8) return a.stats ? EGN_E_BADARG : egn_conv_launch_wino4w(a, lds, abl, stream);
   if (a.stats) {                       // the training tape: BatchNorm statistics in the item end
     if (abl) return EGN_E_BADARG;

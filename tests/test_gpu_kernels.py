@@ -322,6 +322,55 @@ def test_conv_wino4w_kernel(n, h, w, cin, cout, res, act):
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout,res,act', [
+    (2, 16, 16, 16, 48, True, 1),       # one region per image, two 8-channel stages
+    (64, 64, 64, 48, 48, True, 1),      # the 48-channel branch at BASELINE's 64 crops: 1 024 items on 512 blocks
+    (3, 16, 16, 192, 192, True, 1),     # four co-tiles (item mode 1), 24 stages
+    (3, 32, 48, 32, 96, False, 0),      # 2 x 3 regions, 2 co-tiles, no activation, no residual
+    (70, 16, 16, 48, 96, True, 1),      # persistent rounds
+    (5, 32, 32, 96, 384, False, 1),     # eight co-tiles (item mode 2), odd batch
+])
+def test_conv_wino4h_kernel(n, h, w, cin, cout, res, act):
+    """Config 88, conv_wino4h_kernel (csrc/conv_wino4h.hip, round 6): F(4x4,3x3) in half-size blocks -- 6 waves, one
+    16-tile m-tile x 48 channels, 62 KB of LDS, two independent blocks per CU so that one block's prologue / item end
+    runs under the other's MFMAs.  Per output the arithmetic of config 80 (same transform, K order, item end): bit-identical
+    to it, with and without the start skew of a CU's second block; oracle and tolerance as config 70 (hrnet.py:49-76)."""
+    import ctypes as C
+    from egonet_amd import _lib, ops
+    L = _lib.lib()
+    if not L.egn_probe_build():          # measured slower than config 70 (profiles/r6_wino4h_timeline.txt): probe builds only
+        assert L.egn_conv_config_kind(88) == -1 and L.egn_conv_config_kind(90) == -1
+        out = (C.c_int * 12)()
+        assert L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, 88, out) != 0
+        pytest.skip('conv_wino4h_kernel / conv_wino4d_kernel are compiled into probe builds only')
+    assert L.egn_conv_config_kind(88) == 3 and L.egn_conv_config_kind(89) == -1
+    out = (C.c_int * 12)()
+    assert L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, 88, out) == 0
+    assert list(out)[5:8] == [16, 16, 1] and out[10] == n * (h // 16) * (w // 16)
+    err = _conv_case(n, h, w, cin, cout, 3, 1, 1, act=act, use_res=res, cfg=88, seed=n + h + cin)
+    assert err < 5e-4, err
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    pc = ops.PackedConv(wt, None, _bn(cout, g), kind=3)
+    r = torch.randn(n, h, w, cout, generator=g).cuda() if res else None
+    ya = ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=88)
+    yb = ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=80)
+    # config 90, conv_wino4d_kernel: the two blocks of a CU as the halves of one 12-wave workgroup (LDS-counter barriers)
+    assert L.egn_conv_config_kind(90) == 3
+    assert L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, 90, out) == 0
+    yd = [ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=90) for _ in range(3)]
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+    for t in yd:
+        assert torch.equal(t, yb)
+    assert L.egn_conv_plan_query(2, 16, 16, 24, 24, 48, 48, 3, 3, 1, 1, 0, 88, out) != 0
+    assert L.egn_conv_plan_query(2, 8, 8, 48, 48, 48, 48, 3, 3, 1, 1, 0, 88, out) != 0
+    assert L.egn_conv_plan_query(2, 32, 32, 48, 48, 48, 48, 3, 3, 2, 1, 0, 88, out) != 0
+    assert L.egn_conv2d_bnstats_rows(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 88) == 0
+    assert L.egn_conv2d_ticket_words(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 88) == 0
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,res,act', [
     (2, 16, 16, 32, 48, True, 1),       # one stage per half
     (3, 16, 16, 192, 192, True, 1),     # the 16 x 16 maps of the 192-channel branch at a small batch: 6 stages per half
     (16, 16, 16, 192, 192, True, 1),    # BASELINE configs[4]'s per-GPU shard: 64 regions x 4 co-tiles x 2 halves
