@@ -118,6 +118,8 @@ SIGNATURES = {
     'egn_program_run_timed': (_i, [_p, _p, C.POINTER(C.c_float), _i]),
     'egn_program_capture': (_i, [_p, _p]),
     'egn_program_replay': (_i, [_p, _p]),
+    'egn_program_ticket_ops': (_i, [_p]),
+    'egn_program_poke_ticket': (_i, [_p, _i, _i, C.c_uint]),
     'egn_gemm_supported': (_i, [_i] * 7),
     'egn_gemm_ws_bytes': (C.c_long, [_i] * 4),
     'egn_gemm_f32': (_i, [_i, _p, _p, _p, _p] + [_i] * 7 + [_p, C.c_long, _p]),

@@ -431,7 +431,8 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
       W4_COLS(4)
 #undef W4_COLS
 #undef W4_M
-      float st1 = 0.f, st2 = 0.f;        // ST: this lane's 16 stored values of the round (one channel)
+      double st1 = 0.0, st2 = 0.0;       // ST: this lane's 16 stored values of the round (one channel), in doubles from the
+                                         // first add (a mean far above the deviation loses the variance's digits in fp32: ADVICE r5)
 #pragma unroll
       for (int oa = 0; oa < 4; ++oa) {
         float yo[4];
@@ -444,7 +445,7 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
           for (int ob = 0; ob < 4; ++ob) {
             const float v = fmaxf(__builtin_fmaf(yo[ob], sc, sh) + rv[oa][ob], act_lo);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, vo, oa * rowpitch + ob * colpitch, 0);
-            if constexpr (ST) { st1 += v; st2 = __builtin_fmaf(v, v, st2); }
+            if constexpr (ST) { st1 += (double)v; st2 = __builtin_fma((double)v, (double)v, st2); }
           }
         }
       }
@@ -465,7 +466,7 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
           // MI355X_MICROARCH.md "inter-workgroup visibility": sc1 stores AND sc1 loads), adds its own and applies the
           // epilogue.  Two addends: the sum does not depend on who came first.
           constexpr int SC1 = 16;            // aux bit of the raw buffer builtins
-          unsigned* tkw = a.tickets + (reg * nct + ct);
+          unsigned* tkw = a.tickets + 1 + (reg * nct + ct);      // (word 0: the error word of whoever owns the words)
           unsigned* tks = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(w4_smem) + W4_XBYTES);   // (past the exchange)
           if (tid == 0) *tks = __hip_atomic_fetch_add(tkw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __syncthreads();
@@ -484,13 +485,15 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
             if (tid == 0) {
               // bounded [round 5, ADVICE r4]: a word that is not zero at launch (a program run beside itself, a caller
               // that shares words between streams) would make both halves wait for ever; after ~2^22 polls (seconds)
-              // the block gives up, raises the launch's error word (the one behind the item pairs' words: zero in a
-              // healthy run, checked by the tests) and goes on with whatever y holds
+              // the block gives up, raises the owner's error word -- word 0 of the buffer, the same index for every layer
+              // that shares the words (the training tape) [round 6, ADVICE r5]: programs read it back behind every run
+              // and fail the NEXT run (csrc/program.hip), the tape's owner checks it where it reads the loss -- and goes on
+              // with whatever y holds
               unsigned spins = 0;
               while (__hip_atomic_load(tkw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 3u) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > (1u << 22)) {
-                  __hip_atomic_store(a.tickets + nreg * nct, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  __hip_atomic_store(a.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                   break;
                 }
               }
@@ -508,20 +511,23 @@ __device__ __forceinline__ void w4_body(const ConvArgs& a) {
               for (int ob = 0; ob < 4; ++ob) {
                 const float v = fmaxf(__builtin_fmaf(yc[oa][ob] + pv[oa][ob], sc, sh) + rv[oa][ob], act_lo);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, vo, oa * rowpitch + ob * colpitch, 0);
-                if constexpr (ST) { st1 += v; st2 = __builtin_fmaf(v, v, st2); }
+                if constexpr (ST) { st1 += (double)v; st2 = __builtin_fma((double)v, (double)v, st2); }
               }
             if (tid == 0) __hip_atomic_store(tkw, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
       }
       if constexpr (ST) {
-        // 16 values per lane in fp32, the four tiles of a channel (kq) by shuffles, then into the wave's doubles
-        if (vo == EGN_OOB) { st1 = 0.f; st2 = 0.f; }          // (GEO 2: an image past N stores nothing)
+        // 16 values per lane, the four tiles of a channel (kq) by shuffles, then into the wave's doubles.  With the K
+        // split the half that finishes SECOND stores the outputs and owns their statistics: which block's row gets them
+        // depends on arrival order, the total over the rows (egn_bn_stats_finalize_f32 adds them in a fixed order of
+        // rows, each a sum of doubles) only in the last bits of a double -- far below the fp32 mean / variance it feeds.
+        if (vo == EGN_OOB) { st1 = 0.0; st2 = 0.0; }          // (GEO 2: an image past N stores nothing)
         st1 += __shfl_xor(st1, 16); st1 += __shfl_xor(st1, 32);
         st2 += __shfl_xor(st2, 16); st2 += __shfl_xor(st2, 32);
         if (kq == 0) {
-          sS[(wave * 2 + 0) * 16 + li] += (double)st1;
-          sS[(wave * 2 + 1) * 16 + li] += (double)st2;
+          sS[(wave * 2 + 0) * 16 + li] += st1;
+          sS[(wave * 2 + 1) * 16 + li] += st2;
         }
       }
       asm volatile("" ::: "memory");
@@ -609,12 +615,13 @@ bool egn_conv_wino4_applies(const ConvArgs& a, int geo) {
          a.Cout % W4_CO == 0 && a.cs_out == a.Cout && !a.out_nchw && map_ok && !(a.act & EGN_ACT_RES_AFTER) &&
          ((a.act & EGN_ACT_MASK) == EGN_ACT_NONE || (a.act & EGN_ACT_MASK) == EGN_ACT_RELU);
 }
-// ticket words a K-split launch wants (zeroed once; every launch leaves them zero): one per (region, co-tile) + one; 0 = none
+// ticket words a K-split launch wants (zeroed once; every launch leaves them zero): the error word (index 0) + one per
+// (region, co-tile); 0 = none
 // (a: planned -- tiles_x / tiles_y are the regions of an image)
 int egn_conv_wino4_tickets(const ConvArgs& a, int geo) {
   if (!(geo & 4) || !egn_conv_wino4_applies(a, geo)) return 0;
   const int nimg = (geo & 3) == 2 ? 4 : 1;
-  // one word per (region, co-tile) + the launch's error word behind them (raised by a block whose wait ran out)
+  // the error word (raised by a block whose wait ran out) + one word per (region, co-tile)
   return a.tiles_x * a.tiles_y * ((a.N + nimg - 1) / nimg) * (a.Cout / W4_CO) + 1;
 }
 size_t egn_conv_wino4_lds_bytes(int geo) {      // (+ the stamp area of the ABL & 64 build)

@@ -193,7 +193,51 @@ struct egn_program {
   hipEvent_t ev_done = nullptr;
   hipStream_t last_stream = nullptr;
   bool ran = false;
+  // K-split ops: word 0 of an op's ticket buffer is raised by a block whose bounded wait for its partner ran out
+  // (csrc/conv_wino4.hip).  Behind every run one tiny kernel ORs the ops' words into err_dev (and clears them), one
+  // 4-byte copy brings it to the pinned err_host; the NEXT run / replay looks at it: a raised word fails that call with
+  // EGN_E_STATE after all ticket words were zeroed again [round 6, ADVICE r5: nothing read the word before].
+  std::vector<unsigned*> tickets;      // the ticket buffers of the K-split ops (also in `owned`)
+  std::vector<size_t> ticket_words;
+  unsigned** err_ptrs = nullptr;       // device array of the buffers' addresses (built at the first run)
+  unsigned* err_dev = nullptr;
+  unsigned* err_host = nullptr;        // pinned
+  hipStream_t init_stream = nullptr;   // zeroing of new ticket words (never the legacy stream: no device-wide sync)
 };
+
+__global__ void egn_ticket_errors_kernel(unsigned** bufs, int n, unsigned* any) {
+  unsigned e = 0;
+  for (int k = threadIdx.x; k < n; k += 64)
+    if (bufs[k][0]) { e = 1u; bufs[k][0] = 0u; }
+  if (e) *any = 1u;
+}
+
+// behind the ops of a run (eager, or recorded into the capture): gather the error words, copy to the pinned mirror
+static int issue_ticket_check(egn_program* p, hipStream_t s) {
+  if (p->tickets.empty()) return 0;
+  if (!p->err_ptrs) {
+    EGN_CHECK_HIP(hipMalloc(&p->err_ptrs, p->tickets.size() * sizeof(unsigned*)));
+    EGN_CHECK_HIP(hipMalloc(&p->err_dev, sizeof(unsigned)));
+    EGN_CHECK_HIP(hipHostMalloc(&p->err_host, sizeof(unsigned), hipHostMallocDefault));
+    *p->err_host = 0u;
+    // (blocking copies from pageable memory: the program is being run for the first time, nothing of it is in flight)
+    EGN_CHECK_HIP(hipMemcpy(p->err_ptrs, p->tickets.data(), p->tickets.size() * sizeof(unsigned*), hipMemcpyHostToDevice));
+    EGN_CHECK_HIP(hipMemset(p->err_dev, 0, sizeof(unsigned)));
+  }
+  hipLaunchKernelGGL(egn_ticket_errors_kernel, dim3(1), dim3(64), 0, s, p->err_ptrs, (int)p->tickets.size(), p->err_dev);
+  EGN_CHECK_HIP(hipGetLastError());
+  EGN_CHECK_HIP(hipMemcpyAsync(p->err_host, p->err_dev, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+  return 0;
+}
+// at the top of a run / replay: did an EARLIER run raise an error word?  (its copy has landed if ev_done has)
+static int consume_ticket_error(egn_program* p, hipStream_t s) {
+  if (!p->err_host || !p->ran || hipEventQuery(p->ev_done) != hipSuccess || !*p->err_host) return 0;
+  *p->err_host = 0u;
+  EGN_CHECK_HIP(hipMemsetAsync(p->err_dev, 0, sizeof(unsigned), s));
+  for (size_t k = 0; k < p->tickets.size(); ++k)
+    EGN_CHECK_HIP(hipMemsetAsync(p->tickets[k], 0, p->ticket_words[k] * sizeof(unsigned), s));
+  return EGN_E_STATE;
+}
 
 // order this run behind the previous one of the same program if that was issued on another stream (same stream: already
 // ordered).  Not while the stream is being captured (the graph's own edges order a replay; replays are ordered below).
@@ -242,6 +286,10 @@ extern "C" void egn_program_destroy(egn_program* p) {
   if (p->exec) hipGraphExecDestroy(p->exec);
   if (p->graph) hipGraphDestroy(p->graph);
   for (void* d : p->owned) hipFree(d);
+  if (p->err_ptrs) hipFree(p->err_ptrs);
+  if (p->err_dev) hipFree(p->err_dev);
+  if (p->err_host) hipHostFree(p->err_host);
+  if (p->init_stream) hipStreamDestroy(p->init_stream);
   for (int k = 1; k < kMaxLanes; ++k) {
     if (p->side[k]) hipStreamDestroy(p->side[k]);
     if (p->ev_join[k]) hipEventDestroy(p->ev_join[k]);
@@ -296,9 +344,16 @@ extern "C" int egn_program_add_conv2d(egn_program* p, egn_ref x, egn_ref wpack, 
     p->owned.push_back(d);
     // (programs run on the caller's non-blocking streams, which do not order themselves behind the legacy stream: the
     // words are zero in memory before this call returns -- a non-zero ticket would make both halves of a pair wait)
-    EGN_CHECK_HIP(hipMemset(d, 0, (size_t)ntk * sizeof(unsigned)));
-    EGN_CHECK_HIP(hipDeviceSynchronize());
+    // [round 6, ADVICE r5] on a private stream + a wait for THAT stream: no device-wide synchronisation per K-split op
+    // (the tuner builds one-op programs by the hundred) -- programs are built outside stream captures
+    if (!p->init_stream) EGN_CHECK_HIP(hipStreamCreateWithFlags(&p->init_stream, hipStreamNonBlocking));
+    EGN_CHECK_HIP(hipMemsetAsync(d, 0, (size_t)ntk * sizeof(unsigned), p->init_stream));
+    EGN_CHECK_HIP(hipStreamSynchronize(p->init_stream));
     op.conv.tickets = static_cast<unsigned*>(d);
+    p->tickets.push_back(static_cast<unsigned*>(d));
+    p->ticket_words.push_back((size_t)ntk);
+    if (p->err_ptrs) { hipFree(p->err_ptrs); p->err_ptrs = nullptr; hipFree(p->err_dev); p->err_dev = nullptr;
+                       hipHostFree(p->err_host); p->err_host = nullptr; }      // (an op added after a run: rebuilt)
   }
   p->ops.push_back(op);
   return 0;
@@ -510,6 +565,10 @@ extern "C" int egn_program_run(egn_program* p, void* stream) {
   bool capturing = false;
   int rc_o = order_behind_last_run(p, main, &capturing);
   if (rc_o) return rc_o;
+  if (!capturing) {
+    rc_o = consume_ticket_error(p, main);      // an earlier run's K-split wait ran out: that run's output was invalid
+    if (rc_o) return rc_o;
+  }
   for (Op& op : p->ops) {
     if (op.kind == OP_FORK) {
       int rc = ensure_lanes(p);
@@ -538,6 +597,10 @@ extern "C" int egn_program_run(egn_program* p, void* stream) {
     int rc = launch_op(p, op, s);
     if (rc) return rc;
   }
+  if (!capturing || p->err_ptrs) {             // (a capture records the check only if its buffers exist already)
+    int rc = issue_ticket_check(p, main);
+    if (rc) return rc;
+  }
   return mark_run_issued(p, main, capturing);
 }
 
@@ -547,12 +610,19 @@ extern "C" int egn_program_run_timed(egn_program* p, void* stream, float* ms, in
   const size_t n = p->ops.size();
   std::vector<hipEvent_t> ev(n + 1);
   for (auto& e : ev) EGN_CHECK_HIP(hipEventCreate(&e));
-  int rc = 0;
+  // [round 6, ADVICE r5] ordered behind the program's previous run like every other run (one arena, one set of words)
+  bool capturing = false;
+  int rc = order_behind_last_run(p, s, &capturing);
+  if (!rc && capturing) rc = EGN_E_STATE;      // (a timed run synchronises: never inside a capture)
+  if (!rc) rc = consume_ticket_error(p, s);
+  if (rc) { for (auto& e : ev) hipEventDestroy(e); return rc; }
   EGN_CHECK_HIP(hipEventRecord(ev[0], s));
   for (size_t i = 0; i < n && !rc; ++i) {  // serial on the caller's stream: clean per-kernel times
     if (p->ops[i].kind != OP_FORK && p->ops[i].kind != OP_JOIN) rc = launch_op(p, p->ops[i], s);
     if (!rc) rc = (int)hipEventRecord(ev[i + 1], s);
   }
+  if (!rc) rc = issue_ticket_check(p, s);
+  if (!rc) rc = mark_run_issued(p, s, false);
   if (!rc) rc = (int)hipStreamSynchronize(s);
   if (!rc)
     for (size_t i = 0; i < n; ++i) {
@@ -562,6 +632,14 @@ extern "C" int egn_program_run_timed(egn_program* p, void* stream, float* ms, in
     }
   for (auto& e : ev) hipEventDestroy(e);
   return rc;
+}
+
+extern "C" int egn_program_ticket_ops(const egn_program* p) { return p ? (int)p->tickets.size() : 0; }
+extern "C" int egn_program_poke_ticket(egn_program* p, int op, int word, unsigned value) {
+  if (!p || op < 0 || op >= (int)p->tickets.size() || word < 0 || (size_t)word >= p->ticket_words[op]) return EGN_E_BADARG;
+  wait_for_last_run(p);
+  EGN_CHECK_HIP(hipMemcpy(p->tickets[op] + word, &value, sizeof(unsigned), hipMemcpyHostToDevice));
+  return 0;
 }
 
 extern "C" int egn_program_capture(egn_program* p, void* stream) {
@@ -596,6 +674,10 @@ extern "C" int egn_program_replay(egn_program* p, void* stream) {
   bool capturing = false;
   int rc = order_behind_last_run(p, (hipStream_t)stream, &capturing);
   if (rc) return rc;
+  if (!capturing) {
+    rc = consume_ticket_error(p, (hipStream_t)stream);
+    if (rc) return rc;
+  }
   EGN_CHECK_HIP(hipGraphLaunch(p->exec, (hipStream_t)stream));
   return mark_run_issued(p, (hipStream_t)stream, capturing);
 }

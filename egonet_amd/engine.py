@@ -831,6 +831,9 @@ class HRNetEngine(object):
         if x.dtype != torch.float32:
             raise TypeError('egonet_amd HRNet engine computes in fp32, got %s' % x.dtype)
         x = x.contiguous()
+        nmax = self.max_batch(x.shape[1], x.shape[2], x.shape[3])
+        if x.shape[0] > nmax:
+            return self._forward_chunked(x, decode_mode, timed, slot, nmax)
         with torch.cuda.device(x.device):
             prog = self.program(x, decode_mode, slot)
             if not timed and x.shape[0] <= self.graph_max_n and not torch.cuda.is_current_stream_capturing():
@@ -862,6 +865,52 @@ class HRNetEngine(object):
                 prog.run()
         return outs if dec is None else (outs, dec)
 
+
+    # the batch sizes the shipped tile table covers (tuned/gfx950.json): chunks of an oversized batch are cut to these
+    CHUNK_SIZES = (128, 64, 32, 16, 8, 4, 2, 1)
+
+    def max_batch(self, c, h, w):
+        """Largest batch ONE program takes: the kernels address a tensor with 32-bit byte offsets (buffer instructions;
+        csrc/conv_plan.hip refuses a tensor of 2 GiB), and the widest tensor of the network is layer1's 256-channel map at
+        a quarter of the resolution (hrnet.py:512-529) or the stem's 64 channels at half of it: 4 MiB per 256 x 256 crop,
+        i.e. 511 crops.  The reference takes any loader batch (libs/trainer/trainer.py:113-125): larger batches are cut
+        into chunks (_forward_chunked), not refused.  EGONET_AMD_MAX_TENSOR_BYTES lowers the limit (tests)."""
+        import os
+        limit = int(os.environ.get('EGONET_AMD_MAX_TENSOR_BYTES', str(2 ** 31 - 1)))
+        per_crop = 4 * max(256 * (h // 4) * (w // 4), 64 * (h // 2) * (w // 2), c * h * w)
+        return max(1, limit // per_crop)
+
+    def _forward_chunked(self, x, decode_mode, timed, slot, nmax):
+        """A batch whose widest tensor would reach 2 GiB: cut into the largest table-covered chunk sizes that fit (at
+        256 x 256: 128 crops), run chunk by chunk on the same stream, results concatenated -- bit-identical to calling
+        the chunks one by one (tests/test_gpu_models.py::test_oversized_batches_are_chunked)."""
+        n = x.shape[0]
+        sizes, left = [], n
+        for c in self.CHUNK_SIZES:
+            if c > nmax:
+                continue
+            while left >= c:
+                sizes.append(c)
+                left -= c
+        outs, decs, ms, at = [], [], 0.0, 0
+        for c in sizes:
+            r = self.forward(x[at:at + c], decode_mode, timed, slot)
+            at += c
+            if timed:
+                ms += self.last_ms
+            if decode_mode is not None:
+                r, d = r
+                decs.append(d)
+            outs.append(r)
+        if timed:
+            self.last_ms = ms
+        if isinstance(outs[0], tuple):
+            out = tuple(torch.cat([o[k] for o in outs]) for k in range(len(outs[0])))
+        else:
+            out = torch.cat(outs)
+        if decode_mode is None:
+            return out
+        return out, tuple(torch.cat([d[k] for d in decs]) for k in range(3))
 
     def _forward_graphed(self, prog, x, decode_mode):
         """Opt-in (EGONET_AMD_GRAPH_MAX_N=<n>, default 0).  Small batches (BASELINE configs[4]'s per-GPU shard, configs[0]'s

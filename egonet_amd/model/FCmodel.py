@@ -90,6 +90,15 @@ class FCModel(nn.Module):
             self.__dict__['_bridge'] = b
         return b
 
+    def __getstate__(self):
+        # torch.save(model) / copy.deepcopy: the launch programs, the autograd bridge and the hook cache are
+        # per-process device state (ctypes handles, streams) -- rebuilt on first use, never pickled
+        state = dict(self.__dict__)
+        state['_engine'] = None
+        state.pop('_bridge', None)
+        state.pop('_hook_dicts', None)
+        return state
+
     def train(self, mode=True):
         if mode:                 # the weights are about to change: drop programs and packed blobs
             self._engine = None

@@ -26,18 +26,37 @@ _MOMENTUM = 0.1
 
 
 
+# Every registration of a submodule anywhere (add_module / __setattr__ / container item assignment) bumps this counter:
+# the hook cache below is valid for the module TREE it was collected from (a block replaced or wrapped after
+# .eval() and then given a hook was not seen).  torch's global registration hook costs nothing on the forward path.
+_TREE_GENERATION = [0]
+
+
+def _bump_tree_generation(module, name, submodule):
+    _TREE_GENERATION[0] += 1
+
+
+_REG_HOOK = getattr(nn.modules.module, 'register_module_module_registration_hook', None)
+if _REG_HOOK is not None:
+    _REG_HOOK(_bump_tree_generation)
+
+
 def _has_submodule_hooks(module):
     """True if any SUBmodule carries a forward / backward hook (hooks on the module itself fire around its forward
     whichever path runs inside).  Called on every train-mode forward of a launch-bound step: the hook dictionaries of
-    the ~1.5 k submodules (register_*_hook mutates them in place) are collected once per ``.train()`` / ``.eval()`` call
-    -- 0.015 ms per check instead of a 0.9 ms Python walk."""
+    the ~1.5 k submodules (register_*_hook mutates them in place) are collected once per module tree -- the cache is
+    dropped by ``.train()`` / ``.eval()`` and whenever ANY submodule is registered anywhere (_TREE_GENERATION) -- 0.015 ms
+    per check instead of a 0.9 ms Python walk.  The cache lives outside ``__dict__`` pickling
+    (``__getstate__`` drops it)."""
     cache = module.__dict__.get('_hook_dicts')
-    if cache is None:
-        cache = [d for m in module.modules() if m is not module
+    if cache is None or cache[0] != _TREE_GENERATION[0] or _REG_HOOK is None:
+        dicts = [d for m in module.modules() if m is not module
                  for d in (m._forward_hooks, m._forward_pre_hooks, m._backward_hooks,
                            getattr(m, '_backward_pre_hooks', None)) if d is not None]
+        cache = (_TREE_GENERATION[0], dicts)
         module.__dict__['_hook_dicts'] = cache
-    return any(cache)
+    return any(cache[1])
+
 
 def _conv(cin, cout, k, stride=1, bias=False):
     return nn.Conv2d(cin, cout, kernel_size=k, stride=stride, padding=(k - 1) // 2, bias=bias)
@@ -300,6 +319,15 @@ class PoseHighResolutionNet(nn.Module):
             b = autograd.HRNetAutograd(self)
             self.__dict__['_bridge'] = b
         return b
+
+    def __getstate__(self):
+        # torch.save(model) / copy.deepcopy: the launch programs, the autograd bridge and the hook cache are
+        # per-process device state (ctypes handles, streams) -- rebuilt on first use, never pickled
+        state = dict(self.__dict__)
+        state['_engine'] = None
+        state.pop('_bridge', None)
+        state.pop('_hook_dicts', None)
+        return state
 
     def train(self, mode=True):
         if mode:                 # the weights are about to change: drop programs and packed blobs

@@ -285,6 +285,11 @@ class _Tape(object):
         can_f43 = can_wino and f43_ok and self.o.allow_f43 in (('all',) if dgrad else ('all', 'fwd'))
         cfg = tuner.choose(self.dev, key, allow_wino=can_wino, allow_f43=can_f43)
         kind = self.L.egn_conv_config_kind(cfg) if cfg > 0 else 0
+        if kind == 2:
+            # conv_wino43_kernel's filter layout (kind 2) is not one the tape packs: never launch it on a direct-packed
+            # filter -- take the best configuration of the kinds the tape feeds instead
+            cfg = tuner.choose(self.dev, key, allow_wino=can_wino, allow_f43=False)
+            kind = self.L.egn_conv_config_kind(cfg) if cfg > 0 else 0
         ntk = 0
         if kind == 3:
             ntk = self.L.egn_conv2d_ticket_words(n, h, w, cin, cs_in, cout, cs_out, kh, kw, stride, pad, cfg)

@@ -554,6 +554,14 @@ int egn_program_run_timed(egn_program* p, void* stream, float* ms, int n_ms);
 /* capture the op sequence into a hipGraph (bindings frozen) / replay it */
 int egn_program_capture(egn_program* p, void* stream);
 int egn_program_replay(egn_program* p, void* stream);
+/* [round 6] Ticket words of the program's K-split convolution ops (conv_wino4.hip: word 0 of an op's buffer is the error
+ * word a block raises when its bounded wait for its partner runs out; 1.. are the item pairs' words, zero between runs).
+ * A raised error word fails the NEXT egn_program_run / _run_timed / _replay with EGN_E_STATE (the run that raised it
+ * produced invalid output); all words are zeroed again by that call.  egn_program_ticket_ops: how many ops own words.
+ * egn_program_poke_ticket: TEST HOOK -- stores `value` into word `word` of K-split op `op` (0-based among those ops),
+ * synchronously; the reference has no counterpart (its layers are single torch calls: libs/model/heatmapModel/hrnet.py:63-92). */
+int egn_program_ticket_ops(const egn_program* p);
+int egn_program_poke_ticket(egn_program* p, int op, int word, unsigned value);
 /* [round 5] layer1's 1x1 pair as one op (egn_pw_pair_f32 below); w1 / shift1 / hn with slot < 0: the first product alone */
 int egn_program_add_pw_pair(egn_program* p, egn_ref h, egn_ref res, egn_ref w3, egn_ref shift3,
                             egn_ref w1, egn_ref shift1, egn_ref out, egn_ref hn, int M,

@@ -67,7 +67,7 @@ def test_w48_forward_and_decode_at_bench_batch_64_vs_oracle():
     wino = {s: n for s, n in syms.items() if 'wino' in s}
     assert sum(wino.values()) >= 200, syms                         # the 3x3 s1 layers run the Winograd family
     # ... and it is what the committed bench line of this round reports
-    lines = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r5_bench_n1*.json')))
+    lines = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r6_bench_n1*.json')))
     if lines:
         with open(lines[-1]) as f:
             rep = json.load(f)

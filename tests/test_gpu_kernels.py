@@ -555,6 +555,53 @@ def test_conv_wino4c_ticket_path_of_programs(n, cin, cout, res, act):
         L.egn_program_destroy(h)
 
 
+def test_k_split_wait_that_runs_out_fails_the_next_run_of_the_program():
+    """[round 6, ADVICE r5] A ticket word that is not zero at launch (a caller that shares words between streams, a
+    program run beside itself) makes both halves of an item pair wait for a count that never comes; the wait is bounded
+    (2^22 polls), the block raises the owner's error word (word 0) and goes on with invalid output.  Nothing used to read
+    that word.  Now: behind every run the program ORs its K-split ops' error words into a pinned mirror, and the NEXT run
+    (eager, timed or replayed) fails with EGN_E_STATE after zeroing every word -- the run after that is correct again."""
+    from egonet_amd import _lib, ops
+    L = _lib.lib()
+    n, cin, cout = 4, 64, 48
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 8, 8, cin, generator=g).cuda()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    pc = ops.PackedConv(wt, None, _bn(cout, g), kind=3)
+    want = ops.conv2d_nhwc(x, pc, cin, 1, 1, 1, None, cfg=83)
+    y = torch.full((n, 8, 8, cout), float('nan'), device='cuda')
+    h = L.egn_program_create(8)
+    assert h
+    try:
+        refs = []
+        for slot, t in enumerate([x, pc.w, pc.scale, pc.shift, None, y]):
+            if t is None:
+                refs.append(_lib.NULL_REF)
+                continue
+            assert L.egn_program_bind(h, slot, _lib.ptr(t)) == 0
+            refs.append(_lib.Ref(slot, 0))
+        assert L.egn_program_add_conv2d(h, *refs, n, 8, 8, cin, cin, cout, cout, 3, 3, 1, 1, 1, 0, 83) == 0
+        assert L.egn_program_ticket_ops(h) == 1
+        assert L.egn_program_poke_ticket(h, 1, 0, 1) != 0 and L.egn_program_poke_ticket(h, 0, 1 << 20, 1) != 0
+        st = _lib.current_stream()
+        for _ in range(3):
+            assert L.egn_program_run(h, st) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y, want)
+        assert L.egn_program_poke_ticket(h, 0, 1, 5) == 0       # the first item pair's word: both halves will wait in vain
+        assert L.egn_program_run(h, st) == 0                    # (issued fine; its output is invalid)
+        torch.cuda.synchronize()
+        assert L.egn_program_run(h, st) == -3                   # EGN_E_STATE: the previous run raised the error word
+        torch.cuda.synchronize()
+        y.fill_(float('nan'))
+        assert L.egn_program_run(h, st) == 0                    # words zeroed by the failing call: healthy again
+        torch.cuda.synchronize()
+        assert torch.equal(y, want)
+        assert L.egn_program_run(h, st) == 0
+    finally:
+        L.egn_program_destroy(h)
+
+
 @pytest.mark.parametrize('h,c,cfg', [(64, 48, 51), (32, 96, 51), (16, 192, 51), (8, 384, 56), (16, 192, 57)])
 def test_winograd_at_the_bench_batch_size_agrees_with_direct_and_is_linear(h, c, cfg):
     """BASELINE configs[1] size (64 crops): the Winograd kernel of each shape class against the direct

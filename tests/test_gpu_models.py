@@ -438,6 +438,57 @@ def test_small_batches_replay_their_program_as_a_hipgraph(head):
     assert r.returncode == 0 and 'graph case ok' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize('head', ['heatmap', 'coordinates'])
+def test_oversized_batches_are_chunked(head, monkeypatch):
+    """[round 6] engine.HRNetEngine._forward_chunked: the reference takes any loader batch (libs/trainer/trainer.py:113-125,
+    tools/inference.py:135-199); the kernels address tensors with 32-bit byte offsets, so a batch whose widest tensor
+    would reach the limit is cut into the largest table-covered chunk sizes and the results are concatenated -- not
+    refused.  Tiny model with the limit lowered to what 5 crops need: 13 crops run as 4 + 4 + 4 + 1, bit-identical to
+    running those chunks one by one, through forward (+ decode) and through the module."""
+    cfg = configs.tiny_config(head)
+    net, sd = _model(cfg, 6)
+    x = synth.synth_crops(13, 3, 64, 64, seed=41).cuda()
+    eng = net._hip_engine()
+    per_crop = 4 * max(256 * 16 * 16, 64 * 32 * 32, 3 * 64 * 64)
+    monkeypatch.setenv('EGONET_AMD_MAX_TENSOR_BYTES', str(5 * per_crop))
+    assert eng.max_batch(3, 64, 64) == 5
+    got = eng.forward(x, decode_mode=1)
+    parts = [eng.forward(x[a:b], decode_mode=1) for a, b in ((0, 4), (4, 8), (8, 12), (12, 13))]
+    flat_g = torch.utils._pytree.tree_leaves(got)
+    for k, g in enumerate(flat_g):
+        want = torch.cat([torch.utils._pytree.tree_leaves(p)[k] for p in parts])
+        assert g.shape[0] == 13 and torch.equal(g, want)
+    with torch.no_grad():
+        y = net(x)
+    for k, g in enumerate(torch.utils._pytree.tree_leaves(y)):
+        assert torch.equal(g, flat_g[k])
+    monkeypatch.delenv('EGONET_AMD_MAX_TENSOR_BYTES')
+    assert eng.max_batch(3, 256, 256) == 511
+    whole = eng.forward(x, decode_mode=1)            # 13 crops fit one program: same values up to the kernels' batch-size choice
+    for a, b in zip(torch.utils._pytree.tree_leaves(whole), flat_g):
+        assert a.shape == b.shape and (a.float() - b.float()).abs().max().item() < 1e-3
+
+
+def test_w48_batch_of_520_crops_runs_in_chunks():
+    """The real limit: 520 crops of 256 x 256 (layer1's 256-channel tensor would be 2.03 GiB) = 4 x 128 + 8, equal bit for
+    bit to the chunks run one by one; 511 crops is the largest single program."""
+    cfg = configs.w48_config('heatmap')
+    net, sd = _model(cfg, 9)
+    eng = net._hip_engine()
+    assert eng.max_batch(3, 256, 256) == 511
+    base = synth.synth_crops(8, 3, 256, 256, seed=43).cuda()
+    x = base.repeat(65, 1, 1, 1)
+    x += torch.arange(520, device='cuda', dtype=torch.float32).view(-1, 1, 1, 1) * 1e-3
+    got, (xy, mx, idx) = eng.forward(x, decode_mode=1)
+    assert got.shape[0] == 520 and xy.shape[0] == 520
+    at = 0
+    for c in (128, 128, 128, 128, 8):
+        o, (a, b_, i_) = eng.forward(x[at:at + c], decode_mode=1)
+        assert torch.equal(got[at:at + c], o) and torch.equal(xy[at:at + c], a) and torch.equal(idx[at:at + c], i_)
+        at += c
+    assert torch.isfinite(got).all()
+
+
 def test_layer1_on_the_pw_pair_kernel_equals_the_layerwise_program(monkeypatch):
     """[round 5] engine._layer1: conv3 + residual + ReLU + the next block's conv1 + ReLU as ONE launch of csrc/conv_pw.hip
     (the downsample conv and the last conv3 its one-product form) against the same engine with EGONET_AMD_PW_FUSE=0

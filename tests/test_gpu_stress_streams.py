@@ -115,6 +115,7 @@ CONV_CASES = [
     (42, (64, 64, 64, 48, 48, 3, 1, 1), True),       # conv_c48_kernel<8>
     (64, (64, 256, 256, 3, 64, 3, 2, 1), False),     # conv_stem_kernel
     (85, (64, 64, 64, 48, 96, 3, 2, 1), False),      # conv_s2r_kernel [round 5] (gathering LDS-DMA, vmcnt(0) only)
+    (86, (64, 32, 32, 96, 96, 3, 1, 1), True),       # conv_wino4w_kernel [round 6] (96 output channels per item, vmcnt(0) only)
 ]
 
 

@@ -161,3 +161,30 @@ def test_dropout_seed_is_mixed_with_the_rank(monkeypatch):
         monkeypatch.setattr(dist, 'get_rank', lambda r=r: r)
         seeds.append(train_lifter._rank_mixed_seed(s))
     assert seeds[0] == s and len(set(seeds)) == 4 and all(0 <= v < (1 << 62) for v in seeds)
+
+
+def test_hook_cache_follows_the_module_tree_and_stays_out_of_pickles():
+    """[round 6, ADVICE r5] heatmapModel.hrnet._has_submodule_hooks caches the submodules' hook dictionaries; the cache is
+    keyed on a generation counter that every submodule registration bumps, so a block that is replaced AFTER the cache
+    was filled and then given a hook is seen (the native path would skip the hook silently otherwise); and
+    ``torch.save(model)`` carries neither the cache nor per-process device state."""
+    import copy
+    import io
+    from egonet_amd.model.heatmapModel import hrnet as H
+    net = H.get_pose_net(configs.tiny_config('heatmap'), is_train=False)
+    assert not H._has_submodule_hooks(net) and '_hook_dicts' in net.__dict__
+    net.stage2[0].branches[0][0] = copy.deepcopy(net.stage2[0].branches[0][0])       # a new object, unknown to the cache
+    handle = net.stage2[0].branches[0][0].register_forward_hook(_noop_hook)
+    assert H._has_submodule_hooks(net)
+    handle.remove()
+    assert not H._has_submodule_hooks(net)
+    buf = io.BytesIO()
+    torch.save(net, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)
+    assert '_hook_dicts' not in back.__dict__ and '_bridge' not in back.__dict__ and back._engine is None
+    assert list(back.state_dict().keys()) == list(net.state_dict().keys())
+
+
+def _noop_hook(module, inputs, output):
+    return None

@@ -27,7 +27,9 @@ def run(x, env):
     eng = net._hip_engine()
     maps, _ = eng.forward(x, decode_mode=1)
     prog = eng.program(x, 1)
-    n70 = sum(1 for m in prog.meta if m['kind'] == 'conv' and m['cfg'] == 70)
+    # launches of the 12-wave F(4x4,3x3) kernels on the large maps: conv_wino4_kernel (cfg 70) and, since round 6,
+    # conv_wino4w_kernel (cfg 86: the 96-channel layers)
+    n70 = sum(1 for m in prog.meta if m['kind'] == 'conv' and m['cfg'] in (70, 86))
     torch.cuda.synchronize()
     return maps.clone(), n70
 
