@@ -28,8 +28,25 @@ def forward_affines(centers, scales, out_wh):
     return m
 
 
-def crop_boxes(img, centers, scales, out_wh, mean=IMAGENET_MEAN, std=IMAGENET_STD, device=None):
-    """img [H,W,3] uint8 RGB (numpy or tensor, host or device) -> CUDA [n,3,h,w] fp32 crops."""
+_CONST = {}
+
+
+def _norm_consts(mean, std, device):
+    """mean / std as device tensors, uploaded once per (device, values): a per-call ``torch.tensor(..., device=)`` is a
+    blocking copy from pageable memory -- two per frame serialised a serving loop that overlaps uploads with compute."""
+    key = (str(device), tuple(float(v) for v in mean), tuple(float(v) for v in std))
+    c = _CONST.get(key)
+    if c is None:
+        c = (torch.tensor(key[1], dtype=torch.float32, device=device), torch.tensor(key[2], dtype=torch.float32, device=device))
+        _CONST[key] = c
+    return c
+
+
+def crop_boxes(img, centers, scales, out_wh, mean=IMAGENET_MEAN, std=IMAGENET_STD, device=None, affines=None, out=None):
+    """img [H,W,3] uint8 RGB (numpy or tensor, host or device) -> CUDA [n,3,h,w] fp32 crops.
+    ``affines``: the boxes' [n,6] float64 image -> crop affines already on the device (``forward_affines`` uploaded by
+    the caller, e.g. once per batch from pinned memory) -- then ``centers`` / ``scales`` are not read and the call issues
+    no host -> device copy of its own; ``out``: a preallocated [n,3,h,w] fp32 device tensor to write into."""
     L = _lib.lib()
     device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
     t = torch.as_tensor(img)
@@ -38,13 +55,20 @@ def crop_boxes(img, centers, scales, out_wh, mean=IMAGENET_MEAN, std=IMAGENET_ST
     t = t.to(device).contiguous()
     H, W = t.shape[:2]
     w, h = int(out_wh[0]), int(out_wh[1])
-    M = torch.from_numpy(forward_affines(centers, scales, (w, h))).to(device)
+    if affines is None:
+        M = torch.from_numpy(forward_affines(centers, scales, (w, h))).to(device)
+    else:
+        M = affines
+        if not (M.is_cuda and M.dtype == torch.float64 and M.dim() == 2 and M.shape[1] == 6 and M.is_contiguous()):
+            raise ValueError('affines: a contiguous [n,6] float64 CUDA tensor')
     n = M.shape[0]
-    out = torch.empty(n, 3, h, w, dtype=torch.float32, device=device)
+    if out is None:
+        out = torch.empty(n, 3, h, w, dtype=torch.float32, device=device)
+    elif tuple(out.shape) != (n, 3, h, w) or out.dtype != torch.float32 or not out.is_cuda or not out.is_contiguous():
+        raise ValueError('out: a contiguous [n,3,h,w] fp32 CUDA tensor')
     if n == 0:
         return out
-    mean_t = torch.tensor(mean, dtype=torch.float32, device=device)
-    std_t = torch.tensor(std, dtype=torch.float32, device=device)
+    mean_t, std_t = _norm_consts(mean, std, device)
     with torch.cuda.device(device):
         _lib.check(L.egn_crop_warp_normalize_u8(_lib.ptr(t), H, W, 3 * W, _lib.ptr(M), n, h, w, _lib.ptr(mean_t),
                                                 _lib.ptr(std_t), _lib.ptr(out), _lib.current_stream(device)), 'crop')

@@ -270,3 +270,72 @@ def test_gloo_world2_session_guards_and_overlap_switch():
     assert out['after_first'] == 0 and out['after_second'] >= 1
     assert out['mean'] == (1.5, 1.5)
     assert out['off'] is True and out['off_mean'] == (1.5, 1.5)
+
+
+def _world4_worker(rank, world, port, q):
+    """[round 6, VERDICT r5 next #9] Four ranks: more slices than ranks, a ragged slice tail, parameters that span
+    slice borders, and ragged inference shards (one rank with an EMPTY shard) gathered in rank order -- orderings that a
+    world of two cannot get wrong."""
+    from egonet_amd.train_hrnet import FlatParams
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    # (a) flat buffer, 23 slices of 97 floats + a ragged one, every rank a different multiple
+    n = 23 * 97 + 41
+    flat = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    sync = parallel.FlatGradSync(bucket_mb=4 * 97 / 2 ** 20)
+    sl = sync.slices(n)
+    assert len(sl) == 24 > world and sl[0] == (n - 97, n) and sl[-1] == (0, 41)
+    sync(flat)
+    # (b) a session over FlatParams: parameters reported final in backward order, slices cut across parameter borders
+    cfg = configs.tiny_config()
+    net = FCmodel.get_fc_model(1, cfg, 10, 12)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=3))
+    net.eval()
+    fp = FlatParams(net.parameters())
+    g = torch.Generator().manual_seed(7)
+    x, y = torch.randn(10, 10, generator=g), torch.randn(10, 12, generator=g)      # 10 crops over 4 ranks: 3 + 3 + 2 + 2
+    lo, hi = parallel.shard_range(10, world, rank)
+    loss = ((net.w2(net.get_representation(x[lo:hi])) - y[lo:hi]) ** 2).sum() / (10 * 12) * world
+    sess = parallel.FlatGradSync(bucket_mb=4 * 1777 / 2 ** 20).begin(fp)            # 1777 floats: not a divisor of anything
+    assert sess is not None and len(sess.slices) > 2 * world
+    loss.backward()
+    for p in reversed(fp.params):
+        sess.done([p])
+    sess.finish()
+    got = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+    # (c) ragged inference shards: 5 results over 4 ranks = 2 + 1 + 1 + 1, and 3 results = 1 + 1 + 1 + 0 (rank 3 empty)
+    out = {}
+    for total in (5, 3):
+        a, b = parallel.shard_range(total, world, rank)
+        res = parallel.gather_results({'idx': torch.arange(a, b).float().reshape(-1, 1),
+                                       'sq': (torch.arange(a, b).float() ** 2).reshape(-1, 1, 1)})
+        if rank == 0:
+            out[total] = (res['idx'].numpy().ravel(), res['sq'].numpy().ravel())
+    if rank == 0:
+        ref = FCmodel.get_fc_model(1, cfg, 10, 12)
+        ref.load_state_dict(synth.synth_state_dict(ref.state_dict(), seed=3))
+        ref.eval()
+        ((ref.w2(ref.get_representation(x)) - y) ** 2).mean().backward()
+        want = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+        q.put((flat.numpy(), got.numpy(), want.numpy(), out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world4_slices_sessions_and_ragged_shards():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world4_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    flat, got, want, out = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    np.testing.assert_allclose(flat, np.arange(23 * 97 + 41, dtype=np.float32) * 2.5)       # mean of x1 .. x4
+    assert np.abs(want).max() > 1e-3
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-6 * np.abs(want).max())
+    for total in (5, 3):
+        idx, sq = out[total]
+        assert np.array_equal(idx, np.arange(total)) and np.array_equal(sq, np.arange(total) ** 2.0)
