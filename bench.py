@@ -49,7 +49,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_HBM_GBPS = 8000.0
 # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/prof_r4.sh + tools/pmc_traffic.py), newest first
-TRAFFIC_JSONS = [os.path.join(ROOT, 'profiles', n) for n in ('r5_pmc_traffic.json', 'r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json')]
+TRAFFIC_JSONS = [os.path.join(ROOT, 'profiles', n) for n in ('r6_pmc_traffic.json', 'r5_pmc_traffic.json', 'r4_pmc_traffic.json', 'r3_pmc_traffic.json', 'r2_pmc_traffic.json')]
 WINO_EXECUTED = 16.0 / 36.0       # fused Winograd F(2x2,3x3): multiplies executed per direct-algorithm multiply
 WINO4_EXECUTED = 36.0 / 144.0     # F(4x4,3x3): 36 multiplies per 16 outputs instead of 144
 

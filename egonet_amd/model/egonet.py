@@ -28,6 +28,7 @@ import torch.nn as nn
 from .. import _lib
 from . import FCmodel
 from . import heatmapModel  # noqa: F401  (plugin namespace)
+from ..common import img_proc
 from ..common.img_proc import modify_bbox, to_npy
 from ..common.format import get_pred_str, save_txt_file
 import egonet_amd.model as models  # noqa: F401  (eval() lookup below, like the reference)
@@ -146,8 +147,6 @@ class EgoNet(nn.Module):
         of the device kernel (same pose_math.h arithmetic)."""
         if is_cuda:
             instances = instances.cuda()
-        if any(float(r.get('rotation', 0.)) != 0. for r in records):
-            raise NotImplementedError('rotated crops are not produced by the inference path')
         width, height = self.resolution
         centers = np.ascontiguousarray(np.stack([np.asarray(r['center'], dtype=np.float64) for r in records]))
         scales = np.ascontiguousarray(np.stack([np.asarray(r['scale'], dtype=np.float64) for r in records]))
@@ -170,6 +169,19 @@ class EgoNet(nn.Module):
             _lib.check(_lib.lib().egn_keypoints_to_screen_host_f64(
                 loc.ctypes.data, n, J, float(width), float(height), centers.ctypes.data, scales.ctypes.data,
                 int(width), int(height), screen.ctypes.data), 'keypoints_to_screen_host')
+        # Records with a rotation (egonet.py:442-452 passes records[i]['rotation'] to get_affine_transform; the shipped
+        # inference path only makes rot = 0 crops, the device kernel's case): the reference's own host arithmetic --
+        # local *= resolution in float32, the exact three-point affine (common.img_proc.get_affine_transform, inv = 1),
+        # float64 product.  A handful of 33-point products per rotated record, on the host as in the reference.
+        rots = [float(r.get('rotation', 0.)) for r in records]
+        if any(rots):
+            loc = np.array(local.detach().cpu().numpy(), dtype=np.float32, copy=True)
+            loc *= np.array([width, height]).reshape(1, 1, 2)
+            screen = np.array(screen, dtype=np.float64, copy=True)
+            for i, rot in enumerate(rots):
+                if rot != 0.:
+                    t_inv = img_proc.get_affine_transform(centers[i], scales[i], rot, (height, width), inv=1)
+                    screen[i] = img_proc.affine_transform_modified(loc[i], t_inv)
         ret = {}
         for i, record in enumerate(records):
             record['kpts'] = screen[i]

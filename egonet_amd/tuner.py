@@ -134,10 +134,13 @@ def _pick(entry, allow_wino, allow_f43=False):
     2 Winograd F(4x4,3x3) with ``allow_f43``: the inference engine, which transforms filters on the host)."""
     L = _lib.lib()
     ok = {0} | ({1} if allow_wino else set()) | ({2, 3} if allow_f43 else set())
+    # EGONET_AMD_SKIP_CFG=86,84: same-box A/B runs of a new configuration against the table without it
+    skip = {int(v) for v in os.environ.get('EGONET_AMD_SKIP_CFG', '').split(',') if v.strip()}
     cfg = int(entry['cfg'])
-    if cfg <= 0 or L.egn_conv_config_kind(cfg) in ok:
+    if cfg <= 0 or (L.egn_conv_config_kind(cfg) in ok and cfg not in skip):
         return cfg
-    fit = {int(k): v for k, v in entry.get('ms', {}).items() if L.egn_conv_config_kind(int(k)) in ok}
+    fit = {int(k): v for k, v in entry.get('ms', {}).items()
+           if L.egn_conv_config_kind(int(k)) in ok and int(k) not in skip}
     return min(fit, key=fit.get) if fit else 0
 
 

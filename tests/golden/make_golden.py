@@ -22,6 +22,7 @@ Usage:  python tests/golden/make_golden.py            (from the repo root)
         --jmse         only the JointsMSELoss fixture (section 0f)
         --train-only   stop after the training-side fixtures (sections 0 .. 0e)
         --cr-only      stop after the cross-ratio / metric fixtures (0d, 0e)
+        --rot-only     only the rotated-record key-point fixture (section 9)
 The generation is deterministic: re-running leaves the committed files byte-identical.
 """
 import json
@@ -577,5 +578,33 @@ def main():
          alpha_trans=ego.get_observation_angle_trans(e, t))
 
 
+def rotated_keypoints():
+    """Section 9 [round 6]: EgoNet.get_keypoints' crop -> screen step for records with a rotation
+    (libs/model/egonet.py:436-452: local *= resolution in float32, get_affine_transform(center, scale, rot, (h, w),
+    inv=1), affine_transform_modified) -- the reference's own numpy functions on seeded inputs."""
+    _install_stubs()
+    sys.path.insert(0, REF)
+    import libs.common.img_proc as ref_ip
+    rng = np.random.RandomState(9)
+    n, J = 7, 33
+    local = rng.uniform(0.0, 1.0, (n, J, 2)).astype(np.float32)
+    centers = rng.uniform(100.0, 1100.0, (n, 2))
+    scales = np.repeat(rng.uniform(0.3, 1.5, (n, 1)), 2, axis=1)
+    rots = np.array([0.0, 30.0, -45.0, 90.0, 12.5, 180.0, -7.25])
+    res = (256, 256)
+    lc = local.copy()
+    lc *= np.array(res).reshape(1, 1, 2)
+    screen = np.stack([ref_ip.affine_transform_modified(
+        lc[i], ref_ip.get_affine_transform(centers[i], scales[i], rots[i], (res[1], res[0]), inv=1)) for i in range(n)])
+    path = os.path.join(HERE, 'kpts_rotated.npz')
+    np.savez_compressed(path, local=local, centers=centers, scales=scales, rots=rots, resolution=np.array(res),
+                        screen=screen)
+    print('%-28s %8.1f KB' % ('kpts_rotated.npz', os.path.getsize(path) / 1024))
+
+
 if __name__ == '__main__':
-    main()
+    if '--rot-only' in sys.argv:
+        rotated_keypoints()
+    else:
+        main()
+        rotated_keypoints()

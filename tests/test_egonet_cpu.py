@@ -82,3 +82,26 @@ def test_config1_single_crop_w48_demo_topology_on_cpu(tmp_path):
             assert abs(float(a) - float(b)) < 5e-4
         else:
             assert a == b
+
+
+def test_get_keypoints_with_rotated_records_vs_reference():
+    """[round 6] libs/model/egonet.py:442-452: every record's 'rotation' goes into get_affine_transform(inv=1).  The
+    fixture holds the REFERENCE's screen coordinates for seven records with rotations 0 / 30 / -45 / 90 / 12.5 / 180 /
+    -7.25 degrees (tests/golden/make_golden.py section 9); HC is replaced by a stub that returns the fixture's local
+    coordinates, so this checks the crop -> screen step alone (rot = 0 rows take the host twin of the device kernel)."""
+    g = golden('kpts_rotated.npz')
+    ego = EgoNet(configs.tiny_config('coordinates'), pre_trained=False).eval()
+    ego.resolution = [int(v) for v in g['resolution']]
+    local = torch.from_numpy(g['local'])
+    n = local.shape[0]
+
+    class _Stub(torch.nn.Module):
+        def forward(self, x):
+            return None, local
+    ego.HC = _Stub()
+    records = [dict(path='img%d.png' % (i // 4), center=g['centers'][i], scale=g['scales'][i], rotation=float(g['rots'][i]),
+                    bbox_resize=[0, 0, 1, 1], label='Car', score=1.0) for i in range(n)]
+    rec = ego.get_keypoints(torch.zeros(n, 3, 8, 8), records, is_cuda=False)
+    got = np.concatenate([np.concatenate(rec[p]['kpts_2d_pred']) for p in rec]).reshape(n, -1, 2)
+    np.testing.assert_allclose(got, g['screen'], rtol=0, atol=1e-6)
+    assert [r for p in rec for r in rec[p]['rotation']] == [float(v) for v in g['rots']]
