@@ -90,3 +90,33 @@ def test_lifter_program_and_weight_blob():
     w = blob[o:o + 5 * 4 * 1024 * 4].view(5, 1, 4, 1024, 4)
     assert torch.equal(w[0, 0, 0, 3], net.w1.weight[3, 0:4].detach())
     assert float(w[4, 0, 0, :, 2:].abs().sum()) == 0.0      # input channels 66, 67 are padding
+
+
+def test_max_batch_and_chunk_sizes_of_oversized_batches(monkeypatch):
+    """[round 6] HRNetEngine.max_batch / _forward_chunked (host logic, no GPU): the widest tensor of the network decides how
+    many crops one program takes (32-bit byte offsets in the kernels: 2 GiB per tensor); larger batches are cut greedily
+    into the tile table's batch sizes.  The reference accepts any loader batch (libs/trainer/trainer.py:113-125)."""
+    net = hrnet.get_pose_net(configs.tiny_config('heatmap'), is_train=False).eval()
+    eng = engine.HRNetEngine(net)
+    monkeypatch.delenv('EGONET_AMD_MAX_TENSOR_BYTES', raising=False)
+    assert eng.max_batch(3, 256, 256) == 511                      # layer1's 256 channels at 64 x 64: 4 MiB per crop
+    assert eng.max_batch(3, 128, 128) == 2047 and eng.max_batch(3, 512, 512) == 127
+    assert eng.max_batch(3, 2048, 2048) == 7                      # (never below one crop per program: max(1, ...))
+    monkeypatch.setenv('EGONET_AMD_MAX_TENSOR_BYTES', str(4 * 256 * 16 * 16 * 5))
+    assert eng.max_batch(3, 64, 64) == 5
+    seen = []
+
+    def fake_forward(x, decode_mode=None, timed=False, slot=0):   # records the chunks instead of running them
+        seen.append(x.shape[0])
+        n = x.shape[0]
+        maps = torch.arange(n, dtype=torch.float32).view(n, 1, 1, 1) + 100 * len(seen)
+        if decode_mode is None:
+            return maps
+        return (maps, (maps.view(n, 1, 1).expand(n, 1, 2), maps.view(n, 1, 1), maps.view(n, 1).int()))
+    monkeypatch.setattr(eng, 'forward', fake_forward)
+    out, (xy, mx, idx) = eng._forward_chunked(torch.zeros(13, 3, 64, 64), 1, False, 0, 5)
+    assert seen == [4, 4, 4, 1] and out.shape[0] == 13 and xy.shape == (13, 1, 2) and idx.shape == (13, 1)
+    assert out.view(-1).tolist() == [100., 101., 102., 103., 200., 201., 202., 203., 300., 301., 302., 303., 400.]
+    seen.clear()
+    eng._forward_chunked(torch.zeros(520, 3, 8, 8), None, False, 0, 511)
+    assert seen == [128, 128, 128, 128, 8]
