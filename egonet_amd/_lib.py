@@ -94,6 +94,7 @@ SIGNATURES = {
     'egn_gaussian_targets_f32': (_i, [_p, _p, _i, _i, _i, _i, _d, _d, _d, _p, _p, _p]),
     'egn_ema_f32': (_i, [_p, _p, C.c_float, _i, _p]),
     'egn_adam_step_f32': (_i, [_p, _p, _p, _p, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float, _i, _p]),
+    'egn_step_counters_i64': (_i, [_p, _i, _p, _p]),
     'egn_adam_step_dev_f32': (_i, [_p, _p, _p, _p, C.c_long, _p, C.c_float, C.c_float, C.c_float, _p, _p]),
     'egn_adam_l2_step_dev_f32': (_i, [_p, _p, _p, _p, C.c_long, _p, C.c_float, C.c_float, C.c_float, C.c_float, _p, _p]),
     'egn_sgd_step_dev_f32': (_i, [_p, _p, _p, C.c_long, _p, C.c_float, C.c_float, _p, _p]),

@@ -764,6 +764,22 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
     p[e] -= step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
   }
 }
+// Start-of-step bookkeeping in ONE launch [round 6]: the BatchNorm layers' num_batches_tracked counters (int64, one per
+// layer: `counters` is a device array of their addresses) += 1 and the loss accumulator = 0 -- what the steps did with a
+// torch._foreach_add_ and a tensor.zero_() (two ATen launches on the critical path of a 1.4 ms step).
+// Reference: nn.BatchNorm*d.forward in train mode (libs/model/FCmodel.py:24-43, heatmapModel/hrnet.py:63-92).
+__global__ __launch_bounds__(256) void step_counters_kernel(long long* const* __restrict__ counters, int n,
+                                                            double* __restrict__ zero_f64) {
+  for (int k = threadIdx.x; k < n; k += 256) *counters[k] += 1;
+  if (zero_f64 && threadIdx.x == 0) *zero_f64 = 0.0;
+}
+extern "C" int egn_step_counters_i64(long long* const* counters, int n, double* zero_f64, void* stream) {
+  if (n < 0 || (n > 0 && !counters)) return EGN_E_BADARG;
+  if (n == 0 && !zero_f64) return 0;
+  hipLaunchKernelGGL(step_counters_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counters, n, zero_f64);
+  return (int)hipGetLastError();
+}
+
 extern "C" int egn_adam_step_dev_f32(float* p, const float* g, float* m, float* v, long n, const float* lr_dev,
                                      float beta1, float beta2, float eps, int* step_dev, void* stream) {
   if (n <= 0 || !lr_dev || !step_dev) return EGN_E_BADARG;

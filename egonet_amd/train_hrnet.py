@@ -45,6 +45,26 @@ from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID
 from .engine import Buf, HRNetEngine, _round_up
 
 
+class StepCounters(object):
+    """The BatchNorm layers' ``num_batches_tracked`` += 1 and the loss accumulator = 0 as ONE launch at the start of a
+    native step (``egn_step_counters_i64``) instead of a ``torch._foreach_add_`` and a ``tensor.zero_()`` [round 6]: the
+    device array of the counters' addresses is built once and rebuilt if a buffer moved (``.to()``, ``load_state_dict``
+    onto new storage)."""
+
+    def __init__(self):
+        self.ptrs = None
+        self.table = None
+
+    def tick(self, bns, loss_dev, stream):
+        L = _lib.lib()
+        ptrs = [bn.num_batches_tracked.data_ptr() for bn in bns if bn.num_batches_tracked is not None]
+        if ptrs != self.ptrs:
+            dev = loss_dev.device if loss_dev is not None else bns[0].num_batches_tracked.device
+            self.table = torch.tensor(ptrs, dtype=torch.int64, device=dev) if ptrs else None
+            self.ptrs = ptrs
+        _lib.check(L.egn_step_counters_i64(_lib.ptr(self.table), len(ptrs), _lib.ptr(loss_dev), stream), 'step counters')
+
+
 class FlatParams(object):
     """Trainable parameters as views of one flat fp32 buffer (+ flat grad, m, v)."""
 
@@ -690,6 +710,7 @@ class HRNetTrainStep(TapeOwner):
         self.last_target_weight = None
         self.flat = FlatParams(model.parameters())
         self.loss_dev = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self.counters = StepCounters()
         self.last_maps = self.last_coords = None
 
     @torch.no_grad()
@@ -722,9 +743,8 @@ class HRNetTrainStep(TapeOwner):
             self.packs.pack_all(st)          # every forward / data-gradient filter, one launch
             tape = _Tape(self, images)
             self.walker._record(n, cin, h, w, None, r=tape)
-            torch._foreach_add_([bn.num_batches_tracked for bn in tape.bns], 1)
             J = m.num_joints
-            self.loss_dev.zero_()
+            self.counters.tick(tape.bns, self.loss_dev, st)       # num_batches_tracked += 1, loss = 0: one launch
             if m.head_type == 'coordinates':
                 aug, coords = tape.named['head1'], tape.named['head2.4']
                 cd = tape.user['head2.4'].view(n, 2 * J)          # compact [N, 2K] = coords [N,K,2]

@@ -25,7 +25,7 @@ import torch
 
 from . import _lib, tuner
 from .engine import _round_up, invalidate
-from .train_hrnet import FlatParams
+from .train_hrnet import FlatParams, StepCounters
 
 
 class _Unit(object):
@@ -108,6 +108,7 @@ class LifterTrainStep(object):
         self.zeros = torch.zeros(widest, dtype=torch.float32, device=self.dev)   # conv shift for dgrad / wgrad
         self.L = _lib.lib()
         self.loss_dev = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        self.counters = StepCounters()
         # weight gradients on a side stream, beside the backward chain (as in train_hrnet;
         # EGONET_AMD_WGRAD_STREAM=0: one stream)
         self.wgrad_stream = torch.cuda.Stream(device=self.dev) \
@@ -331,7 +332,8 @@ class LifterTrainStep(object):
                 block_in = out
                 a = out
             ld_a = u.outf
-        torch._foreach_add_([u.bn.num_batches_tracked for u in self.units], 1)
+        if not getattr(self, '_native_tick', False):       # (the native step ticks the counters with the loss reset)
+            torch._foreach_add_([u.bn.num_batches_tracked for u in self.units], 1)
         feat = a
         nf = self.final.in_features
         no = self.final.out_features
@@ -416,10 +418,15 @@ class LifterTrainStep(object):
         with torch.cuda.device(dev):
             st = self._st()
             self._layer_epoch = self._noupdate_forwards        # (0 in a training loop: every step updates)
-            pred, ctx = self._forward(x)
+            # num_batches_tracked += 1 and loss = 0 in one launch (no ATen kernel inside the step)
+            self.counters.tick([u.bn for u in self.units], self.loss_dev, st)
+            self._native_tick = True
+            try:
+                pred, ctx = self._forward(x)
+            finally:
+                self._native_tick = False
             B, no = ctx[0], self.final.out_features
             # loss + gradient of the prediction
-            self.loss_dev.zero_()
             dpred = self._buf('dpred', B, no)
             _lib.check(L.egn_mse_f32(_lib.ptr(pred), _lib.ptr(target), B, no, no, no, 1.0, 0, _lib.ptr(dpred),
                                      _lib.ptr(self.loss_dev), st), 'mse')

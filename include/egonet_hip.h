@@ -484,6 +484,10 @@ int egn_adam_step_f32(float* p, const float* g, float* m, float* v, long n,
  * and the learning rate (lr_dev[0]) in device memory: nothing of the iteration
  * is baked into kernel arguments, so a hipGraph captured around a whole
  * training step replays correctly */
+/* [round 6] start-of-step bookkeeping in one launch: *counters[k] += 1 for the n BatchNorm num_batches_tracked words
+ * (int64; `counters` = device array of their addresses) and *zero_f64 = 0 (the loss accumulator; may be NULL).
+ * Replaces torch's own increment of BatchNorm.num_batches_tracked in train-mode forwards (FCmodel.py:24-43, hrnet.py:63-92). */
+int egn_step_counters_i64(long long* const* counters, int n, double* zero_f64, void* stream);
 int egn_adam_step_dev_f32(float* p, const float* g, float* m, float* v, long n,
                           const float* lr_dev, float beta1, float beta2,
                           float eps, int* step_dev, void* stream);
