@@ -131,6 +131,8 @@ static const ConvConfig kConfigs[] = {
     {89, 6, 1, 1, 3, 17, 64, 7},   // 88 with s_memtime stamps (tools/wino4_clk.py)
     {90, 12, 1, 1, 3, 49, 0, 7},   // (probe builds only: NEGATIVE result) conv_wino4d_kernel [round 6]: 88's two blocks of a CU as the independent halves of ONE 12-wave workgroup (ai bit 5: LDS-counter barriers per half); filter kind 3
     {91, 12, 1, 1, 3, 49, 64, 7},  // 90 with s_memtime stamps (tools/wino4_clk.py)
+    {92, 12, 1, 1, 3, 64, 0, 7},   // (probe builds only: NEGATIVE result) conv_wino4r_kernel [round 6]: F(4x4,3x3) on 16 x 32 regions with ROW-OWNER waves -- the row pass of the output transform in the accumulators, ONE exchange round per item (ai bit 6; conv_wino4r.hip); filter kind 3
+    {93, 12, 1, 1, 3, 64, 64, 7},  // 92 with s_memtime stamps (tools/wino4_clk.py)
 };
 static const int kNumConfigs = sizeof(kConfigs) / sizeof(kConfigs[0]);
 
@@ -154,7 +156,8 @@ extern "C" int egn_conv_config_info(int cfg, int* tile_m, int* tile_n) {
 static bool probe_only(const ConvConfig& c) {
   if (c.dma == 4) return c.id == 41 || c.id == 43;
   if (c.dma == 5) return (c.bi >> 4) != 0 || (c.bi & 15) <= 1 || (c.bi & 15) >= 10;
-  if (c.dma == 7) return c.bi != 0 || (c.ai & 16) != 0;    // stamp builds; the half-block kernels (88 / 90: measured slower, profiles/r6_wino4h_*.txt)
+  // stamp builds; the half-block kernels (88 / 90) and the row-owner kernel (92): measured slower, profiles/r6_wino4h_*.txt, r6_wino4r_probe.txt
+  if (c.dma == 7) return c.bi != 0 || (c.ai & (16 | 64)) != 0;
   return false;
 }
 extern "C" int egn_conv_config_kind(int cfg) {
@@ -185,6 +188,7 @@ extern "C" int egn_conv_config_name(int cfg, char* buf, int len) {
   const ConvConfig& c = kConfigs[cfg - 1];
   if (c.dma == 6) { snprintf(buf, len, "conv_stem_kernel(ConvArgs)"); return 0; }
   if (c.dma == 7 && (c.ai & 3) == 2) { snprintf(buf, len, "void conv_wino4c_kernel<%d, %d>(ConvArgs)", c.bi, (c.ai & 4) ? 2 : 1); return 0; }
+  if (c.dma == 7 && c.ai == 64) { snprintf(buf, len, "void conv_wino4r_kernel<%d>(ConvArgs)", c.bi); return 0; }
   if (c.dma == 7 && c.ai == 49) { snprintf(buf, len, "void conv_wino4d_kernel<%d>(ConvArgs)", c.bi); return 0; }
   if (c.dma == 7 && c.ai == 17) { snprintf(buf, len, "void conv_wino4h_kernel<%d>(ConvArgs)", c.bi); return 0; }
   if (c.dma == 7 && c.ai == 9) { snprintf(buf, len, "void conv_wino4w_kernel<%d>(ConvArgs)", c.bi); return 0; }

@@ -603,7 +603,12 @@ bool egn_conv_wino4h_applies(const ConvArgs& a);
 // bit 5 (geo 49): the two blocks of a CU as the halves of ONE 12-wave workgroup (conv_wino4d_kernel)
 size_t egn_conv_wino4h_lds_bytes(int dual);
 int egn_conv_launch_wino4h(ConvArgs a, size_t lds, int abl, int dual, hipStream_t stream);
+// bit 6 (geo 64) [round 6]: row-owner waves, one exchange round per item, 16 x 32 regions -- conv_wino4r.hip
+bool egn_conv_wino4r_applies(const ConvArgs& a);
+size_t egn_conv_wino4r_lds_bytes();
+int egn_conv_launch_wino4r(ConvArgs a, size_t lds, int abl, hipStream_t stream);
 bool egn_conv_wino4_applies(const ConvArgs& a, int geo) {
+  if (geo & 64) return geo == 64 && egn_conv_wino4r_applies(a);
   if (geo & 16) return (geo == 17 || geo == 49) && egn_conv_wino4h_applies(a);
   if (geo & 8) return geo == 9 && egn_conv_wino4w_applies(a);
   const int g = geo & 3, ks = (geo & 4) ? 2 : 1;
@@ -625,6 +630,7 @@ int egn_conv_wino4_tickets(const ConvArgs& a, int geo) {
   return a.tiles_x * a.tiles_y * ((a.N + nimg - 1) / nimg) * (a.Cout / W4_CO) + 1;
 }
 size_t egn_conv_wino4_lds_bytes(int geo) {      // (+ the stamp area of the ABL & 64 build)
+  if (geo & 64) return egn_conv_wino4r_lds_bytes();
   if (geo & 16) return egn_conv_wino4h_lds_bytes(geo & 32);
   return ((geo & 3) == 2 ? w4_lds_bytes<2>() : w4_lds_bytes<0>()) + 12 * 96 * 8;
 }
@@ -679,7 +685,7 @@ static int w4_grid(int nwork, int nck) {
 }
 // rows of the BatchNorm partial table a launch with ConvArgs::stats writes (a: planned): one per block; 0 = none
 int egn_conv_wino4_stats_rows(const ConvArgs& a, int geo) {
-  if ((geo & 24) || !egn_conv_wino4_applies(a, geo)) return 0;      // (the wide items / half blocks have no training build)
+  if ((geo & (24 | 64)) || !egn_conv_wino4_applies(a, geo)) return 0;      // (the wide items / half blocks have no training build)
   const int g = geo & 3, ks = (geo & 4) ? 2 : 1, nimg = g == 2 ? 4 : 1;
   const int nct = a.Cout / W4_CO;
   const int nreg = a.tiles_x * a.tiles_y * ((a.N + nimg - 1) / nimg);
@@ -723,6 +729,7 @@ static int wino4_launch(ConvArgs a, size_t lds, hipStream_t stream) {
 }
 int egn_conv_launch_wino4(ConvArgs a, size_t lds, int abl, int geo, hipStream_t stream) {
   if (!egn_conv_wino4_applies(a, geo)) return EGN_E_BADARG;
+  if (geo & 64) return a.stats ? EGN_E_BADARG : egn_conv_launch_wino4r(a, lds, abl, stream);
   if (geo & 16) return a.stats ? EGN_E_BADARG : egn_conv_launch_wino4h(a, lds, abl, geo & 32, stream);
   if (geo & 8) return a.stats ? EGN_E_BADARG : egn_conv_launch_wino4w(a, lds, abl, stream);
   if (a.stats) {                       // the training tape: BatchNorm statistics in the item end

@@ -371,6 +371,49 @@ def test_conv_wino4h_kernel(n, h, w, cin, cout, res, act):
 
 
 @pytest.mark.parametrize('n,h,w,cin,cout,res,act', [
+    (2, 16, 32, 16, 48, True, 1),       # one region per image, two 8-channel stages
+    (64, 64, 64, 48, 48, True, 1),      # the 48-channel branch at BASELINE's 64 crops: 512 items
+    (3, 16, 32, 192, 192, True, 1),     # four co-tiles (item mode 1), 24 stages
+    (3, 32, 64, 32, 96, False, 0),      # 2 x 2 regions, 2 co-tiles, no activation, no residual
+    (70, 16, 32, 48, 96, True, 1),      # persistent rounds
+    (5, 32, 32, 96, 384, False, 1),     # eight co-tiles (item mode 2), odd batch
+    (2, 64, 64, 256, 48, False, 1),     # the 256 -> 48 transition's shape class
+])
+def test_conv_wino4r_kernel(n, h, w, cin, cout, res, act):
+    """Config 92, conv_wino4r_kernel (csrc/conv_wino4r.hip, round 6): F(4x4,3x3) on 16 x 32 regions with row-owner waves --
+    the row pass of Y = A^T M A in the accumulators, ONE exchange round per item.  Same transform, K order and filter pack
+    as config 70; the two 1-D passes of the output transform run in the other order, so the outputs agree with config 70
+    to rounding (not bit for bit); oracle and tolerance as config 70 (hrnet.py:49-76).  Deterministic: two runs, same bits."""
+    import ctypes as C
+    from egonet_amd import _lib, ops
+    L = _lib.lib()
+    if not L.egn_probe_build():          # measured slower than config 70 (profiles/r6_wino4r_probe.txt): probe builds only
+        assert L.egn_conv_config_kind(92) == -1
+        pytest.skip('conv_wino4r_kernel is compiled into probe builds only')
+    assert L.egn_conv_config_kind(92) == 3 and L.egn_conv_config_kind(93) == -1
+    out = (C.c_int * 12)()
+    assert L.egn_conv_plan_query(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 0, 92, out) == 0
+    assert list(out)[5:8] == [16, 32, 1] and out[10] == n * (h // 16) * (w // 32)
+    err = _conv_case(n, h, w, cin, cout, 3, 1, 1, act=act, use_res=res, cfg=92, seed=n + h + cin)
+    assert err < 5e-4, err
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    pc = ops.PackedConv(wt, None, _bn(cout, g), kind=3)
+    r = torch.randn(n, h, w, cout, generator=g).cuda() if res else None
+    ya = ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=92)
+    yb = ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=92)
+    yc = ops.conv2d_nhwc(x, pc, cin, 1, 1, act, r, cfg=70)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+    assert (ya - yc).abs().max().item() < 2e-5 * max(1.0, yc.abs().max().item())
+    assert L.egn_conv_plan_query(2, 16, 16, 48, 48, 48, 48, 3, 3, 1, 1, 0, 92, out) != 0      # whole 16 x 32 regions only
+    assert L.egn_conv_plan_query(2, 16, 32, 24, 24, 48, 48, 3, 3, 1, 1, 0, 92, out) != 0
+    assert L.egn_conv2d_bnstats_rows(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 92) == 0
+    assert L.egn_conv2d_ticket_words(n, h, w, cin, cin, cout, cout, 3, 3, 1, 1, 92) == 0
+
+
+@pytest.mark.parametrize('n,h,w,cin,cout,res,act', [
     (2, 16, 16, 32, 48, True, 1),       # one stage per half
     (3, 16, 16, 192, 192, True, 1),     # the 16 x 16 maps of the 192-channel branch at a small batch: 6 stages per half
     (16, 16, 16, 192, 192, True, 1),    # BASELINE configs[4]'s per-GPU shard: 64 regions x 4 co-tiles x 2 halves

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Static check of the F(4x4,3x3) kernels' compiled ISA (csrc/conv_wino4.hip, conv_wino4w.hip, conv_wino4h.hip).
+"""Static check of the F(4x4,3x3) kernels' compiled ISA (csrc/conv_wino4.hip, conv_wino4w.hip, conv_wino4h.hip, conv_wino4r.hip).
 
 The kernel loads its MFMA B operands (the transformed filter) with raw `buffer_load_dword` instructions and
 waits for them with hand-counted `s_waitcnt vmcnt(N)`: the compiler does not know that the destination
@@ -24,9 +24,9 @@ def compile_isa(name='conv_wino4'):
     src = os.path.join(ROOT, 'egonet_amd', 'csrc', name + '.hip')
     out = os.path.join(tempfile.mkdtemp(prefix='w4isa'), name + '.s')
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    # (conv_wino4h.hip's kernels exist in probe builds only)
+    # (conv_wino4h.hip's and conv_wino4r.hip's kernels exist in probe builds only)
     subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-c', '-S', '--cuda-device-only'] +
-                   (['-DEGN_PROBES'] if name == 'conv_wino4h' else []) + ['-o', out, src],
+                   (['-DEGN_PROBES'] if name in ('conv_wino4h', 'conv_wino4r') else []) + ['-o', out, src],
                    check=True, stderr=subprocess.DEVNULL)
     return out
 
@@ -62,7 +62,9 @@ KERNELS = ('conv_wino4_kernelILi0E', 'conv_wino4b_kernelILi0E', 'conv_wino4bk_ke
 KERNELS_W = ('conv_wino4w_kernelILi0E',)
 # conv_wino4h.hip [round 6]: half-size blocks, two per CU
 KERNELS_H = ('conv_wino4h_kernelILi0E', 'conv_wino4d_kernelILi0E')
-FILES = (('conv_wino4', KERNELS), ('conv_wino4w', KERNELS_W), ('conv_wino4h', KERNELS_H))
+# conv_wino4r.hip [round 6]: row-owner waves, one exchange round
+KERNELS_R = ('conv_wino4r_kernelILi0E',)
+FILES = (('conv_wino4', KERNELS), ('conv_wino4w', KERNELS_W), ('conv_wino4h', KERNELS_H), ('conv_wino4r', KERNELS_R))
 
 
 def check(path, kernel='conv_wino4_kernelILi0E'):
