@@ -68,7 +68,21 @@ class FCModel(nn.Module):
         # eval mode + CUDA input: the HIP program, whatever the autograd mode (the reference evaluates with
         # grad enabled, libs/trainer/trainer.py:421) -- unless the caller asks for a graph: an input that
         # requires a gradient, or ``model.hip_eval = False``
-        return x.is_cuda and not self.training and self.hip_eval and not (torch.is_grad_enabled() and x.requires_grad)
+        return x.is_cuda and not self.training and self.hip_eval and not (torch.is_grad_enabled() and x.requires_grad) \
+            and not self._dropout_active()
+
+    def _dropout_active(self):
+        """``model.eval()`` followed by ``Dropout.train()`` on the dropout layers -- the reference's
+        ``testing_settings.apply_dropout`` (libs/trainer/trainer.py:424-428): BatchNorm on running statistics, dropout
+        masks drawn.  The eval-mode HIP program has no dropout, so that state takes the module's torch graph (the
+        reference's own path) instead of silently ignoring the masks [round 6].  The dropout layers are collected once
+        per module tree (heatmapModel.hrnet._TREE_GENERATION)."""
+        from .heatmapModel.hrnet import _TREE_GENERATION
+        cache = self.__dict__.get('_dropouts')
+        if cache is None or cache[0] != _TREE_GENERATION[0]:
+            cache = (_TREE_GENERATION[0], [m for m in self.modules() if isinstance(m, nn.Dropout)])
+            self.__dict__['_dropouts'] = cache
+        return any(m.training and m.p > 0 for m in cache[1])
 
     def _native_autograd_ok(self, x):
         # train mode under autograd (the reference's hot loop, libs/trainer/trainer.py:183-209, unchanged):
@@ -97,6 +111,7 @@ class FCModel(nn.Module):
         state['_engine'] = None
         state.pop('_bridge', None)
         state.pop('_hook_dicts', None)
+        state.pop('_dropouts', None)
         return state
 
     def train(self, mode=True):

@@ -216,9 +216,14 @@ def evaluate(eval_dataset, model, loss_func, cfgs, logger, evaluator, save=False
     ts = cfgs['testing_settings']
     unnorm = bool(ts.get('unnormalize', False))
     stats = eval_dataset.statistics if unnorm else None
-    if ts.get('apply_dropout', False):
-        raise NotImplementedError('testing_settings.apply_dropout: the eval-mode HIP program has no dropout')
     model.eval()
+    if ts.get('apply_dropout', False):
+        # trainer.py:424-428: dropout layers back in train mode ("a loss similar to the training loss"); the model's
+        # forward sees that state and takes its torch graph (FCModel._dropout_active) -- the HIP program has no dropout
+        def apply_dropout(m):
+            if type(m) == torch.nn.Dropout:
+                m.train()
+        model.apply(apply_dropout)
     loader = get_loader(eval_dataset, cfgs, 'testing', collate_fn)
     use_cuda = cfgs.get('use_gpu', True) and torch.cuda.is_available()
     loss_sum, seen = 0.0, 0

@@ -489,6 +489,32 @@ def test_w48_batch_of_520_crops_runs_in_chunks():
     assert torch.isfinite(got).all()
 
 
+def test_lifter_with_apply_dropout_takes_the_torch_graph_not_the_hip_program():
+    """[round 6] trainer.py:424-428: eval mode with the dropout layers switched back to train mode.  The HIP program has
+    no dropout; the module must not run it silently (launch counter unchanged, masks drawn: two calls differ); back in
+    plain eval mode the HIP program runs again."""
+    from egonet_amd import _lib
+    cfg = configs.tiny_config()
+    cfg['FCModel']['dropout'] = 0.5
+    net = hip_fc.get_fc_model(1, cfg, 66, 96)
+    net.load_state_dict(synth.synth_state_dict(net.state_dict(), seed=3))
+    net = net.eval().cuda()
+    x = torch.randn(8, 66, generator=torch.Generator().manual_seed(1)).cuda()
+    L = _lib.lib()
+    n0 = L.egn_launch_count()
+    y0 = net(x)
+    assert L.egn_launch_count() > n0                        # the HIP program
+    for m in net.modules():
+        if type(m) == torch.nn.Dropout:
+            m.train()
+    n1 = L.egn_launch_count()
+    with torch.no_grad():
+        a, b = net(x), net(x)
+    assert L.egn_launch_count() == n1 and not torch.equal(a, b)
+    net.eval()
+    assert torch.equal(net(x), y0) and L.egn_launch_count() > n1
+
+
 def test_layer1_on_the_pw_pair_kernel_equals_the_layerwise_program(monkeypatch):
     """[round 5] engine._layer1: conv3 + residual + ReLU + the next block's conv1 + ReLU as ONE launch of csrc/conv_pw.hip
     (the downsample conv and the last conv3 its one-product form) against the same engine with EGONET_AMD_PW_FUSE=0

@@ -188,3 +188,28 @@ def test_hook_cache_follows_the_module_tree_and_stays_out_of_pickles():
 
 def _noop_hook(module, inputs, output):
     return None
+
+
+def test_apply_dropout_state_is_seen_by_the_lifter():
+    """[round 6] libs/trainer/trainer.py:424-428 (testing_settings.apply_dropout): ``model.eval()`` then ``Dropout.train()``.
+    FCModel._dropout_active reports that state (the eval-mode HIP program has no dropout: such a forward must take the
+    module's torch graph); plain eval / train states do not trigger it, p = 0 never does."""
+    from egonet_amd.model import FCmodel
+    cfg = configs.tiny_config()
+    net = FCmodel.get_fc_model(1, cfg, 10, 12).eval()
+    assert not net._dropout_active()
+
+    def apply_dropout(m):
+        if type(m) == torch.nn.Dropout:
+            m.train()
+    net.apply(apply_dropout)
+    assert net._dropout_active() == (cfg['FCModel']['dropout'] > 0)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.5
+    assert net._dropout_active()
+    a, b = net(torch.ones(4, 10)), net(torch.ones(4, 10))
+    assert not torch.equal(a, b)                 # masks are drawn (CPU tensors run the torch graph anyway)
+    net.eval()
+    assert not net._dropout_active()
+    assert torch.equal(net(torch.ones(4, 10)), net(torch.ones(4, 10)))
