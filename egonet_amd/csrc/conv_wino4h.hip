@@ -1,5 +1,12 @@
 // conv_wino4h.hip -- fused Winograd F(4x4,3x3) in HALF-size blocks, two independent blocks per CU [round 6].
 //
+// OUTCOME: measured NEGATIVE in both forms, kept for probe builds only (-DEGN_PROBES):
+//   conv_wino4h_kernel (two 6-wave workgroups per CU)   64.3 us against conv_wino4_kernel's 51.1 on 48 -> 48 @ 64 x 64, 64 crops:
+//                      the two workgroups of a CU are never resident together (profiles/r6_wino4h_timeline.txt);
+//   conv_wino4d_kernel (two halves of one 12-wave workgroup, LDS-counter barriers)   52.7 us; 118 000 cycles per CU against
+//                      103 000 (profiles/r6_wino4d_timeline.txt).  The start skew (EGN_W4H_SKEW, default 0) changes nothing.
+// What follows is the design as it was built.
+//
 // Why.  An item of conv_wino4_kernel on the 48-channel branch (48 -> 48 @ 64 x 64: 24 % of the forward's kernel time)
 // spends 11 % of its cycles in the prologue (first halo pieces, first transform) and 21 % in the item end (exchange,
 // Y = A^T M A, stores) with the matrix pipe idle (profiles/r3_wino4_timeline_v2.txt; ablation: -28 % without the item
@@ -19,7 +26,7 @@
 //     units 6r .. 6r+5, i.e. 1.5 co sub-tiles), reader wave rw finishes unit 6r + rw: every lane one (tile, co).
 // Phase: two blocks that start together stay in phase (profiles/r3_wino9_kq2_timeline.txt) and would idle the pipe
 // together.  The second block of a CU (its LDS allocation does not start at 0: HW_REG_LDS_ALLOC) therefore starts
-// `skew` x 64 cycles late (ConvArgs::spix_off, set by the launcher; the measured best is in w4h_default_skew).
+// `skew` x 64 cycles late (ConvArgs::spix_off, set by the launcher from EGN_W4H_SKEW; no value helped).
 // Every vector-memory wait is vmcnt(0) (conv_wino4.hip).
 // Reference: the 3x3 stride-1 convolutions of libs/model/heatmapModel/hrnet.py (BasicBlock :49-76).
 #include <stdlib.h>

@@ -1,5 +1,10 @@
 // conv_wino4r.hip -- fused Winograd F(4x4,3x3), "row owner" waves: ONE exchange round per item [round 6].
 //
+// OUTCOME: correct, measured SLOWER than conv_wino4_kernel (54.1 against 50.4 us on 48 -> 48 @ 64 x 64 at 64 crops, 216.7
+// against 192.7 on 256 -> 48: profiles/r6_wino4r_probe.txt) -- probe builds only (-DEGN_PROBES).  The
+// claim below that the doubled filter stream is free did not hold at twelve load instructions per wave and stage.
+// What follows is the design as it was built.
+//
 // conv_wino4_kernel's item end takes 21 % of an item on the 48-channel branch (profiles/r3_wino4_timeline_v2.txt): a wave
 // holds three frequency points of a row of the 6 x 6 grid for BOTH m-tiles, nothing of Y = A^T M A can be formed in its
 // registers, so all 36 points of every (tile, channel) cross the LDS -- 108 KB per m-tile, two rounds of write / barrier /
